@@ -1,0 +1,189 @@
+/* mjs_scene_spec.h — scene constants (DATA ONLY) for the four task scenes.
+ *
+ * Own-authored. Two provenances, marked per block:
+ *   [REF]  derived from the reference's scene-building code, cited file:line
+ *          (paths relative to /root/reference/mujoco_sim/).
+ *   [MEN]  re-authored from the public mujoco_menagerie UR5e / Robotiq 2F-85
+ *          descriptions, which the reference downloads at run time
+ *          (entities/robots/robot.py:311-313, entities/eef/gripper.py:5,37) and
+ *          which are NOT present under /root/reference. Unverified recollection:
+ *          "parity unpinned" for every robot scene.
+ *   [MJ]   MuJoCo engine defaults (third-party, recalled).
+ *
+ * Consumed by oracle/ (CPU restatement, test infrastructure) and by
+ * mujoco_sim_amd/csrc (HIP kernels). Quaternions here are MuJoCo order (w,x,y,z).
+ */
+#ifndef MJS_SCENE_SPEC_H
+#define MJS_SCENE_SPEC_H
+
+#ifdef __cplusplus
+#define MJS_K constexpr
+#else
+#define MJS_K static const
+#endif
+
+/* ------------------------------------------------------------------ [MJ] */
+MJS_K double MJS_GRAVITY_Z = -9.81;
+MJS_K double MJS_MINVAL = 1e-15;               /* mjMINVAL */
+MJS_K double MJS_MAXVAL = 1e10;                /* mjMAXVAL: bad-state threshold */
+MJS_K double MJS_SOLREF_TIMECONST = 0.02;      /* default solref[0] */
+MJS_K double MJS_SOLREF_DAMPRATIO = 1.0;       /* default solref[1] */
+MJS_K double MJS_SOLIMP_D0 = 0.9;              /* default solimp */
+MJS_K double MJS_SOLIMP_DWIDTH = 0.95;
+MJS_K double MJS_SOLIMP_WIDTH = 0.001;
+MJS_K double MJS_SOLIMP_MIDPOINT = 0.5;
+MJS_K double MJS_SOLIMP_POWER = 2.0;
+MJS_K double MJS_SOLVER_TOLERANCE = 1e-8;      /* opt.tolerance */
+MJS_K int    MJS_SOLVER_ITERATIONS = 100;      /* opt.iterations */
+MJS_K double MJS_GEOM_FRICTION_SLIDE = 1.0;    /* default geom friction */
+MJS_K double MJS_GEOM_FRICTION_SPIN = 0.005;
+MJS_K double MJS_GEOM_FRICTION_ROLL = 0.0001;
+MJS_K double MJS_GEOM_DENSITY = 1000.0;
+
+/* ------------------------------------------------- Pointmass-Reach [REF] */
+/* environments/tasks/point_reach.py:24-28 */
+MJS_K double MJS_PM_PHYSICS_DT = 0.02;
+MJS_K double MJS_PM_CONTROL_DT = 0.1;
+MJS_K int    MJS_PM_NSUB = 5;                  /* round(0.1/0.02) */
+MJS_K int    MJS_PM_MAX_CONTROL_STEPS = 50;
+MJS_K double MJS_PM_GOAL_THRESHOLD = 0.02;
+MJS_K double MJS_PM_MAX_STEP_SIZE = 0.05;
+/* entities/pointmass.py:52-55, point_reach.py:80 */
+MJS_K double MJS_PM_RADIUS = 0.05;
+MJS_K double MJS_PM_MASS = 0.1;
+/* entities/arenas/walled_pointmass_arena.py:9-10, mjcf/walled_pointmass_arena.xml:15-19 */
+MJS_K double MJS_PM_ARENA_LO = -0.5;
+MJS_K double MJS_PM_ARENA_HI = 0.5;
+MJS_K double MJS_PM_WALL_Z = 0.02;
+/* point_reach.py:91-93 (target site z set to radius/2 in initialize_episode :136) */
+MJS_K double MJS_PM_TARGET_DEFAULT_POS[3] = {0.25, 0.25, 0.01};
+/* camera geoms point_reach.py:22, entities/camera.py:78-88 (static, never in reach) */
+MJS_K double MJS_PM_CAMERA_POS[3] = {0.0, 0.0, 2.4};
+
+/* ------------------------------------------------------ UR5e arm [MEN] */
+#define MJS_UR_NJ 6
+/* body frame offsets (parent frame), MuJoCo quat order (w,x,y,z), un-normalised
+ * as in the XML; bodies: base, shoulder, upper_arm, forearm, wrist_1..3 */
+#define MJS_UR_NBODY 7
+MJS_K double MJS_UR_BODY_POS[MJS_UR_NBODY][3] = {
+    {0.0, 0.0, 0.0},      /* base (robot_site at world origin, empty_robot_arena.py:22) */
+    {0.0, 0.0, 0.163},    /* shoulder_link  */
+    {0.0, 0.138, 0.0},    /* upper_arm_link */
+    {0.0, -0.131, 0.425}, /* forearm_link   */
+    {0.0, 0.0, 0.392},    /* wrist_1_link   */
+    {0.0, 0.127, 0.0},    /* wrist_2_link   */
+    {0.0, 0.0, 0.1},      /* wrist_3_link   */
+};
+MJS_K double MJS_UR_BODY_QUAT[MJS_UR_NBODY][4] = {
+    {0.0, 0.0, 0.0, -1.0}, /* [REF] entities/robots/robot.py:320 */
+    {1.0, 0.0, 0.0, 0.0},
+    {1.0, 0.0, 1.0, 0.0},
+    {1.0, 0.0, 0.0, 0.0},
+    {1.0, 0.0, 1.0, 0.0},
+    {1.0, 0.0, 0.0, 0.0},
+    {1.0, 0.0, 0.0, 0.0},
+};
+MJS_K double MJS_UR_BODY_MASS[MJS_UR_NBODY] = {4.0, 3.7, 8.393, 2.275, 1.219, 1.219, 0.1889};
+MJS_K double MJS_UR_BODY_IPOS[MJS_UR_NBODY][3] = {
+    {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.2125}, {0.0, 0.0, 0.196},
+    {0.0, 0.127, 0.0}, {0.0, 0.0, 0.1}, {0.0, 0.0771683, 0.0},
+};
+MJS_K double MJS_UR_BODY_IQUAT[MJS_UR_NBODY][4] = {
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0},
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 1},
+};
+MJS_K double MJS_UR_BODY_DIAGINERTIA[MJS_UR_NBODY][3] = {
+    {0.00443333156, 0.00443333156, 0.0072},
+    {0.0102675, 0.0102675, 0.00666},
+    {0.133886, 0.133886, 0.0151074},
+    {0.0311796, 0.0311796, 0.004095},
+    {0.0025599, 0.0025599, 0.0021942},
+    {0.0025599, 0.0025599, 0.0021942},
+    {0.000132134, 9.90863e-05, 9.90863e-05},
+};
+/* joint j lives on body j+1; hinge axes in the body frame; joint pos = body origin */
+MJS_K double MJS_UR_JNT_AXIS[MJS_UR_NJ][3] = {
+    {0, 0, 1}, {0, 1, 0}, {0, 1, 0}, {0, 1, 0}, {0, 0, 1}, {0, 1, 0},
+};
+MJS_K double MJS_UR_JNT_RANGE[MJS_UR_NJ][2] = {
+    {-6.28319, 6.28319}, {-6.28319, 6.28319}, {-3.1415, 3.1415},
+    {-6.28319, 6.28319}, {-6.28319, 6.28319}, {-6.28319, 6.28319},
+};
+MJS_K double MJS_UR_ARMATURE = 0.1;
+/* position servos: force = kp*ctrl - kp*q - kd*qdot, clamped to +-frc
+ * (general actuator, gaintype fixed, biastype affine) */
+MJS_K double MJS_UR_ACT_KP[MJS_UR_NJ] = {2000, 2000, 2000, 500, 500, 500};
+MJS_K double MJS_UR_ACT_KD[MJS_UR_NJ] = {400, 400, 400, 100, 100, 100};
+MJS_K double MJS_UR_ACT_FRC[MJS_UR_NJ] = {150, 150, 150, 28, 28, 28};
+MJS_K double MJS_UR_ACT_CTRLRANGE[MJS_UR_NJ][2] = {
+    {-6.2831, 6.2831}, {-6.2831, 6.2831}, {-3.1415, 3.1415},
+    {-6.2831, 6.2831}, {-6.2831, 6.2831}, {-6.2831, 6.2831},
+};
+/* flange site on wrist_3 ("attachment_site", [REF] robot.py:304-305 names it) */
+MJS_K double MJS_UR_FLANGE_POS[3] = {0.0, 0.1, 0.0};
+MJS_K double MJS_UR_FLANGE_QUAT[4] = {-1.0, 1.0, 0.0, 0.0};
+/* [REF] robot.py:307 */
+MJS_K double MJS_UR_HOME_Q[MJS_UR_NJ] = {-1.5707963267948966, -1.5707963267948966, 1.5707963267948966,
+                                         -1.5707963267948966, -1.5707963267948966, -1.5707963267948966};
+/* arm collision proxies (capsules; last one a cylinder): body index, local pos,
+ * local quat, radius, half-length. Used for contact DETECTION vs the floor. */
+#define MJS_UR_NCOLGEOM 10
+MJS_K int MJS_UR_COL_BODY[MJS_UR_NCOLGEOM] = {1, 2, 2, 3, 3, 4, 5, 5, 6, 6};
+MJS_K int MJS_UR_COL_TYPE[MJS_UR_NCOLGEOM] = {3, 3, 3, 3, 3, 3, 3, 3, 3, 5}; /* 3 capsule, 5 cylinder */
+MJS_K double MJS_UR_COL_POS[MJS_UR_NCOLGEOM][3] = {
+    {0, 0, -0.04}, {0, -0.04, 0}, {0, 0, 0.2}, {0, 0.08, 0}, {0, 0, 0.2},
+    {0, 0.05, 0},  {0, 0, 0.04},  {0, 0.02, 0.1}, {0, 0.08, 0}, {0, 0.08, 0},
+};
+MJS_K double MJS_UR_COL_QUAT[MJS_UR_NCOLGEOM][4] = {
+    {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 0, 0, 0},
+    {1, 1, 0, 0}, {1, 0, 0, 0}, {1, 1, 0, 0}, {1, 1, 0, 0}, {1, 1, 0, 0},
+};
+MJS_K double MJS_UR_COL_SIZE[MJS_UR_NCOLGEOM][2] = {
+    {0.06, 0.06}, {0.06, 0.06}, {0.05, 0.2}, {0.055, 0.06}, {0.038, 0.19},
+    {0.04, 0.07}, {0.04, 0.06}, {0.04, 0.04}, {0.04, 0.02}, {0.04, 0.02},
+};
+
+/* analytic-IK kinematic constants: real UR5e DH (inside third-party
+ * ur_analytic_ik, call site [REF] robot.py:33-37). Differ from the model's own
+ * rounded offsets by ~1 mm; the reference tolerates 1e-2
+ * (test/test_ur_frame_matches_real.py:29). */
+MJS_K double MJS_UR_DH_D1 = 0.1625;
+MJS_K double MJS_UR_DH_A2 = -0.425;
+MJS_K double MJS_UR_DH_A3 = -0.3922;
+MJS_K double MJS_UR_DH_D4 = 0.1333;
+MJS_K double MJS_UR_DH_D5 = 0.0997;
+MJS_K double MJS_UR_DH_D6 = 0.0996;
+
+/* ---------------------------------- end-effectors as attached bodies */
+/* Robotiq 2F-85 lumped into ONE rigid payload body at the flange (deviation D-1,
+ * SURVEY.md §8): the reference attaches the articulated 8-DoF gripper
+ * (robot_reach.py:92-94). Mass/inertia [MEN, approximate]; gravcomp 0 because
+ * gravcomp is set on the arm bodies before the EEF is attached (robot.py:80-82). */
+MJS_K double MJS_G2F85_MASS = 0.925;
+MJS_K double MJS_G2F85_IPOS[3] = {0.0, 0.0, 0.045};
+MJS_K double MJS_G2F85_DIAGINERTIA[3] = {0.0011, 0.0009, 0.0005};
+MJS_K double MJS_G2F85_TCP_Z = 0.174;          /* [REF] gripper.py:46-48 */
+MJS_K double MJS_G2F85_OPEN = 0.085;           /* [REF] gripper.py:50-52 */
+MJS_K double MJS_G2F85_MAX_DRIVER = 0.8;       /* [REF] gripper.py:38 */
+/* cylinder EEF [REF] entities/eef/cylinder.py:17-41 */
+MJS_K double MJS_CYL_RADIUS = 0.02;
+MJS_K double MJS_CYL_HALFLEN = 0.05;
+MJS_K double MJS_CYL_MASS = 0.1;
+MJS_K double MJS_CYL_POS_Z = 0.051;
+MJS_K double MJS_CYL_TCP_Z = 0.1;
+
+/* ------------------------------------------------ Robot-Reach task [REF] */
+/* environments/tasks/robot_reach.py:30,59-68,104,108-110 */
+MJS_K double MJS_RR_PHYSICS_DT = 0.005;
+MJS_K double MJS_RR_CONTROL_DT = 0.1;
+MJS_K int    MJS_RR_NSUB = 20;
+MJS_K int    MJS_RR_MAX_CONTROL_STEPS = 100;
+MJS_K double MJS_RR_GOAL_THRESHOLD = 0.02;
+MJS_K double MJS_RR_SPACE_LO[3] = {-0.1, -0.6, 0.02};
+MJS_K double MJS_RR_SPACE_HI[3] = {0.1, -0.4, 0.2};
+MJS_K double MJS_RR_TARGET_DEFAULT_POS[3] = {0.0, -0.5, 0.001};
+/* TOP_DOWN_QUATERNION, scalar-LAST (x,y,z,w) per type_aliases.py:6-10 */
+MJS_K double MJS_TOP_DOWN_QUAT_XYZW[4] = {1.0, 0.0, 0.0, 0.0};
+MJS_K double MJS_ROBOT_ARENA_HALF = 1.5;       /* EmptyRobotArena(3), empty_robot_arena.py:18-20 */
+
+#endif /* MJS_SCENE_SPEC_H */

@@ -1,0 +1,982 @@
+/* om_engine.c — ORACLE (test infrastructure): scalar float64 restatement of the
+ * MuJoCo pipeline stages the four scenes exercise, i.e. what
+ * `Physics.step()` does underneath the reference's step path
+ * (environments/dmc2gym.py:136 -> composer.Environment.step -> Physics.step;
+ * direct call sites robot_planar_push.py:160-161, test/test_ur_control_api.py:21).
+ *
+ * MuJoCo itself is a third-party dependency absent from /root/reference
+ * (unpinned in setup.py:11-20); this file restates its published algorithms
+ * (MuJoCo documentation, "Computation" chapter; Featherstone 2008 for CRBA/RNEA):
+ *   kinematics -> composite-rigid-body inertia -> collision -> constraint rows
+ *   (equality, joint limit, pyramidal contact) with impedance/reference
+ *   acceleration -> bias forces (RNE), gravity compensation, affine actuators ->
+ *   unconstrained acceleration -> primal Newton solver with exact line search ->
+ *   semi-implicit Euler / implicitfast integration.
+ * Spatial quantities are expressed in world axes about the world origin (MuJoCo
+ * uses the kinematic tree's subtree-COM; a rounding-level difference).
+ * PARITY UNPINNED — see mjs_oracle.h.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "../include/mjs_scene_spec.h"
+#include "mjs_oracle.h"
+
+/* ------------------------------------------------------------ small math */
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static double norm3(const double* a) { return sqrt(dot3(a, a)); }
+static void mulMatVec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mulQuat(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+static void negQuat(double* r, const double* q) { r[0] = q[0]; r[1] = -q[1]; r[2] = -q[2]; r[3] = -q[3]; }
+static void normQuat(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MJS_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void quat2Mat(double* m, const double* q) {
+  double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3];
+  double q11 = q[1] * q[1], q12 = q[1] * q[2], q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q12 - q03); m[2] = 2 * (q13 + q02); m[3] = 2 * (q12 + q03);
+  m[5] = 2 * (q23 - q01); m[6] = 2 * (q13 - q02); m[7] = 2 * (q23 + q01);
+}
+static void rotVecQuat(double* r, const double* v, const double* q) {
+  double m[9];
+  quat2Mat(m, q);
+  mulMatVec3(r, m, v);
+}
+static void axisAngle2Quat(double* q, const double* axis, double angle) {
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+
+/* ----------------------------------------------------------- kinematics */
+/* mj_kinematics: body, joint-anchor, geom and site poses from qpos */
+static void om_kinematics(const om_model* m, om_data* d) {
+  d->xpos[0][0] = d->xpos[0][1] = d->xpos[0][2] = 0;
+  d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  quat2Mat(d->xmat[0], d->xquat[0]);
+  memcpy(d->xipos[0], d->xpos[0], sizeof(double) * 3);
+  memcpy(d->ximat[0], d->xmat[0], sizeof(double) * 9);
+  for (int b = 1; b < m->nbody; b++) {
+    double xpos[3], xquat[4], tmp[3];
+    int p = m->body_parent[b];
+    if (m->body_mocapid[b] >= 0) {
+      memcpy(xpos, d->mocap_pos[m->body_mocapid[b]], sizeof xpos);
+      memcpy(xquat, d->mocap_quat[m->body_mocapid[b]], sizeof xquat);
+      normQuat(xquat);
+    } else {
+      int jadr = m->body_jntadr[b], jnum = m->body_jntnum[b];
+      if (jnum == 1 && m->jnt_type[jadr] == OM_JNT_FREE) {
+        int qa = m->jnt_qposadr[jadr];
+        memcpy(xpos, d->qpos + qa, sizeof xpos);
+        memcpy(xquat, d->qpos + qa + 3, sizeof xquat);
+        normQuat(xquat);
+        memcpy(d->xanchor[jadr], xpos, sizeof xpos);
+        d->xaxis[jadr][0] = 0; d->xaxis[jadr][1] = 0; d->xaxis[jadr][2] = 1;
+      } else {
+        mulMatVec3(tmp, d->xmat[p], m->body_pos[b]);
+        for (int k = 0; k < 3; k++) xpos[k] = d->xpos[p][k] + tmp[k];
+        mulQuat(xquat, d->xquat[p], m->body_quat[b]);
+        for (int j = jadr; j < jadr + jnum; j++) {
+          int qa = m->jnt_qposadr[j];
+          rotVecQuat(d->xaxis[j], m->jnt_axis[j], xquat);
+          rotVecQuat(tmp, m->jnt_pos[j], xquat);
+          for (int k = 0; k < 3; k++) d->xanchor[j][k] = xpos[k] + tmp[k];
+          if (m->jnt_type[j] == OM_JNT_SLIDE) {
+            double dq = d->qpos[qa] - m->qpos0[qa];
+            for (int k = 0; k < 3; k++) xpos[k] += d->xaxis[j][k] * dq;
+          } else if (m->jnt_type[j] == OM_JNT_HINGE) {
+            double qloc[4], q2[4];
+            axisAngle2Quat(qloc, m->jnt_axis[j], d->qpos[qa] - m->qpos0[qa]);
+            mulQuat(q2, xquat, qloc);
+            memcpy(xquat, q2, sizeof q2);
+            rotVecQuat(tmp, m->jnt_pos[j], xquat);
+            for (int k = 0; k < 3; k++) xpos[k] = d->xanchor[j][k] - tmp[k];
+          }
+        }
+      }
+    }
+    normQuat(xquat);
+    memcpy(d->xpos[b], xpos, sizeof xpos);
+    memcpy(d->xquat[b], xquat, sizeof xquat);
+    quat2Mat(d->xmat[b], xquat);
+    mulMatVec3(tmp, d->xmat[b], m->body_ipos[b]);
+    for (int k = 0; k < 3; k++) d->xipos[b][k] = xpos[k] + tmp[k];
+    double iq[4];
+    mulQuat(iq, xquat, m->body_iquat[b]);
+    quat2Mat(d->ximat[b], iq);
+  }
+  for (int g = 0; g < m->ngeom; g++) {
+    int b = m->geom_body[g];
+    double tmp[3], q[4];
+    mulMatVec3(tmp, d->xmat[b], m->geom_pos[g]);
+    for (int k = 0; k < 3; k++) d->geom_xpos[g][k] = d->xpos[b][k] + tmp[k];
+    mulQuat(q, d->xquat[b], m->geom_quat[g]);
+    quat2Mat(d->geom_xmat[g], q);
+  }
+  for (int s = 0; s < m->nsite; s++) {
+    int b = m->site_body[s];
+    double tmp[3], q[4];
+    mulMatVec3(tmp, d->xmat[b], m->site_pos[s]);
+    for (int k = 0; k < 3; k++) d->site_xpos[s][k] = d->xpos[b][k] + tmp[k];
+    mulQuat(q, d->xquat[b], m->site_quat[s]);
+    quat2Mat(d->site_xmat[s], q);
+  }
+}
+
+/* motion subspace of every dof, world axes, about the world origin (role of cdof) */
+static void om_subspaces(const om_model* m, om_data* d) {
+  for (int j = 0; j < m->njnt; j++) {
+    int da = m->jnt_dofadr[j], b = m->jnt_body[j];
+    if (m->jnt_type[j] == OM_JNT_HINGE) {
+      memcpy(d->S[da], d->xaxis[j], sizeof(double) * 3);
+      cross3(d->S[da] + 3, d->xanchor[j], d->xaxis[j]);
+    } else if (m->jnt_type[j] == OM_JNT_SLIDE) {
+      d->S[da][0] = d->S[da][1] = d->S[da][2] = 0;
+      memcpy(d->S[da] + 3, d->xaxis[j], sizeof(double) * 3);
+    } else if (m->jnt_type[j] == OM_JNT_FREE) {
+      /* translational dofs: world axes; rotational dofs: body-local axes through xpos */
+      for (int k = 0; k < 3; k++) {
+        memset(d->S[da + k], 0, sizeof(double) * 6);
+        d->S[da + k][3 + k] = 1;
+        double ax[3] = {d->xmat[b][k], d->xmat[b][3 + k], d->xmat[b][6 + k]};
+        memcpy(d->S[da + 3 + k], ax, sizeof ax);
+        cross3(d->S[da + 3 + k] + 3, d->xpos[b], ax);
+      }
+    }
+  }
+}
+
+/* spatial inertia about the world origin: I (sym 3x3 as xx,xy,xz,yy,yz,zz), h = m*c, mass */
+typedef struct { double I[6], h[3], mass; } sinertia;
+static void om_body_inertia(const om_model* m, const om_data* d, int b, sinertia* s) {
+  const double* R = d->ximat[b];
+  const double* di = m->body_inertia[b];
+  const double* c = d->xipos[b];
+  double mass = m->body_mass[b];
+  /* R diag(di) R^T */
+  double Ic[6];
+  int idx = 0;
+  for (int r = 0; r < 3; r++)
+    for (int cc = r; cc < 3; cc++)
+      Ic[idx++] = R[3 * r] * di[0] * R[3 * cc] + R[3 * r + 1] * di[1] * R[3 * cc + 1] + R[3 * r + 2] * di[2] * R[3 * cc + 2];
+  double c2 = dot3(c, c);
+  s->I[0] = Ic[0] + mass * (c2 - c[0] * c[0]);
+  s->I[1] = Ic[1] - mass * c[0] * c[1];
+  s->I[2] = Ic[2] - mass * c[0] * c[2];
+  s->I[3] = Ic[3] + mass * (c2 - c[1] * c[1]);
+  s->I[4] = Ic[4] - mass * c[1] * c[2];
+  s->I[5] = Ic[5] + mass * (c2 - c[2] * c[2]);
+  for (int k = 0; k < 3; k++) s->h[k] = mass * c[k];
+  s->mass = mass;
+}
+/* spatial momentum/force f = I * v, v = [ang, lin] */
+static void sinertia_mul(double* f, const sinertia* s, const double* v) {
+  double hv[3], wh[3];
+  cross3(hv, s->h, v + 3);
+  cross3(wh, v, s->h);
+  f[0] = s->I[0] * v[0] + s->I[1] * v[1] + s->I[2] * v[2] + hv[0];
+  f[1] = s->I[1] * v[0] + s->I[3] * v[1] + s->I[4] * v[2] + hv[1];
+  f[2] = s->I[2] * v[0] + s->I[4] * v[1] + s->I[5] * v[2] + hv[2];
+  for (int k = 0; k < 3; k++) f[3 + k] = s->mass * v[3 + k] + wh[k];
+}
+/* spatial cross products: motion x motion, motion x* force */
+static void cross_motion(double* r, const double* v, const double* s) {
+  double a[3], b[3], c[3];
+  cross3(a, v, s);
+  cross3(b, v, s + 3);
+  cross3(c, v + 3, s);
+  for (int k = 0; k < 3; k++) { r[k] = a[k]; r[3 + k] = b[k] + c[k]; }
+}
+static void cross_force(double* r, const double* v, const double* f) {
+  double a[3], b[3], c[3];
+  cross3(a, v, f);
+  cross3(b, v + 3, f + 3);
+  cross3(c, v, f + 3);
+  for (int k = 0; k < 3; k++) { r[k] = a[k] + b[k]; r[3 + k] = c[k]; }
+}
+
+/* mj_crb + armature -> dense M; then Cholesky (role of mj_factorM) */
+static int chol_factor(int n, double A[][OM_MAXV], double L[][OM_MAXV]) {
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= L[i][k] * L[j][k];
+      if (i == j) {
+        if (s < MJS_MINVAL) return 0;
+        L[i][i] = sqrt(s);
+      } else
+        L[i][j] = s / L[j][j];
+    }
+  return 1;
+}
+static void chol_solve(int n, double L[][OM_MAXV], double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s / L[i][i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+
+static void om_crb(const om_model* m, om_data* d) {
+  sinertia crb[OM_MAXBODY];
+  for (int b = 0; b < m->nbody; b++) om_body_inertia(m, d, b, &crb[b]);
+  for (int b = m->nbody - 1; b > 0; b--) {
+    int p = m->body_parent[b];
+    for (int k = 0; k < 6; k++) crb[p].I[k] += crb[b].I[k];
+    for (int k = 0; k < 3; k++) crb[p].h[k] += crb[b].h[k];
+    crb[p].mass += crb[b].mass;
+  }
+  for (int i = 0; i < m->nv; i++)
+    for (int j = 0; j < m->nv; j++) d->M[i][j] = 0;
+  for (int i = 0; i < m->nv; i++) {
+    double f[6];
+    sinertia_mul(f, &crb[m->dof_body[i]], d->S[i]);
+    for (int j = i; j >= 0; j = m->dof_parent[j]) {
+      double v = 0;
+      for (int k = 0; k < 6; k++) v += d->S[j][k] * f[k];
+      d->M[i][j] = d->M[j][i] = v;
+    }
+    d->M[i][i] += m->dof_armature[i];
+  }
+  chol_factor(m->nv, d->M, d->Lm);
+}
+
+/* translational / rotational Jacobian of a world point attached to body b */
+static void om_jac(const om_model* m, const om_data* d, int b, const double* p, double jt[3][OM_MAXV], double jr[3][OM_MAXV]) {
+  for (int k = 0; k < 3; k++)
+    for (int i = 0; i < m->nv; i++) { jt[k][i] = 0; jr[k][i] = 0; }
+  while (b > 0 && m->body_dofnum[b] == 0) b = m->body_parent[b];
+  if (b <= 0) return;
+  for (int i = m->body_dofadr[b] + m->body_dofnum[b] - 1; i >= 0; i = m->dof_parent[i]) {
+    double wxp[3];
+    cross3(wxp, d->S[i], p);
+    for (int k = 0; k < 3; k++) { jt[k][i] = d->S[i][3 + k] + wxp[k]; jr[k][i] = d->S[i][k]; }
+  }
+}
+
+/* ------------------------------------------------------------ collision */
+static void make_frame(double* frame) {
+  /* mju_makeFrame: frame[0:3] is the normal; build two tangents */
+  double n = norm3(frame);
+  for (int k = 0; k < 3; k++) frame[k] /= n;
+  double y[3];
+  if (frame[1] > -0.5 && frame[1] < 0.5) { y[0] = 0; y[1] = 1; y[2] = 0; } else { y[0] = 0; y[1] = 0; y[2] = 1; }
+  double dp = dot3(frame, y);
+  for (int k = 0; k < 3; k++) y[k] -= dp * frame[k];
+  n = norm3(y);
+  for (int k = 0; k < 3; k++) frame[3 + k] = y[k] / n;
+  cross3(frame + 6, frame, frame + 3);
+}
+
+static int add_contact(const om_model* m, om_data* d, int g1, int g2, double dist, const double* pos, const double* normal) {
+  if (d->ncon >= OM_MAXCON) return 0;
+  om_contact* c = &d->contact[d->ncon];
+  memset(c, 0, sizeof *c);
+  c->dist = dist;
+  memcpy(c->pos, pos, sizeof(double) * 3);
+  memcpy(c->frame, normal, sizeof(double) * 3);
+  make_frame(c->frame);
+  c->geom1 = g1; c->geom2 = g2;
+  c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+  /* equal priority: friction = element-wise max; solref/solimp: equal solmix -> average (all default here) */
+  double fr[3];
+  for (int k = 0; k < 3; k++) fr[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+  c->friction[0] = c->friction[1] = fr[0]; c->friction[2] = fr[1]; c->friction[3] = c->friction[4] = fr[2];
+  memcpy(c->solref, m->solref, sizeof c->solref);
+  memcpy(c->solimp, m->solimp, sizeof c->solimp);
+  c->includemargin = 0.0; /* margin - gap, both default 0 */
+  c->exclude = (c->dist >= c->includemargin);
+  c->efc_address = -1;
+  d->ncon++;
+  return 1;
+}
+
+/* plane (g1) vs sphere/capsule/cylinder (g2); normal points from plane into the body */
+static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
+  const double* pm = d->geom_xmat[g1];
+  double n[3] = {pm[2], pm[5], pm[8]};
+  const double* pp = d->geom_xpos[g1];
+  const double* gp = d->geom_xpos[g2];
+  const double* gm = d->geom_xmat[g2];
+  const double* sz = m->geom_size[g2];
+  double margin = 0.0, tmp[3], pos[3];
+  if (m->geom_type[g2] == OM_GEOM_SPHERE) {
+    for (int k = 0; k < 3; k++) tmp[k] = gp[k] - pp[k];
+    double cd = dot3(tmp, n);
+    if (cd > margin + sz[0]) return;
+    double dist = cd - sz[0];
+    for (int k = 0; k < 3; k++) pos[k] = gp[k] - n[k] * (sz[0] + 0.5 * dist);
+    add_contact(m, d, g1, g2, dist, pos, n);
+  } else if (m->geom_type[g2] == OM_GEOM_CAPSULE) {
+    /* two end spheres (mjc_PlaneCapsule) */
+    double axis[3] = {gm[2], gm[5], gm[8]};
+    for (int e = -1; e <= 1; e += 2) {
+      double c[3];
+      for (int k = 0; k < 3; k++) c[k] = gp[k] + e * sz[1] * axis[k];
+      for (int k = 0; k < 3; k++) tmp[k] = c[k] - pp[k];
+      double cd = dot3(tmp, n);
+      if (cd > margin + sz[0]) continue;
+      double dist = cd - sz[0];
+      for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (sz[0] + 0.5 * dist);
+      add_contact(m, d, g1, g2, dist, pos, n);
+    }
+  } else if (m->geom_type[g2] == OM_GEOM_CYLINDER) {
+    /* mjc_PlaneCylinder: deepest rim point, then up to two more rim points and the opposite one */
+    double axis[3] = {gm[2], gm[5], gm[8]};
+    for (int k = 0; k < 3; k++) tmp[k] = gp[k] - pp[k];
+    double dist0 = dot3(tmp, n);
+    double prjaxis = dot3(n, axis);
+    if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+    double vec[3];
+    for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
+    double len = norm3(vec);
+    if (len < 1e-12) {
+      /* disk parallel to plane: pick x-axis of the cylinder scaled by radius */
+      for (int k = 0; k < 3; k++) vec[k] = gm[3 * k] * sz[0];
+    } else {
+      for (int k = 0; k < 3; k++) vec[k] *= sz[0] / len;
+    }
+    double prjvec = dot3(vec, n);
+    for (int k = 0; k < 3; k++) axis[k] *= sz[1];
+    prjaxis *= sz[1];
+    int cnt = 0;
+    /* first contact: deepest */
+    double dd = dist0 + prjaxis + prjvec;
+    if (dd > margin) return;
+    for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] + axis[k] - n[k] * dd * 0.5;
+    cnt += add_contact(m, d, g1, g2, dd, pos, n);
+    /* second: opposite end of the axis, same side */
+    dd = dist0 - prjaxis + prjvec;
+    if (dd <= margin) {
+      for (int k = 0; k < 3; k++) pos[k] = gp[k] + vec[k] - axis[k] - n[k] * dd * 0.5;
+      cnt += add_contact(m, d, g1, g2, dd, pos, n);
+    }
+    /* two side points of the lower disk */
+    double side[3];
+    cross3(side, vec, axis);
+    double sl = norm3(side);
+    if (sl > 1e-12) {
+      for (int k = 0; k < 3; k++) side[k] *= sz[0] * sqrt(3.0) * 0.5 / sl;
+      dd = dist0 + prjaxis - 0.5 * prjvec;
+      if (dd <= margin) {
+        for (int s = -1; s <= 1; s += 2) {
+          for (int k = 0; k < 3; k++) pos[k] = gp[k] + s * side[k] + axis[k] - 0.5 * vec[k] - n[k] * dd * 0.5;
+          cnt += add_contact(m, d, g1, g2, dd, pos, n);
+        }
+      }
+    }
+    (void)cnt;
+  }
+}
+
+static int body_weld(const om_model* m, int b) { return m->body_weldid[b]; }
+
+static void om_collision(const om_model* m, om_data* d) {
+  d->ncon = 0;
+  for (int g1 = 0; g1 < m->ngeom; g1++)
+    for (int g2 = g1 + 1; g2 < m->ngeom; g2++) {
+      int b1 = m->geom_body[g1], b2 = m->geom_body[g2];
+      int w1 = body_weld(m, b1), w2 = body_weld(m, b2);
+      if (w1 == w2) continue; /* same (welded) body, incl. static-static */
+      if (!((m->geom_contype[g1] & m->geom_conaffinity[g2]) || (m->geom_contype[g2] & m->geom_conaffinity[g1]))) continue;
+      if (w1 != 0 && w2 != 0) {
+        int p1 = body_weld(m, m->body_parent[w1]), p2 = body_weld(m, m->body_parent[w2]);
+        if (w1 == p2 || w2 == p1) continue; /* parent-child filter */
+      }
+      int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+      if (t1 == OM_GEOM_PLANE && t2 != OM_GEOM_PLANE) collide_plane(m, d, g1, g2);
+      else if (t2 == OM_GEOM_PLANE && t1 != OM_GEOM_PLANE) collide_plane(m, d, g2, g1);
+      /* other pairs: not needed by the Pointmass / Robot-Reach scenes */
+    }
+}
+
+/* ----------------------------------------------------- constraint rows */
+static int add_row(om_data* d, int nv, const double* J, double pos, double margin, int type, int id) {
+  if (d->nefc >= OM_MAXEFC) return -1;
+  int r = d->nefc++;
+  memcpy(d->efc_J[r], J, sizeof(double) * nv);
+  d->efc_pos[r] = pos; d->efc_margin[r] = margin; d->efc_type[r] = type; d->efc_id[r] = id;
+  return r;
+}
+
+static void om_make_constraint(const om_model* m, om_data* d) {
+  int nv = m->nv;
+  d->nefc = d->ne = d->nl = 0;
+  double jt1[3][OM_MAXV], jr1[3][OM_MAXV], jt2[3][OM_MAXV], jr2[3][OM_MAXV], J[OM_MAXV];
+  /* equality: weld (mj_instantiateEquality, mjEQ_WELD) */
+  for (int e = 0; e < m->neq; e++) {
+    int b1 = m->eq_body1[e], b2 = m->eq_body2[e];
+    const double* data = m->eq_data[e];
+    double pos0[3], pos1[3], tmp[3], cpos[6];
+    mulMatVec3(tmp, d->xmat[b1], data + 3);
+    for (int k = 0; k < 3; k++) pos0[k] = d->xpos[b1][k] + tmp[k];
+    mulMatVec3(tmp, d->xmat[b2], data);
+    for (int k = 0; k < 3; k++) pos1[k] = d->xpos[b2][k] + tmp[k];
+    for (int k = 0; k < 3; k++) cpos[k] = pos0[k] - pos1[k];
+    om_jac(m, d, b1, pos0, jt1, jr1);
+    om_jac(m, d, b2, pos1, jt2, jr2);
+    double torquescale = data[10];
+    double quat[4], quat1[4], quat2[4];
+    mulQuat(quat, d->xquat[b1], data + 6);
+    negQuat(quat1, d->xquat[b2]);
+    mulQuat(quat2, quat1, quat);
+    for (int k = 0; k < 3; k++) cpos[3 + k] = quat2[1 + k] * torquescale;
+    for (int k = 0; k < 3; k++) {
+      for (int i = 0; i < nv; i++) J[i] = jt1[k][i] - jt2[k][i];
+      add_row(d, nv, J, cpos[k], 0, OM_CNSTR_EQUALITY, e);
+    }
+    /* rotational rows: 0.5 * neg(q2) * (jr1-jr2) * q1 * relpose, axis part, scaled */
+    double Jrot[3][OM_MAXV];
+    for (int i = 0; i < nv; i++) {
+      double ax[4] = {0, jr1[0][i] - jr2[0][i], jr1[1][i] - jr2[1][i], jr1[2][i] - jr2[2][i]};
+      double q3[4], q4[4];
+      mulQuat(q3, ax, quat);
+      mulQuat(q4, quat1, q3);
+      for (int k = 0; k < 3; k++) Jrot[k][i] = 0.5 * q4[1 + k] * torquescale;
+    }
+    for (int k = 0; k < 3; k++) add_row(d, nv, Jrot[k], cpos[3 + k], 0, OM_CNSTR_EQUALITY, e);
+  }
+  d->ne = d->nefc;
+  /* joint limits (mj_instantiateLimit): lower side first */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j]) continue;
+    if (m->jnt_type[j] != OM_JNT_HINGE && m->jnt_type[j] != OM_JNT_SLIDE) continue;
+    double value = d->qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[j][(side + 1) / 2] - value);
+      if (dist < margin) {
+        memset(J, 0, sizeof(double) * nv);
+        J[m->jnt_dofadr[j]] = -side;
+        add_row(d, nv, J, dist, margin, OM_CNSTR_LIMIT_JOINT, j);
+      }
+    }
+  }
+  d->nl = d->nefc - d->ne;
+  /* contacts (mj_instantiateContact), pyramidal cone */
+  for (int c = 0; c < d->ncon; c++) {
+    om_contact* con = &d->contact[c];
+    if (con->exclude) continue;
+    int b1 = m->geom_body[con->geom1], b2 = m->geom_body[con->geom2];
+    om_jac(m, d, b1, con->pos, jt1, jr1);
+    om_jac(m, d, b2, con->pos, jt2, jr2);
+    /* rows of the contact frame applied to (jac2 - jac1) */
+    double Jc[6][OM_MAXV];
+    int allzero = 1;
+    for (int r = 0; r < 3; r++)
+      for (int i = 0; i < nv; i++) {
+        double vt = 0, vr = 0;
+        for (int k = 0; k < 3; k++) {
+          vt += con->frame[3 * r + k] * (jt2[k][i] - jt1[k][i]);
+          vr += con->frame[3 * r + k] * (jr2[k][i] - jr1[k][i]);
+        }
+        Jc[r][i] = vt; Jc[3 + r][i] = vr;
+        if (vt != 0 || (con->dim > 3 && vr != 0)) allzero = 0;
+      }
+    if (allzero) { con->exclude = 3; continue; } /* no dofs */
+    con->efc_address = d->nefc;
+    if (con->dim == 1) {
+      add_row(d, nv, Jc[0], con->dist, con->includemargin, OM_CNSTR_CONTACT_FRICTIONLESS, c);
+    } else {
+      for (int k = 1; k < con->dim; k++) {
+        /* Jc row order: normal, tangent1, tangent2, torsion(=rot normal), roll1, roll2 */
+        const double* Jk = (k < 3) ? Jc[k] : Jc[k];
+        double mu = con->friction[k - 1];
+        for (int s = 1; s >= -1; s -= 2) {
+          for (int i = 0; i < nv; i++) J[i] = Jc[0][i] + s * mu * Jk[i];
+          add_row(d, nv, J, con->dist, con->includemargin, OM_CNSTR_CONTACT_PYRAMIDAL, c);
+        }
+      }
+    }
+  }
+}
+
+/* mj_makeImpedance helper */
+static void get_impedance(const double* solimp, double pos, double margin, double* imp, double* impP) {
+  if (solimp[0] == solimp[1] || solimp[2] <= MJS_MINVAL) { *imp = 0.5 * (solimp[0] + solimp[1]); *impP = 0; return; }
+  double x = (pos - margin) / solimp[2], sgn = 1;
+  if (x < 0) { x = -x; sgn = -1; }
+  if (x >= 1 || x <= 0) { *imp = (x >= 1 ? solimp[1] : solimp[0]); *impP = 0; return; }
+  double y, yP;
+  if (solimp[4] == 1) { y = x; yP = 1; }
+  else if (x <= solimp[3]) {
+    double a = 1 / pow(solimp[3], solimp[4] - 1);
+    y = a * pow(x, solimp[4]); yP = solimp[4] * a * pow(x, solimp[4] - 1);
+  } else {
+    double b = 1 / pow(1 - solimp[3], solimp[4] - 1);
+    y = 1 - b * pow(1 - x, solimp[4]); yP = solimp[4] * b * pow(1 - x, solimp[4] - 1);
+  }
+  *imp = solimp[0] + y * (solimp[1] - solimp[0]);
+  *impP = yP * sgn * (solimp[1] - solimp[0]) / solimp[2];
+}
+
+/* mj_diagApprox + mj_makeImpedance + mj_referenceConstraint (aref needs efc_vel) */
+static void om_make_impedance(const om_model* m, om_data* d) {
+  int nv = m->nv;
+  /* diagApprox from body/dof inverse weights at qpos0 */
+  for (int i = 0; i < d->nefc; i++) {
+    int id = d->efc_id[i];
+    if (d->efc_type[i] == OM_CNSTR_EQUALITY) {
+      int b1 = m->eq_body1[id], b2 = m->eq_body2[id];
+      double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+      double rot = m->body_invweight0[b1][1] + m->body_invweight0[b2][1];
+      for (int k = 0; k < 3; k++) { d->efc_diagApprox[i + k] = tran; d->efc_diagApprox[i + 3 + k] = rot; }
+      i += 5;
+    } else if (d->efc_type[i] == OM_CNSTR_LIMIT_JOINT) {
+      d->efc_diagApprox[i] = m->dof_invweight0[m->jnt_dofadr[id]];
+    } else {
+      const om_contact* con = &d->contact[id];
+      int b1 = m->geom_body[con->geom1], b2 = m->geom_body[con->geom2];
+      double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+      double rot = m->body_invweight0[b1][1] + m->body_invweight0[b2][1];
+      if (d->efc_type[i] == OM_CNSTR_CONTACT_FRICTIONLESS) d->efc_diagApprox[i] = tran;
+      else {
+        int nrow = 2 * (con->dim - 1);
+        for (int j = 0; j < nrow; j++) {
+          double fri = con->friction[j / 2];
+          d->efc_diagApprox[i + j] = tran + fri * fri * (j < 4 ? tran : rot);
+        }
+        i += nrow - 1;
+      }
+    }
+  }
+  for (int i = 0; i < d->nefc;) {
+    int id = d->efc_id[i], dim = 1;
+    double pos = d->efc_pos[i], solref[2], solimp[5];
+    memcpy(solref, m->solref, sizeof solref);
+    memcpy(solimp, m->solimp, sizeof solimp);
+    if (d->efc_type[i] == OM_CNSTR_EQUALITY) {
+      memcpy(solref, m->eq_solref[id], sizeof solref);
+      memcpy(solimp, m->eq_solimp[id], sizeof solimp);
+      dim = 6; pos = 0;
+      for (int k = 0; k < 6; k++) pos += d->efc_pos[i + k] * d->efc_pos[i + k];
+      pos = sqrt(pos); /* getposdim: weld uses the norm of the 6-vector residual */
+    } else if (d->efc_type[i] == OM_CNSTR_CONTACT_PYRAMIDAL) {
+      const om_contact* con = &d->contact[id];
+      memcpy(solref, con->solref, sizeof solref);
+      memcpy(solimp, con->solimp, sizeof solimp);
+      dim = 2 * (con->dim - 1);
+    } else if (d->efc_type[i] == OM_CNSTR_CONTACT_FRICTIONLESS) {
+      memcpy(solref, d->contact[id].solref, sizeof solref);
+      memcpy(solimp, d->contact[id].solimp, sizeof solimp);
+    }
+    /* refsafe */
+    if (solref[0] > 0 && solref[0] < 2 * m->dt) solref[0] = 2 * m->dt;
+    double imp, impP;
+    get_impedance(solimp, pos, d->efc_margin[i], &imp, &impP);
+    double K, B, dmax = solimp[1];
+    if (solref[0] > 0) {
+      K = 1 / fmax(MJS_MINVAL, dmax * dmax * solref[0] * solref[0] * solref[1] * solref[1]);
+      B = 2 / fmax(MJS_MINVAL, dmax * solref[0]);
+    } else { K = -solref[0] / fmax(MJS_MINVAL, dmax * dmax); B = -solref[1] / fmax(MJS_MINVAL, dmax); }
+    for (int j = 0; j < dim; j++) {
+      d->efc_R[i + j] = fmax(MJS_MINVAL, (1 - imp) * d->efc_diagApprox[i + j] / imp);
+      d->efc_KBIP[i + j][0] = K; d->efc_KBIP[i + j][1] = B; d->efc_KBIP[i + j][2] = imp; d->efc_KBIP[i + j][3] = impP;
+    }
+    if (d->efc_type[i] == OM_CNSTR_CONTACT_PYRAMIDAL) {
+      om_contact* con = &d->contact[id];
+      con->mu = con->friction[0] * sqrt(1 / m->impratio);
+      double Rpy = 2 * con->mu * con->mu * d->efc_R[i];
+      for (int j = 0; j < dim; j++) d->efc_R[i + j] = Rpy;
+    }
+    for (int j = 0; j < dim; j++) d->efc_D[i + j] = 1 / d->efc_R[i + j];
+    i += dim;
+  }
+  (void)nv;
+}
+
+static void om_reference_constraint(const om_model* m, om_data* d) {
+  for (int i = 0; i < d->nefc; i++) {
+    double v = 0;
+    for (int k = 0; k < m->nv; k++) v += d->efc_J[i][k] * d->qvel[k];
+    d->efc_vel[i] = v;
+    d->efc_aref[i] = -d->efc_KBIP[i][1] * v - d->efc_KBIP[i][0] * d->efc_KBIP[i][2] * (d->efc_pos[i] - d->efc_margin[i]);
+  }
+}
+
+/* ------------------------------------------------ velocity / force stages */
+static void om_com_vel(const om_model* m, om_data* d) {
+  memset(d->cvel[0], 0, sizeof d->cvel[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    memcpy(d->cvel[b], d->cvel[m->body_parent[b]], sizeof d->cvel[b]);
+    for (int i = m->body_dofadr[b]; i < m->body_dofadr[b] + m->body_dofnum[b]; i++)
+      for (int k = 0; k < 6; k++) d->cvel[b][k] += d->S[i][k] * d->qvel[i];
+  }
+}
+
+/* mj_rne with flg_acc=0: Coriolis/centrifugal + gravity */
+static void om_rne_bias(const om_model* m, om_data* d) {
+  double cacc[OM_MAXBODY][6], cfrc[OM_MAXBODY][6];
+  memset(cacc[0], 0, sizeof cacc[0]);
+  for (int k = 0; k < 3; k++) cacc[0][3 + k] = -m->gravity[k];
+  memset(cfrc[0], 0, sizeof cfrc[0]);
+  for (int b = 1; b < m->nbody; b++) {
+    int p = m->body_parent[b];
+    double v[6];
+    memcpy(cacc[b], cacc[p], sizeof cacc[b]);
+    memcpy(v, d->cvel[p], sizeof v);
+    for (int i = m->body_dofadr[b]; i < m->body_dofadr[b] + m->body_dofnum[b]; i++) {
+      double sd[6];
+      int j = m->dof_jnt[i];
+      if (m->jnt_type[j] == OM_JNT_FREE && i - m->jnt_dofadr[j] < 3) memset(sd, 0, sizeof sd);
+      else if (m->jnt_type[j] == OM_JNT_FREE) cross_motion(sd, d->cvel[b], d->S[i]); /* local axes move with the body */
+      else cross_motion(sd, v, d->S[i]);
+      for (int k = 0; k < 6; k++) { cacc[b][k] += sd[k] * d->qvel[i]; v[k] += d->S[i][k] * d->qvel[i]; }
+    }
+    sinertia I;
+    om_body_inertia(m, d, b, &I);
+    double Ia[6], Iv[6], vIv[6];
+    sinertia_mul(Ia, &I, cacc[b]);
+    sinertia_mul(Iv, &I, d->cvel[b]);
+    cross_force(vIv, d->cvel[b], Iv);
+    for (int k = 0; k < 6; k++) cfrc[b][k] = Ia[k] + vIv[k];
+  }
+  for (int b = m->nbody - 1; b > 0; b--)
+    for (int k = 0; k < 6; k++) cfrc[m->body_parent[b]][k] += cfrc[b][k];
+  for (int i = 0; i < m->nv; i++) {
+    double v = 0;
+    for (int k = 0; k < 6; k++) v += d->S[i][k] * cfrc[m->dof_body[i]][k];
+    d->qfrc_bias[i] = v;
+  }
+}
+
+/* mj_passive: joint damping is added implicitly by the integrators' derivative;
+ * here: damper force + gravity compensation (mj_gravcomp) */
+static void om_passive(const om_model* m, om_data* d) {
+  for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+  for (int b = 1; b < m->nbody; b++) {
+    if (m->body_gravcomp[b] == 0) continue;
+    double F[3], jt[3][OM_MAXV], jr[3][OM_MAXV];
+    for (int k = 0; k < 3; k++) F[k] = -m->gravity[k] * m->body_mass[b] * m->body_gravcomp[b];
+    om_jac(m, d, b, d->xipos[b], jt, jr);
+    for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] += jt[0][i] * F[0] + jt[1][i] * F[1] + jt[2][i] * F[2];
+  }
+}
+
+/* mj_fwdActuation: fixed gain, affine bias, joint transmission, force clamp */
+static void om_actuation(const om_model* m, om_data* d) {
+  for (int i = 0; i < m->nv; i++) d->qfrc_actuator[i] = 0;
+  for (int u = 0; u < m->nu; u++) {
+    int j = m->act_jnt[u];
+    double ctrl = d->ctrl[u];
+    if (m->act_ctrllimited[u]) ctrl = fmin(fmax(ctrl, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
+    double len = d->qpos[m->jnt_qposadr[j]], vel = d->qvel[m->jnt_dofadr[j]];
+    double f = m->act_gain[u] * ctrl + m->act_bias[u][0] + m->act_bias[u][1] * len + m->act_bias[u][2] * vel;
+    if (m->act_forcelimited[u]) f = fmin(fmax(f, m->act_forcerange[u][0]), m->act_forcerange[u][1]);
+    d->actuator_force[u] = f;
+    d->qfrc_actuator[m->jnt_dofadr[j]] += f;
+  }
+}
+
+/* ------------------------------------------------------ Newton solver */
+typedef struct {
+  double cost, gauss;
+} cstate;
+
+static double constraint_update(const om_model* m, om_data* d, const double* jar, const double* qacc, const double* Ma, int* active, double* force) {
+  double cost = 0;
+  for (int i = 0; i < d->nefc; i++) {
+    int act = (d->efc_type[i] == OM_CNSTR_EQUALITY) ? 1 : (jar[i] < 0);
+    active[i] = act;
+    force[i] = act ? -d->efc_D[i] * jar[i] : 0;
+    if (act) cost += 0.5 * d->efc_D[i] * jar[i] * jar[i];
+  }
+  double gauss = 0;
+  for (int i = 0; i < m->nv; i++) gauss += (Ma[i] - d->qfrc_smooth[i]) * (qacc[i] - d->qacc_smooth[i]);
+  return cost + 0.5 * gauss;
+}
+
+/* exact minimiser of the piecewise-quadratic cost along `search` (role of PrimalSearch) */
+static double line_search(const om_model* m, const om_data* d, const double* jar, const double* jv, double g1, double g2) {
+  double alpha = 0, lo = 0, hi = INFINITY;
+  for (int it = 0; it < 50; it++) {
+    double d1 = g1 + alpha * g2, d2 = g2;
+    for (int i = 0; i < d->nefc; i++) {
+      double x = jar[i] + alpha * jv[i];
+      if (d->efc_type[i] == OM_CNSTR_EQUALITY || x < 0) { d1 += d->efc_D[i] * x * jv[i]; d2 += d->efc_D[i] * jv[i] * jv[i]; }
+    }
+    if (d1 < 0) lo = alpha; else hi = alpha;
+    if (d2 <= 0) break;
+    double step = -d1 / d2;
+    double next = alpha + step;
+    if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+    if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+    alpha = next;
+  }
+  (void)m;
+  return alpha;
+}
+
+static void om_solve_constraint(const om_model* m, om_data* d) {
+  int nv = m->nv, nefc = d->nefc;
+  if (nefc == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof(double) * nv);
+    memset(d->qfrc_constraint, 0, sizeof(double) * nv);
+    d->solver_niter = 0;
+    return;
+  }
+  static __thread double jar[OM_MAXEFC], jv[OM_MAXEFC], force[OM_MAXEFC], H[OM_MAXV][OM_MAXV], Lh[OM_MAXV][OM_MAXV];
+  static __thread int active[OM_MAXEFC];
+  double qacc[OM_MAXV], Ma[OM_MAXV], grad[OM_MAXV], search[OM_MAXV], Mv[OM_MAXV];
+  /* warmstart: pick the cheaper of qacc_warmstart and qacc_smooth */
+  double best = INFINITY;
+  for (int trial = 0; trial < 2; trial++) {
+    const double* q0 = trial == 0 ? d->qacc_warmstart : d->qacc_smooth;
+    double ma[OM_MAXV], jr[OM_MAXEFC];
+    for (int i = 0; i < nv; i++) { ma[i] = 0; for (int k = 0; k < nv; k++) ma[i] += d->M[i][k] * q0[k]; }
+    for (int i = 0; i < nefc; i++) { jr[i] = -d->efc_aref[i]; for (int k = 0; k < nv; k++) jr[i] += d->efc_J[i][k] * q0[k]; }
+    double c = constraint_update(m, d, jr, q0, ma, active, force);
+    if (c < best) { best = c; memcpy(qacc, q0, sizeof(double) * nv); }
+  }
+  for (int i = 0; i < nv; i++) { Ma[i] = 0; for (int k = 0; k < nv; k++) Ma[i] += d->M[i][k] * qacc[k]; }
+  for (int i = 0; i < nefc; i++) { jar[i] = -d->efc_aref[i]; for (int k = 0; k < nv; k++) jar[i] += d->efc_J[i][k] * qacc[k]; }
+  double cost = constraint_update(m, d, jar, qacc, Ma, active, force);
+  double scale = 1 / (m->meaninertia * (nv > 1 ? nv : 1));
+  int iter = 0;
+  for (; iter < m->iterations; iter++) {
+    /* gradient, Hessian, Newton direction */
+    for (int i = 0; i < nv; i++) {
+      grad[i] = Ma[i] - d->qfrc_smooth[i];
+      for (int r = 0; r < nefc; r++) grad[i] -= d->efc_J[r][i] * force[r];
+    }
+    for (int i = 0; i < nv; i++)
+      for (int j = 0; j <= i; j++) {
+        double h = d->M[i][j];
+        for (int r = 0; r < nefc; r++)
+          if (active[r]) h += d->efc_J[r][i] * d->efc_D[r] * d->efc_J[r][j];
+        H[i][j] = H[j][i] = h;
+      }
+    if (!chol_factor(nv, H, Lh)) break;
+    for (int i = 0; i < nv; i++) search[i] = -grad[i];
+    chol_solve(nv, Lh, search);
+    /* line search */
+    double g1 = 0, g2 = 0, snorm = 0;
+    for (int i = 0; i < nv; i++) { Mv[i] = 0; for (int k = 0; k < nv; k++) Mv[i] += d->M[i][k] * search[k]; }
+    for (int i = 0; i < nv; i++) { g1 += search[i] * (Ma[i] - d->qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    for (int r = 0; r < nefc; r++) { jv[r] = 0; for (int k = 0; k < nv; k++) jv[r] += d->efc_J[r][k] * search[k]; }
+    double alpha = line_search(m, d, jar, jv, g1, g2);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) { qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+    for (int r = 0; r < nefc; r++) jar[r] += alpha * jv[r];
+    double oldcost = cost;
+    cost = constraint_update(m, d, jar, qacc, Ma, active, force);
+    double gn = 0;
+    for (int i = 0; i < nv; i++) {
+      double g = Ma[i] - d->qfrc_smooth[i];
+      for (int r = 0; r < nefc; r++) g -= d->efc_J[r][i] * force[r];
+      gn += g * g;
+    }
+    double improvement = scale * (oldcost - cost), gradient = scale * sqrt(gn);
+    if (improvement < m->tolerance || gradient < m->tolerance) { iter++; break; }
+  }
+  d->solver_niter = iter;
+  memcpy(d->qacc, qacc, sizeof(double) * nv);
+  memcpy(d->efc_force, force, sizeof(double) * nefc);
+  for (int i = 0; i < nv; i++) {
+    double f = 0;
+    for (int r = 0; r < nefc; r++) f += d->efc_J[r][i] * force[r];
+    d->qfrc_constraint[i] = f;
+  }
+}
+
+/* ------------------------------------------------------------ pipeline */
+static void om_fwd_position(const om_model* m, om_data* d) {
+  om_kinematics(m, d);
+  om_subspaces(m, d);
+  om_crb(m, d);
+  om_collision(m, d);
+  om_make_constraint(m, d);
+  om_make_impedance(m, d);
+}
+static void om_fwd_velocity(const om_model* m, om_data* d) {
+  om_com_vel(m, d);
+  om_passive(m, d);
+  om_rne_bias(m, d);
+  om_reference_constraint(m, d);
+}
+static void om_fwd_acceleration(const om_model* m, om_data* d) {
+  for (int i = 0; i < m->nv; i++) {
+    d->qfrc_smooth[i] = d->qfrc_passive[i] - d->qfrc_bias[i] + d->qfrc_actuator[i];
+    d->qacc_smooth[i] = d->qfrc_smooth[i];
+  }
+  chol_solve(m->nv, d->Lm, d->qacc_smooth);
+}
+
+static void integrate_pos(const om_model* m, om_data* d, double dt) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == OM_JNT_FREE) {
+      for (int k = 0; k < 3; k++) d->qpos[qa + k] += dt * d->qvel[da + k];
+      double w[3] = {d->qvel[da + 3], d->qvel[da + 4], d->qvel[da + 5]};
+      double ang = norm3(w);
+      if (ang >= MJS_MINVAL) {
+        double ax[3] = {w[0] / ang, w[1] / ang, w[2] / ang}, qr[4], qn[4];
+        axisAngle2Quat(qr, ax, ang * dt);
+        normQuat(d->qpos + qa + 3);
+        mulQuat(qn, d->qpos + qa + 3, qr);
+        memcpy(d->qpos + qa + 3, qn, sizeof qn);
+      }
+      normQuat(d->qpos + qa + 3);
+    } else
+      d->qpos[qa] += dt * d->qvel[da];
+  }
+}
+
+static void om_check_state(const om_model* m, om_data* d) {
+  for (int i = 0; i < m->nq; i++)
+    if (!isfinite(d->qpos[i]) || fabs(d->qpos[i]) > MJS_MAXVAL) d->warning_bad = 1;
+  for (int i = 0; i < m->nv; i++) {
+    if (!isfinite(d->qvel[i]) || fabs(d->qvel[i]) > MJS_MAXVAL) d->warning_bad = 1;
+    if (!isfinite(d->qacc[i]) || fabs(d->qacc[i]) > MJS_MAXVAL) d->warning_bad = 1;
+  }
+}
+
+void om_step1(const om_model* m, om_data* d) {
+  om_fwd_position(m, d);
+  om_fwd_velocity(m, d);
+}
+
+void om_step2(const om_model* m, om_data* d) {
+  int nv = m->nv;
+  om_actuation(m, d);
+  om_fwd_acceleration(m, d);
+  om_solve_constraint(m, d);
+  om_check_state(m, d);
+  memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
+  double qacc[OM_MAXV];
+  if (m->integrator == OM_INT_IMPLICITFAST) {
+    /* mj_implicit (fast): (M - dt*dF/dv) qacc = qfrc_smooth + qfrc_constraint; dF/dv from
+     * joint damping and the velocity term of unclamped affine actuators (mjd_smooth_vel) */
+    double A[OM_MAXV][OM_MAXV], L[OM_MAXV][OM_MAXV];
+    for (int i = 0; i < nv; i++) {
+      for (int j = 0; j < nv; j++) A[i][j] = d->M[i][j];
+      A[i][i] += m->dt * m->dof_damping[i];
+      qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+    }
+    for (int u = 0; u < m->nu; u++) {
+      if (m->act_forcelimited[u] && (d->actuator_force[u] <= m->act_forcerange[u][0] || d->actuator_force[u] >= m->act_forcerange[u][1])) continue;
+      int da = m->jnt_dofadr[m->act_jnt[u]];
+      A[da][da] -= m->dt * m->act_bias[u][2];
+    }
+    chol_factor(nv, A, L);
+    chol_solve(nv, L, qacc);
+  } else {
+    /* mj_Euler; implicit-in-damping variant when any dof_damping > 0 */
+    int damped = 0;
+    for (int i = 0; i < nv; i++) if (m->dof_damping[i] > 0) damped = 1;
+    if (damped) {
+      double A[OM_MAXV][OM_MAXV], L[OM_MAXV][OM_MAXV];
+      for (int i = 0; i < nv; i++) {
+        for (int j = 0; j < nv; j++) A[i][j] = d->M[i][j];
+        A[i][i] += m->dt * m->dof_damping[i];
+        qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+      }
+      chol_factor(nv, A, L);
+      chol_solve(nv, L, qacc);
+    } else
+      memcpy(qacc, d->qacc, sizeof(double) * nv);
+  }
+  for (int i = 0; i < nv; i++) d->qvel[i] += m->dt * qacc[i];
+  integrate_pos(m, d, m->dt);
+  d->time += m->dt;
+}
+
+void om_forward(const om_model* m, om_data* d) {
+  om_step1(m, d);
+  om_actuation(m, d);
+  om_fwd_acceleration(m, d);
+  om_solve_constraint(m, d);
+}
+
+/* dm_control Physics.step() legacy mode (non-RK4): mj_step2 then mj_step1, so that
+ * positions/contacts are in sync with the new state */
+void om_physics_step(const om_model* m, om_data* d) {
+  om_step2(m, d);
+  om_step1(m, d);
+}
+
+void om_reset_data(const om_model* m, om_data* d) {
+  memset(d, 0, sizeof *d);
+  memcpy(d->qpos, m->qpos0, sizeof(double) * m->nq);
+  for (int b = 0; b < m->nbody; b++)
+    if (m->body_mocapid[b] >= 0) {
+      memcpy(d->mocap_pos[m->body_mocapid[b]], m->body_pos[b], sizeof(double) * 3);
+      memcpy(d->mocap_quat[m->body_mocapid[b]], m->body_quat[b], sizeof(double) * 4);
+    }
+}
+
+/* mj_setConst: body/dof inverse weights and mean inertia at qpos0 */
+void om_set_const(om_model* m) {
+  static __thread om_data d;
+  om_reset_data(m, &d);
+  /* weld ids */
+  m->body_weldid[0] = 0;
+  for (int b = 1; b < m->nbody; b++) m->body_weldid[b] = (m->body_jntnum[b] == 0) ? m->body_weldid[m->body_parent[b]] : b;
+  for (int e = 0; e < m->neq; e++) {
+    /* weld relpose from qpos0 when not specified (quat all zero): done by the scene builder */
+  }
+  om_kinematics(m, &d);
+  om_subspaces(m, &d);
+  om_crb(m, &d);
+  int nv = m->nv;
+  double tr = 0;
+  for (int i = 0; i < nv; i++) tr += d.M[i][i];
+  m->meaninertia = nv > 0 ? tr / nv : 1.0;
+  for (int b = 0; b < m->nbody; b++) {
+    m->body_invweight0[b][0] = m->body_invweight0[b][1] = 0;
+    if (m->body_weldid[b] == 0) continue;
+    double jt[3][OM_MAXV], jr[3][OM_MAXV];
+    om_jac(m, &d, b, d.xipos[b], jt, jr);
+    double tsum = 0, rsum = 0;
+    for (int k = 0; k < 3; k++) {
+      double x[OM_MAXV];
+      memcpy(x, jt[k], sizeof(double) * nv);
+      chol_solve(nv, d.Lm, x);
+      for (int i = 0; i < nv; i++) tsum += jt[k][i] * x[i];
+      memcpy(x, jr[k], sizeof(double) * nv);
+      chol_solve(nv, d.Lm, x);
+      for (int i = 0; i < nv; i++) rsum += jr[k][i] * x[i];
+    }
+    m->body_invweight0[b][0] = fmax(MJS_MINVAL, tsum / 3);
+    m->body_invweight0[b][1] = fmax(MJS_MINVAL, rsum / 3);
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int da = m->jnt_dofadr[j];
+    int nd = m->jnt_type[j] == OM_JNT_FREE ? 6 : 1;
+    double diag[6];
+    for (int k = 0; k < nd; k++) {
+      double x[OM_MAXV];
+      memset(x, 0, sizeof x);
+      x[da + k] = 1;
+      chol_solve(nv, d.Lm, x);
+      diag[k] = x[da + k];
+    }
+    if (nd == 6) {
+      double t = (diag[0] + diag[1] + diag[2]) / 3, r = (diag[3] + diag[4] + diag[5]) / 3;
+      for (int k = 0; k < 3; k++) { m->dof_invweight0[da + k] = t; m->dof_invweight0[da + 3 + k] = r; }
+    } else
+      m->dof_invweight0[da] = diag[0];
+  }
+}

@@ -1,0 +1,395 @@
+/* om_tasks.c — ORACLE (test infrastructure): scene assembly, the
+ * composer.Environment step/reset loop and the task logic, restated from
+ *   environments/dmc2gym.py:133-163          (term/trunc split, reset)
+ *   environments/tasks/point_reach.py:125-212 (Pointmass-Reach task)
+ *   entities/pointmass.py:44-66,87-148        (PointMass2D entity)
+ *   mjcf/walled_pointmass_arena.xml:11-20     (arena geometry)
+ *   environments/tasks/robot_reach.py:85-207  (Robot-Reach task)
+ *   entities/robots/robot.py:113-272,301-321  (servoL/servoJ, gravcomp, base quat)
+ *   entities/robots/joint_trajectory.py:33-47 (linear joint interpolation)
+ *   environments/tasks/spaces.py:24-31        (reset sampling order)
+ * and dm_control's composer loop semantics (third-party).
+ * PARITY UNPINNED — see mjs_oracle.h.
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mjs_scene_spec.h"
+#include "mjs_oracle.h"
+
+/* ------------------------------------------------------- model building */
+static void quat_z2vec(double* q, const double* vec) {
+  /* mju_quatZ2Vec: rotation taking (0,0,1) to vec */
+  double z[3] = {0, 0, 1}, v[3] = {vec[0], vec[1], vec[2]};
+  double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+  q[0] = 1; q[1] = q[2] = q[3] = 0;
+  if (n < MJS_MINVAL) return;
+  for (int k = 0; k < 3; k++) v[k] /= n;
+  double ax[3] = {z[1] * v[2] - z[2] * v[1], z[2] * v[0] - z[0] * v[2], z[0] * v[1] - z[1] * v[0]};
+  double s = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (s < 1e-10) { ax[0] = 1; ax[1] = ax[2] = 0; } else { for (int k = 0; k < 3; k++) ax[k] /= s; }
+  double ang = atan2(s, v[2]);
+  q[0] = cos(ang / 2);
+  for (int k = 0; k < 3; k++) q[1 + k] = ax[k] * sin(ang / 2);
+}
+static void quat_norm(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  for (int k = 0; k < 4; k++) q[k] /= n;
+}
+
+static void model_defaults(om_model* m) {
+  memset(m, 0, sizeof *m);
+  m->gravity[2] = MJS_GRAVITY_Z;
+  m->tolerance = MJS_SOLVER_TOLERANCE;
+  m->iterations = MJS_SOLVER_ITERATIONS;
+  m->impratio = 1.0;
+  m->solref[0] = MJS_SOLREF_TIMECONST; m->solref[1] = MJS_SOLREF_DAMPRATIO;
+  m->solimp[0] = MJS_SOLIMP_D0; m->solimp[1] = MJS_SOLIMP_DWIDTH; m->solimp[2] = MJS_SOLIMP_WIDTH;
+  m->solimp[3] = MJS_SOLIMP_MIDPOINT; m->solimp[4] = MJS_SOLIMP_POWER;
+  m->nbody = 1; /* world */
+  m->body_mocapid[0] = -1;
+  m->body_quat[0][0] = m->body_iquat[0][0] = 1;
+}
+static int add_body(om_model* m, int parent, const double* pos, const double* quat, double mass, const double* ipos,
+                    const double* iquat, const double* inertia, double gravcomp) {
+  int b = m->nbody++;
+  m->body_parent[b] = parent;
+  memcpy(m->body_pos[b], pos, sizeof(double) * 3);
+  memcpy(m->body_quat[b], quat, sizeof(double) * 4);
+  quat_norm(m->body_quat[b]);
+  m->body_mass[b] = mass;
+  if (ipos) memcpy(m->body_ipos[b], ipos, sizeof(double) * 3);
+  m->body_iquat[b][0] = 1;
+  if (iquat) { memcpy(m->body_iquat[b], iquat, sizeof(double) * 4); quat_norm(m->body_iquat[b]); }
+  if (inertia) memcpy(m->body_inertia[b], inertia, sizeof(double) * 3);
+  m->body_gravcomp[b] = gravcomp;
+  m->body_mocapid[b] = -1;
+  m->body_jntadr[b] = m->njnt;
+  m->body_dofadr[b] = m->nv;
+  return b;
+}
+static int add_joint(om_model* m, int body, int type, const double* axis, int limited, double lo, double hi, double armature) {
+  int j = m->njnt++;
+  m->jnt_type[j] = type; m->jnt_body[j] = body;
+  m->jnt_qposadr[j] = m->nq; m->jnt_dofadr[j] = m->nv;
+  if (axis) memcpy(m->jnt_axis[j], axis, sizeof(double) * 3);
+  m->jnt_limited[j] = limited; m->jnt_range[j][0] = lo; m->jnt_range[j][1] = hi;
+  int nd = type == OM_JNT_FREE ? 6 : 1, nqj = type == OM_JNT_FREE ? 7 : 1;
+  for (int k = 0; k < nd; k++) {
+    int dof = m->nv + k;
+    m->dof_body[dof] = body; m->dof_jnt[dof] = j; m->dof_armature[dof] = armature;
+    if (k > 0 || m->body_dofnum[body] > 0) m->dof_parent[dof] = dof - 1;
+    else {
+      /* last dof of the nearest ancestor that has dofs */
+      int p = m->body_parent[body];
+      while (p > 0 && m->body_dofnum[p] == 0) p = m->body_parent[p];
+      m->dof_parent[dof] = (p > 0) ? m->body_dofadr[p] + m->body_dofnum[p] - 1 : -1;
+    }
+  }
+  m->body_jntnum[body]++;
+  m->body_dofnum[body] += nd;
+  m->nv += nd; m->nq += nqj;
+  return j;
+}
+static int add_geom(om_model* m, int body, int type, const double* pos, const double* quat, double s0, double s1, double s2) {
+  int g = m->ngeom++;
+  m->geom_type[g] = type; m->geom_body[g] = body;
+  if (pos) memcpy(m->geom_pos[g], pos, sizeof(double) * 3);
+  m->geom_quat[g][0] = 1;
+  if (quat) { memcpy(m->geom_quat[g], quat, sizeof(double) * 4); quat_norm(m->geom_quat[g]); }
+  m->geom_size[g][0] = s0; m->geom_size[g][1] = s1; m->geom_size[g][2] = s2;
+  m->geom_contype[g] = 1; m->geom_conaffinity[g] = 1; m->geom_condim[g] = 3;
+  m->geom_friction[g][0] = MJS_GEOM_FRICTION_SLIDE; m->geom_friction[g][1] = MJS_GEOM_FRICTION_SPIN; m->geom_friction[g][2] = MJS_GEOM_FRICTION_ROLL;
+  return g;
+}
+
+/* Pointmass-Reach scene (point_reach.py:75-102) */
+static void build_pointmass(om_model* m) {
+  model_defaults(m);
+  m->dt = MJS_PM_PHYSICS_DT;
+  m->integrator = OM_INT_EULER;
+  const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
+  /* arena planes on the world body, XML order */
+  add_geom(m, 0, OM_GEOM_PLANE, zero3, ident, 0.5, 0.5, 0.1);
+  const double wall_pos[4][3] = {{MJS_PM_ARENA_LO, 0, MJS_PM_WALL_Z}, {0, MJS_PM_ARENA_LO, MJS_PM_WALL_Z}, {MJS_PM_ARENA_HI, 0, MJS_PM_WALL_Z}, {0, MJS_PM_ARENA_HI, MJS_PM_WALL_Z}};
+  const double wall_z[4][3] = {{1, 0, 0}, {0, 1, 0}, {-1, 0, 0}, {0, -1, 0}};
+  for (int w = 0; w < 4; w++) {
+    double q[4];
+    quat_z2vec(q, wall_z[w]);
+    add_geom(m, 0, OM_GEOM_PLANE, wall_pos[w], q, 0.5, 0.5, 0.02);
+  }
+  /* mocap body (entities/utils.py:32-41) */
+  int mocap = add_body(m, 0, zero3, ident, 0, NULL, NULL, NULL, 0);
+  m->body_mocapid[mocap] = 0; m->nmocap = 1;
+  /* pointmass body: sphere, two slide joints (pointmass.py:52-66) */
+  const double bpos[3] = {0, 0, MJS_PM_RADIUS};
+  double I = 0.4 * MJS_PM_MASS * MJS_PM_RADIUS * MJS_PM_RADIUS;
+  const double inertia[3] = {I, I, I};
+  int pm = add_body(m, 0, bpos, ident, MJS_PM_MASS, zero3, ident, inertia, 0);
+  const double ax[3] = {1, 0, 0}, ay[3] = {0, 1, 0};
+  add_joint(m, pm, OM_JNT_SLIDE, ax, 0, 0, 0, 0);
+  add_joint(m, pm, OM_JNT_SLIDE, ay, 0, 0, 0, 0);
+  add_geom(m, pm, OM_GEOM_SPHERE, zero3, ident, MJS_PM_RADIUS, 0, 0);
+  /* weld mocap <-> pointmass (point_reach.py:84-89); relpose from qpos0 */
+  m->neq = 1;
+  m->eq_body1[0] = mocap; m->eq_body2[0] = pm;
+  double* data = m->eq_data[0];
+  memset(data, 0, sizeof(double) * 11);
+  data[3] = 0; data[4] = 0; data[5] = MJS_PM_RADIUS; /* body2 anchor seen from body1 at qpos0 */
+  data[6] = 1; data[10] = 1;
+  memcpy(m->eq_solref[0], m->solref, sizeof m->solref);
+  memcpy(m->eq_solimp[0], m->solimp, sizeof m->solimp);
+  om_set_const(m);
+}
+
+/* UR5e + lumped 2F-85 payload on the empty arena (robot_reach.py:90-119) */
+static void build_robot(om_model* m, int eef_gripper) {
+  model_defaults(m);
+  m->dt = MJS_RR_PHYSICS_DT;
+  m->integrator = OM_INT_IMPLICITFAST;
+  const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
+  add_geom(m, 0, OM_GEOM_PLANE, zero3, ident, MJS_ROBOT_ARENA_HALF, MJS_ROBOT_ARENA_HALF, 0.1);
+  int parent = 0, bodies[MJS_UR_NBODY];
+  for (int b = 0; b < MJS_UR_NBODY; b++) {
+    bodies[b] = add_body(m, parent, MJS_UR_BODY_POS[b], MJS_UR_BODY_QUAT[b], MJS_UR_BODY_MASS[b], MJS_UR_BODY_IPOS[b],
+                         MJS_UR_BODY_IQUAT[b], MJS_UR_BODY_DIAGINERTIA[b], 1.0 /* robot.py:80-82 */);
+    if (b > 0) {
+      int j = b - 1;
+      add_joint(m, bodies[b], OM_JNT_HINGE, MJS_UR_JNT_AXIS[j], 1, MJS_UR_JNT_RANGE[j][0], MJS_UR_JNT_RANGE[j][1], MJS_UR_ARMATURE);
+    }
+    parent = bodies[b];
+  }
+  for (int g = 0; g < MJS_UR_NCOLGEOM; g++)
+    add_geom(m, bodies[MJS_UR_COL_BODY[g]], MJS_UR_COL_TYPE[g], MJS_UR_COL_POS[g], MJS_UR_COL_QUAT[g], MJS_UR_COL_SIZE[g][0], MJS_UR_COL_SIZE[g][1], 0);
+  /* flange site */
+  m->nsite = 1;
+  m->site_body[0] = bodies[6];
+  memcpy(m->site_pos[0], MJS_UR_FLANGE_POS, sizeof(double) * 3);
+  memcpy(m->site_quat[0], MJS_UR_FLANGE_QUAT, sizeof(double) * 4);
+  quat_norm(m->site_quat[0]);
+  /* end-effector body attached at the flange site, gravcomp 0 */
+  if (eef_gripper)
+    add_body(m, bodies[6], MJS_UR_FLANGE_POS, MJS_UR_FLANGE_QUAT, MJS_G2F85_MASS, MJS_G2F85_IPOS, ident, MJS_G2F85_DIAGINERTIA, 0.0);
+  /* position servos */
+  m->nu = MJS_UR_NJ;
+  for (int u = 0; u < MJS_UR_NJ; u++) {
+    m->act_jnt[u] = u;
+    m->act_gain[u] = MJS_UR_ACT_KP[u];
+    m->act_bias[u][0] = 0; m->act_bias[u][1] = -MJS_UR_ACT_KP[u]; m->act_bias[u][2] = -MJS_UR_ACT_KD[u];
+    m->act_ctrllimited[u] = 1; m->act_forcelimited[u] = 1;
+    m->act_ctrlrange[u][0] = MJS_UR_ACT_CTRLRANGE[u][0]; m->act_ctrlrange[u][1] = MJS_UR_ACT_CTRLRANGE[u][1];
+    m->act_forcerange[u][0] = -MJS_UR_ACT_FRC[u]; m->act_forcerange[u][1] = MJS_UR_ACT_FRC[u];
+  }
+  om_set_const(m);
+}
+
+/* ------------------------------------------------------------ task API */
+void om_default_config(int task, om_task_config* cfg) {
+  memset(cfg, 0, sizeof *cfg);
+  cfg->task = task;
+  cfg->autoreset = OM_AUTORESET_NEXT_STEP;
+  if (task == OM_TASK_POINTMASS) {
+    cfg->reward_type = OM_REW_DENSE_BIASED_NEG_DISTANCE;                  /* point_reach.py:63 */
+    cfg->time_limit = MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT;      /* __init__.py:21,28 */
+  } else {
+    cfg->reward_type = OM_REW_DENSE_NEG_DISTANCE;                         /* robot_reach.py:75 */
+    cfg->time_limit = MJS_RR_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      /* BASELINE cfg 3 */
+  }
+}
+int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : 12; }
+int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : 3; }
+int om_sizeof_step_out(void) { return (int)sizeof(om_step_out); }
+
+void om_env_seed(om_env* e, uint32_t seed) { om_rng_seed(&e->rng, seed); }
+
+void om_env_init(om_env* e, const om_task_config* cfg, uint32_t seed) {
+  memset(e, 0, sizeof *e);
+  e->cfg = *cfg;
+  if (cfg->task == OM_TASK_POINTMASS) { build_pointmass(&e->m); e->n_sub = (int)round(MJS_PM_CONTROL_DT / MJS_PM_PHYSICS_DT); }
+  else { build_robot(&e->m, 1); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
+  e->distance_to_target = 1.0;          /* point_reach.py:112-113 */
+  e->previous_distance_to_target = 1.0;
+  om_env_seed(e, seed);
+  om_reset_data(&e->m, &e->d);
+  e->reset_pending = 1;
+}
+
+/* TCP pose -> flange pose -> IK (robot.py:113-121,138-151); pose quaternion is scalar-last */
+static int tcp_pose_to_joints(const double* pos, const double* quat_xyzw, double tcp_z, const double* q_guess, double* q_out) {
+  double x = quat_xyzw[0], y = quat_xyzw[1], z = quat_xyzw[2], w = quat_xyzw[3];
+  double n = sqrt(x * x + y * y + z * z + w * w);
+  x /= n; y /= n; z /= n; w /= n;
+  double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  double T[16] = {R[0], R[1], R[2], pos[0] - R[2] * tcp_z, R[3], R[4], R[5], pos[1] - R[5] * tcp_z,
+                  R[6], R[7], R[8], pos[2] - R[8] * tcp_z, 0, 0, 0, 1};
+  return om_ur5e_ik_closest(T, q_guess, q_out);
+}
+
+static void get_tcp_position(const om_env* e, double* tcp) {
+  /* robot.py:153-168: flange site pose, then the TCP offset along the flange z axis */
+  const double* p = e->d.site_xpos[0];
+  const double* R = e->d.site_xmat[0];
+  for (int k = 0; k < 3; k++) tcp[k] = p[k] + R[3 * k + 2] * MJS_G2F85_TCP_Z;
+}
+
+static void write_obs(const om_env* e, double* obs) {
+  if (e->cfg.task == OM_TASK_POINTMASS) {
+    obs[0] = e->d.xpos[2][0]; obs[1] = e->d.xpos[2][1];     /* pointmass/position (pointmass.py:87-98) */
+    obs[2] = e->target_pos[0]; obs[3] = e->target_pos[1];   /* goal_position (point_reach.py:211-212) */
+  } else {
+    get_tcp_position(e, obs);                                /* ur5e/tcp_position */
+    for (int j = 0; j < 6; j++) obs[3 + j] = e->d.qpos[j];   /* ur5e/joint_configuration */
+    for (int k = 0; k < 3; k++) obs[9 + k] = e->target_pos[k]; /* target_position */
+  }
+}
+
+static void episode_init(om_env* e) {
+  om_model* m = &e->m;
+  om_data* d = &e->d;
+  om_reset_data(m, d);
+  e->traj_active = 0;
+  e->ik_failed = 0;
+  if (e->cfg.task == OM_TASK_POINTMASS) {
+    /* point_reach.py:125-144: goal_x, goal_y, point_x, point_y */
+    double lo = MJS_PM_ARENA_LO + MJS_PM_RADIUS, hi = MJS_PM_ARENA_HI - MJS_PM_RADIUS;
+    double gx = om_rng_uniform(&e->rng, lo, hi), gy = om_rng_uniform(&e->rng, lo, hi);
+    e->target_pos[0] = gx; e->target_pos[1] = gy; e->target_pos[2] = MJS_PM_RADIUS / 2;
+    double px = om_rng_uniform(&e->rng, lo, hi), py = om_rng_uniform(&e->rng, lo, hi);
+    d->qpos[0] = px; d->qpos[1] = py; d->qvel[0] = d->qvel[1] = 0;
+    d->mocap_pos[0][0] = px; d->mocap_pos[0][1] = py;
+  } else {
+    /* robot_reach.py:143-150 with spaces.py:24-31 */
+    double rp[3], tp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 3; k++) rp[k] = om_rng_uniform(&e->rng, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+    if (tcp_pose_to_joints(rp, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, zeros, q)) {
+      for (int j = 0; j < 6; j++) { d->qpos[j] = q[j]; d->qvel[j] = 0; d->ctrl[j] = q[j]; } /* robot.py:185-189 */
+    } /* else: silently keep qpos0 (robot.py:179-183) */
+    for (int k = 0; k < 3; k++) tp[k] = om_rng_uniform(&e->rng, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+    memcpy(e->target_pos, tp, sizeof tp);
+  }
+  om_forward(m, d);
+}
+
+static int count_contacts(const om_data* d) { return d->ncon; }
+
+void om_env_reset(om_env* e, om_step_out* out) {
+  memset(out, 0, sizeof *out);
+  episode_init(e);
+  e->reset_pending = 0;
+  write_obs(e, out->obs);
+  out->step_type = OM_STEP_FIRST;
+  out->reward = 0.0; out->discount = 1.0; /* dm_env: None / None on FIRST */
+  out->ncon = count_contacts(&e->d);
+}
+
+static int task_accomplished(const om_env* e, double* dist_out) {
+  double tcp[3], dd = 0;
+  get_tcp_position(e, tcp);
+  for (int k = 0; k < 3; k++) dd += (tcp[k] - e->target_pos[k]) * (tcp[k] - e->target_pos[k]);
+  dd = sqrt(dd);
+  if (dist_out) *dist_out = dd;
+  return dd < MJS_RR_GOAL_THRESHOLD;
+}
+
+void om_env_step(om_env* e, const double* action, om_step_out* out) {
+  om_model* m = &e->m;
+  om_data* d = &e->d;
+  if (e->reset_pending && e->cfg.autoreset == OM_AUTORESET_NEXT_STEP) { om_env_reset(e, out); return; }
+  memset(out, 0, sizeof *out);
+  d->warning_bad = 0;
+  /* before_step hooks */
+  if (e->cfg.task == OM_TASK_POINTMASS) {
+    /* point_reach.py:150-163 */
+    for (int k = 0; k < 2; k++) {
+      double t = d->xpos[2][k] + action[k];
+      t = fmin(fmax(t, MJS_PM_ARENA_LO), MJS_PM_ARENA_HI);
+      d->mocap_pos[0][k] = t;
+    }
+  } else {
+    /* robot_reach.py:159-169 -> robot.py:218-259 */
+    double q_now[6], q_ik[6];
+    memcpy(q_now, d->qpos, sizeof q_now);
+    if (!tcp_pose_to_joints(action, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, q_now, q_ik)) {
+      e->ik_failed = 1; /* reference raises ValueError (robot.py:221-224); batched: flag + hold (D-4) */
+      memcpy(q_ik, q_now, sizeof q_ik);
+    }
+    memcpy(e->traj_q0, q_now, sizeof q_now);
+    memcpy(e->traj_q1, q_ik, sizeof q_ik);
+    e->traj_t0 = d->time;
+    e->traj_t1 = d->time + MJS_RR_CONTROL_DT;
+    e->traj_active = 1;
+  }
+  /* substeps */
+  for (int s = 0; s < e->n_sub; s++) {
+    if (e->traj_active) {
+      /* robot.py:261-263, joint_trajectory.py:33-47 */
+      double t = fmin(fmax(d->time, e->traj_t0), e->traj_t1);
+      for (int j = 0; j < 6; j++) d->ctrl[j] = e->traj_q0[j] + (e->traj_q1[j] - e->traj_q0[j]) * (t - e->traj_t0) / (e->traj_t1 - e->traj_t0);
+    }
+    om_physics_step(m, d);
+  }
+  /* after_step + reward/discount/termination */
+  int terminate = 0, success = 0;
+  double reward = 0, discount = 1;
+  if (e->cfg.task == OM_TASK_POINTMASS) {
+    /* point_reach.py:165-202 */
+    e->previous_distance_to_target = e->distance_to_target;
+    double dx = d->xpos[2][0] - e->target_pos[0], dy = d->xpos[2][1] - e->target_pos[1];
+    e->distance_to_target = sqrt(dx * dx + dy * dy);
+    success = e->distance_to_target < MJS_PM_GOAL_THRESHOLD;
+    switch (e->cfg.reward_type) {
+      case OM_REW_SPARSE: reward = success ? 1.0 : 0.0; break; /* intended; reference branch broken (App. D-4) */
+      case OM_REW_DENSE_NEG_DISTANCE: reward = -e->distance_to_target; break;
+      case OM_REW_DENSE_POTENTIAL: reward = e->previous_distance_to_target - e->distance_to_target; break;
+      default: reward = -e->distance_to_target + 0.5; break;
+    }
+    terminate = success;
+    discount = success ? 0.0 : 1.0;
+  } else {
+    double dist;
+    success = task_accomplished(e, &dist);
+    reward = (e->cfg.reward_type == OM_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist; /* robot_reach.py:174-181 */
+    if (e->cfg.terminate_on_success && success) { terminate = 1; discount = 0.0; } /* opt-in, D-2 */
+  }
+  if (d->warning_bad) { reward = 0; discount = 0; terminate = 1; out->fault = 1; } /* PhysicsError path */
+  if (d->time >= e->cfg.time_limit) terminate = 1;
+  write_obs(e, out->obs);
+  out->reward = reward; out->discount = discount;
+  out->step_type = terminate ? OM_STEP_LAST : OM_STEP_MID;
+  out->terminated = terminate && discount == 0.0; /* dmc2gym.py:144-145 */
+  out->truncated = terminate && discount > 0.0;
+  out->is_success = success;
+  out->ncon = count_contacts(d);
+  out->ik_failed = e->ik_failed;
+  e->reset_pending = terminate;
+  if (terminate && e->cfg.autoreset == OM_AUTORESET_SAME_STEP) {
+    memcpy(out->terminal_obs, out->obs, sizeof out->obs);
+    episode_init(e);
+    e->reset_pending = 0;
+    write_obs(e, out->obs);
+  }
+}
+
+/* ---------------------------------------------------------------- batch */
+struct om_batch { int n; om_env* envs; };
+
+om_batch* om_batch_create(const om_task_config* cfg, int n, uint32_t base_seed) {
+  om_batch* b = (om_batch*)malloc(sizeof *b);
+  b->n = n;
+  b->envs = (om_env*)malloc(sizeof(om_env) * (size_t)n);
+  for (int i = 0; i < n; i++) om_env_init(&b->envs[i], cfg, base_seed + (uint32_t)i);
+  return b;
+}
+void om_batch_destroy(om_batch* b) { free(b->envs); free(b); }
+om_env* om_batch_env(om_batch* b, int i) { return &b->envs[i]; }
+void om_batch_reset(om_batch* b, om_step_out* outs) {
+  for (int i = 0; i < b->n; i++) om_env_reset(&b->envs[i], &outs[i]);
+}
+void om_batch_step(om_batch* b, const double* actions, om_step_out* outs, int nthreads) {
+  int A = om_action_dim(b->envs[0].cfg.task);
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+  for (int i = 0; i < b->n; i++) om_env_step(&b->envs[i], actions + (size_t)i * A, &outs[i]);
+}

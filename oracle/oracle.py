@@ -1,0 +1,208 @@
+"""ctypes front-end of the C oracle (oracle/*.c). TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+import numpy as np
+
+_HERE = Path(__file__).resolve().parent
+_LIB_PATH = _HERE / "_build" / "liboracle.so"
+
+TASK_POINTMASS, TASK_ROBOT_REACH = 0, 1
+STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
+REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DISTANCE = 0, 1, 2, 3
+AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
+MAXOBS = 16
+
+
+class TaskConfig(C.Structure):
+    _fields_ = [
+        ("task", C.c_int),
+        ("reward_type", C.c_int),
+        ("autoreset", C.c_int),
+        ("time_limit", C.c_double),
+        ("terminate_on_success", C.c_int),
+    ]
+
+
+class StepOut(C.Structure):
+    _fields_ = [
+        ("obs", C.c_double * MAXOBS),
+        ("terminal_obs", C.c_double * MAXOBS),
+        ("reward", C.c_double),
+        ("discount", C.c_double),
+        ("step_type", C.c_int),
+        ("terminated", C.c_int),
+        ("truncated", C.c_int),
+        ("is_success", C.c_int),
+        ("ncon", C.c_int),
+        ("fault", C.c_int),
+        ("ik_failed", C.c_int),
+    ]
+
+
+_STEP_DTYPE = np.dtype(
+    {
+        "names": ["obs", "terminal_obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon", "fault", "ik_failed"],
+        "formats": [(np.float64, MAXOBS), (np.float64, MAXOBS), np.float64, np.float64] + [np.int32] * 7,
+        "offsets": [0, 8 * MAXOBS, 16 * MAXOBS, 16 * MAXOBS + 8] + [16 * MAXOBS + 16 + 4 * i for i in range(7)],
+        "itemsize": C.sizeof(StepOut),
+    }
+)
+
+
+class _Rng(C.Structure):
+    _fields_ = [("mt", C.c_uint32 * 624), ("pos", C.c_int)]
+
+
+def build(force: bool = False) -> Path:
+    """Compile oracle/*.c with gcc (Makefile in this directory)."""
+    srcs = [*_HERE.glob("*.c"), _HERE / "mjs_oracle.h", _HERE.parent / "include" / "mjs_scene_spec.h"]
+    stale = not _LIB_PATH.exists() or any(s.stat().st_mtime > _LIB_PATH.stat().st_mtime for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", str(_HERE), "-B" if force else "-s"], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not _LIB_PATH.exists() or os.access(_HERE / "Makefile", os.R_OK) and _sources_newer():
+            build()
+        L = C.CDLL(str(_LIB_PATH))
+        L.om_default_config.argtypes = [C.c_int, C.POINTER(TaskConfig)]
+        L.om_obs_dim.argtypes = [C.c_int]
+        L.om_action_dim.argtypes = [C.c_int]
+        L.om_batch_create.argtypes = [C.POINTER(TaskConfig), C.c_int, C.c_uint32]
+        L.om_batch_create.restype = C.c_void_p
+        L.om_batch_destroy.argtypes = [C.c_void_p]
+        L.om_batch_env.argtypes = [C.c_void_p, C.c_int]
+        L.om_batch_env.restype = C.c_void_p
+        L.om_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.om_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.om_env_seed.argtypes = [C.c_void_p, C.c_uint32]
+        L.om_rng_seed.argtypes = [C.POINTER(_Rng), C.c_uint32]
+        L.om_rng_uniform.argtypes = [C.POINTER(_Rng), C.c_double, C.c_double]
+        L.om_rng_uniform.restype = C.c_double
+        L.om_rng_u32.argtypes = [C.POINTER(_Rng)]
+        L.om_rng_u32.restype = C.c_uint32
+        L.om_ur5e_fk_dh.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.om_ur5e_ik_all.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.om_ur5e_ik_closest.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        assert L.om_sizeof_step_out() == C.sizeof(StepOut), "StepOut layout mismatch"
+        _lib = L
+    return _lib
+
+
+def _sources_newer() -> bool:
+    if not _LIB_PATH.exists():
+        return True
+    t = _LIB_PATH.stat().st_mtime
+    return any(s.stat().st_mtime > t for s in [*_HERE.glob("*.c"), *_HERE.glob("*.h")])
+
+
+def _dptr(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+class OracleRng:
+    """numpy-legacy MT19937 stream of the oracle (for pinning against numpy)."""
+
+    def __init__(self, seed: int):
+        self._r = _Rng()
+        lib().om_rng_seed(C.byref(self._r), seed & 0xFFFFFFFF)
+
+    def uniform(self, lo: float, hi: float) -> float:
+        return lib().om_rng_uniform(C.byref(self._r), lo, hi)
+
+    def u32(self) -> int:
+        return lib().om_rng_u32(C.byref(self._r))
+
+
+def ur5e_fk_dh(q) -> np.ndarray:
+    q = np.ascontiguousarray(q, dtype=np.float64)
+    T = np.zeros(16)
+    lib().om_ur5e_fk_dh(_dptr(q), _dptr(T))
+    return T.reshape(4, 4)
+
+
+def ur5e_ik_all(T) -> np.ndarray:
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    sols = np.zeros((8, 6))
+    n = lib().om_ur5e_ik_all(_dptr(T), _dptr(sols))
+    return sols[:n]
+
+
+def ur5e_ik_closest(T, q_guess):
+    T = np.ascontiguousarray(T, dtype=np.float64).reshape(16)
+    g = np.ascontiguousarray(q_guess, dtype=np.float64)
+    out = np.zeros(6)
+    ok = lib().om_ur5e_ik_closest(_dptr(T), _dptr(g), _dptr(out))
+    return out if ok else None
+
+
+class OracleBatch:
+    """N independent oracle envs, env i seeded ``base_seed + i`` (reach_sac.py:84)."""
+
+    def __init__(self, task: int, n: int, base_seed: int = 0, *, reward_type: int | None = None,
+                 autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
+                 terminate_on_success: bool = False, nthreads: int = 1):
+        L = lib()
+        cfg = TaskConfig()
+        L.om_default_config(task, C.byref(cfg))
+        if reward_type is not None:
+            cfg.reward_type = reward_type
+        if time_limit is not None:
+            cfg.time_limit = time_limit
+        cfg.autoreset = autoreset
+        cfg.terminate_on_success = int(terminate_on_success)
+        self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
+        self.obs_dim, self.action_dim = L.om_obs_dim(task), L.om_action_dim(task)
+        self._h = L.om_batch_create(C.byref(cfg), n, base_seed & 0xFFFFFFFF)
+        self._out = np.zeros(n, dtype=_STEP_DTYPE)
+
+    def seed(self, base_seed: int):
+        for i in range(self.n):
+            lib().om_env_seed(lib().om_batch_env(self._h, i), (base_seed + i) & 0xFFFFFFFF)
+
+    def _result(self):
+        o = self._out
+        return {
+            "obs": o["obs"][:, : self.obs_dim].copy(),
+            "terminal_obs": o["terminal_obs"][:, : self.obs_dim].copy(),
+            "reward": o["reward"].copy(),
+            "discount": o["discount"].copy(),
+            "step_type": o["step_type"].copy(),
+            "terminated": o["terminated"].astype(bool),
+            "truncated": o["truncated"].astype(bool),
+            "is_success": o["is_success"].astype(bool),
+            "ncon": o["ncon"].copy(),
+            "fault": o["fault"].astype(bool),
+            "ik_failed": o["ik_failed"].astype(bool),
+        }
+
+    def reset(self):
+        lib().om_batch_reset(self._h, self._out.ctypes.data)
+        return self._result()
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, self.action_dim)
+        lib().om_batch_step(self._h, a.ctypes.data, self._out.ctypes.data, self.nthreads)
+        return self._result()
+
+    def close(self):
+        if self._h:
+            lib().om_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
