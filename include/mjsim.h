@@ -1,0 +1,126 @@
+/* mjsim.h — C ABI of libmjsim.so: the MI355X-native batched replacement for the
+ * reference's per-step hot path.
+ *
+ * The reference has no native boundary (it is Python over the third-party
+ * `mujoco`/`dm_control` wheels), so each entry point below cites the Python
+ * interface it replaces (paths relative to /root/reference/mujoco_sim/). A
+ * handle steps N independent environments of ONE task on ONE GPU; all pointers
+ * named *_dev are DEVICE pointers owned by the caller (PyTorch-ROCm tensors);
+ * the engine owns only its persistent struct-of-arrays state. Every call
+ * enqueues work on the caller's HIP stream (`stream` = hipStream_t, NULL = the
+ * default stream) and never synchronises. Return value: 0 = ok, negative =
+ * MJS_ERR_*; nothing throws across the ABI; per-env faults are data
+ * (`mjs_outputs.fault`), not errors. A handle is not thread-safe.
+ * Binding stubs for the reference side: INTEGRATION.md.
+ */
+#ifndef MJSIM_H
+#define MJSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MJS_ABI_VERSION 1
+
+/* tasks (environments/tasks/*.py) */
+enum { MJS_TASK_POINTMASS_REACH = 0, MJS_TASK_ROBOT_REACH = 1 };
+/* reward types: point_reach.py:11-14, robot_reach.py:37-38 */
+enum { MJS_REW_SPARSE = 0, MJS_REW_DENSE_POTENTIAL = 1, MJS_REW_DENSE_NEG_DISTANCE = 2, MJS_REW_DENSE_BIASED_NEG_DISTANCE = 3 };
+/* dm_env StepType as produced by composer.Environment (dmc2gym.py:144-145 reads .last()) */
+enum { MJS_STEP_FIRST = 0, MJS_STEP_MID = 1, MJS_STEP_LAST = 2 };
+/* auto-reset: NEXT_STEP is composer.Environment's behaviour (the step after LAST ignores the
+ * action and returns the reset observation); SAME_STEP is what SB3 VecEnv expects
+ * (scripts/sb3/reach_sac.py:93-96): reset immediately, expose `terminal_obs`. */
+enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_DISABLED = 2 };
+/* mjs_outputs.fault bits */
+enum { MJS_FAULT_BAD_STATE = 1, MJS_FAULT_IK_FAILED = 2, MJS_FAULT_LIMIT_COLDSTART = 4 };
+
+enum {
+  MJS_OK = 0,
+  MJS_ERR_INVALID_ARG = -1,
+  MJS_ERR_NO_DEVICE = -2,
+  MJS_ERR_HIP = -3,
+  MJS_ERR_ALLOC = -4,
+  MJS_ERR_UNSUPPORTED = -5
+};
+
+typedef struct mjs_handle mjs_handle;
+
+typedef struct {
+  int32_t task;                 /* MJS_TASK_* */
+  int32_t num_envs;             /* N on this GPU */
+  int32_t device;               /* HIP device ordinal */
+  int32_t reward_type;          /* MJS_REW_*; <0 = task default */
+  int32_t autoreset;            /* MJS_AUTORESET_* */
+  int32_t terminate_on_success; /* Robot-Reach opt-in; ignored by Pointmass */
+  int32_t env_index_offset;     /* global index of local env 0 (multi-GPU shards keep global seeds) */
+  int32_t reserved;
+  double time_limit;            /* composer.Environment(time_limit=...) (__init__.py:21); <=0 = task default */
+} mjs_config;
+
+/* Per-step outputs. Device pointers, caller-owned, any may be NULL.
+ * Replaces the (obs, reward, terminated, truncated, info) tuple of
+ * DMCEnvironmentAdapter.step (environments/dmc2gym.py:133-155). */
+typedef struct {
+  double* obs;           /* [N, obs_dim] row-major, layout: mjs_obs_dim() */
+  double* terminal_obs;  /* [N, obs_dim]; written only under SAME_STEP for envs that ended */
+  double* reward;        /* [N]; 0 on FIRST (dm_env: None) */
+  double* discount;      /* [N]; info["discount"] (dmc2gym.py:153); 1 on FIRST (dm_env: None) */
+  uint8_t* terminated;   /* [N]; last && discount == 0 (dmc2gym.py:145) */
+  uint8_t* truncated;    /* [N]; last && discount > 0  (dmc2gym.py:144) */
+  uint8_t* is_success;   /* [N]; info["is_success"] (dmc2gym.py:149-150) */
+  uint8_t* step_type;    /* [N]; MJS_STEP_* */
+  uint8_t* fault;        /* [N]; MJS_FAULT_* bits */
+  int32_t* ncon;         /* [N]; detected contacts after the step (MuJoCo's d->ncon) */
+} mjs_outputs;
+
+/* Rollout outputs: same fields with a leading time axis [T, N, ...]. */
+
+const char* mjs_version(void);
+/* flat observation width: Pointmass {pointmass/position(2), goal_position(2)} (point_reach.py:115-118);
+ * Robot-Reach {ur5e/tcp_position(3), ur5e/joint_configuration(6), target_position(3)}
+ * (robot_reach.py:134-137, robot.py:292-298) */
+int mjs_obs_dim(int task);
+/* action width: 2 (point_reach.py:204-209) / 3 (robot_reach.py:187-201) */
+int mjs_action_dim(int task);
+/* number of float64 per env in mjs_get_state / mjs_set_state */
+int mjs_state_dim(int task);
+/* algorithmic HBM bytes one env-step moves (state R+W, action, outputs), from the real layout */
+int mjs_algorithmic_bytes_per_env_step(int task);
+/* physics substeps per control step: 5 (point_reach.py:24-25) / 20 (robot_reach.py:62-63) */
+int mjs_substeps(int task);
+
+/* Replaces task + composer.Environment + DMCEnvironmentAdapter construction
+ * (mujoco_sim/__init__.py:19-23). Allocates the SoA state for N envs. */
+int mjs_create(const mjs_config* cfg, mjs_handle** out);
+void mjs_destroy(mjs_handle* h);
+const char* mjs_last_error(const mjs_handle* h);
+
+/* Replaces DMCEnvironmentAdapter.seed (dmc2gym.py:126-131): env i gets the numpy-legacy
+ * MT19937 stream RandomState(base_seed + env_index_offset + i) (reach_sac.py:84 seeds
+ * sub-env `rank` with seed+rank). The stream lives on the device. */
+int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream);
+
+/* Replaces DMCEnvironmentAdapter.reset -> composer.Environment.reset (dmc2gym.py:157-163):
+ * starts a new episode for every env whose mask byte is non-zero (mask_dev NULL = all). */
+int mjs_reset(mjs_handle* h, const uint8_t* mask_dev, const mjs_outputs* out, void* stream);
+
+/* Replaces DMCEnvironmentAdapter.step -> composer.Environment.step -> n_sub x Physics.step
+ * (dmc2gym.py:133-155): one control step of all N envs, one kernel launch.
+ * actions_dev: float64 [N, action_dim]. */
+int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, void* stream);
+
+/* T consecutive mjs_step calls with precomputed actions [T, N, action_dim]; outputs carry a
+ * leading T axis. Open-loop rollouts (random / scripted policies, point_reach.py:218-240). */
+int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_outputs* out, void* stream);
+
+/* checkpoint / resume of the physics+task state (not the RNG): float64 [state_dim, N] */
+int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);
+int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MJSIM_H */

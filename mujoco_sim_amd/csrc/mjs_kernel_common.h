@@ -1,0 +1,60 @@
+// mjs_kernel_common.h — launch parameters shared by the task kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mjsim.h"
+#include "../../include/mjs_scene_spec.h"
+#include "mjs_dev_math.h"
+#include "mjs_dev_rng.h"
+
+// per-env flag byte
+enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2 };
+
+struct KernelParams {
+  int N;
+  int reward_type;
+  int autoreset;
+  int terminate_on_success;
+  double time_limit;
+  double* state;    // [state_dim][N] struct-of-arrays float64
+  uint8_t* flags;   // [N]
+  DevRng rng;
+  const double* actions;      // [N, A] (step) or nullptr (reset)
+  const uint8_t* reset_mask;  // reset kernel only; nullptr = all
+  mjs_outputs out;
+};
+
+template <int OBS>
+__device__ __forceinline__ void write_outputs(const KernelParams& p, int i, const double* obs, double reward, double discount,
+                                              int step_type, bool terminated, bool truncated, bool success, int fault, int ncon) {
+  if (p.out.obs) {
+#pragma unroll
+    for (int k = 0; k < OBS; k++) p.out.obs[(size_t)i * OBS + k] = obs[k];
+  }
+  if (p.out.reward) p.out.reward[i] = reward;
+  if (p.out.discount) p.out.discount[i] = discount;
+  if (p.out.terminated) p.out.terminated[i] = terminated;
+  if (p.out.truncated) p.out.truncated[i] = truncated;
+  if (p.out.is_success) p.out.is_success[i] = success;
+  if (p.out.step_type) p.out.step_type[i] = (uint8_t)step_type;
+  if (p.out.fault) p.out.fault[i] = (uint8_t)fault;
+  if (p.out.ncon) p.out.ncon[i] = ncon;
+}
+
+// MuJoCo impedance curve d(r) (mj_makeImpedance / getimpedance) for the default solimp
+__device__ __forceinline__ double impedance_default(double pos_minus_margin) {
+  const double d0 = MJS_SOLIMP_D0, d1 = MJS_SOLIMP_DWIDTH, width = MJS_SOLIMP_WIDTH, mid = MJS_SOLIMP_MIDPOINT;
+  double x = pos_minus_margin / width;
+  if (x < 0) x = -x;
+  if (x >= 1 || x <= 0) return (x >= 1) ? d1 : d0;
+  double y;
+  if (x <= mid) {
+    double a = 1 / mid;  // power 2: 1/mid^(p-1)
+    y = a * (x * x);
+  } else {
+    double b = 1 / (1 - mid);
+    y = 1 - b * ((1 - x) * (1 - x));
+  }
+  return d0 + y * (d1 - d0);
+}

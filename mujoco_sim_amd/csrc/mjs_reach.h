@@ -1,0 +1,505 @@
+// mjs_reach.h — Robot-Reach (UR5e 6-DoF) fused control-step kernel (BASELINE config 3, the
+// headline workload).
+//
+// One env per wavefront lane; persistent state (q6, v6, time, target3 = 16 doubles, SoA in HBM)
+// is read and written once per control step; the analytic IK, the 20 physics substeps and the
+// observation/reward/termination logic run in registers.
+// Path replaced (reference, paths under /root/reference/mujoco_sim/):
+//   environments/tasks/robot_reach.py:159-169 before_step -> entities/robots/robot.py:218-259
+//       servoL/servoJ (TCP pose -> flange pose -> analytic IK closest to current q -> 2-waypoint
+//       joint trajectory)
+//   per substep: robot.py:261-263 + entities/robots/joint_trajectory.py:33-47 (ctrl = lerp) and
+//       Physics.step() on the UR5e scene of robot_reach.py:90-119: forward kinematics,
+//       composite-rigid-body inertia, Coriolis/centrifugal bias (RNE), gravity compensation on
+//       the arm bodies (robot.py:80-82) with the un-compensated end-effector payload, affine
+//       position servos with force clamp, implicitfast integration
+//   robot.py:153-168,292-298 observables (tcp_position, joint_configuration),
+//       robot_reach.py:122,171-181,206-207 target observable / reward / success
+//   robot_reach.py:143-150 + environments/tasks/spaces.py:24-31 initialize_episode (6 uniforms + IK)
+//   dm_control composer loop + environments/dmc2gym.py:144-153 termination / truncation split
+// Dynamics are written in world axes about the world origin (same formulation as the oracle,
+// hand-specialised to the UR5e chain; gravity compensation is folded analytically: only the
+// payload's weight survives). Bound: per-lane FP64 dependency chains, not HBM.
+#pragma once
+#include "mjs_kernel_common.h"
+
+namespace rr {
+
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, STATE_DIM = 16;
+constexpr int OBS_DIM = 12, ACT_DIM = 3, NJ = 6;
+constexpr double PI = 3.14159265358979323846;
+
+// ----------------------------------------------------------------------------- constants
+// wrist_3 link merged with the lumped 2F-85 payload (deviation D-1). Both COMs lie on the local
+// y axis and both tensors are diagonal in the wrist_3 frame (flange frame = Rx(-90deg)).
+constexpr double W3_M = MJS_UR_BODY_MASS[6], W3_CY = MJS_UR_BODY_IPOS[6][1];
+// inertial frame of wrist_3 is Rz(90deg): principal x -> body y
+constexpr double W3_IXX = MJS_UR_BODY_DIAGINERTIA[6][1], W3_IYY = MJS_UR_BODY_DIAGINERTIA[6][0], W3_IZZ = MJS_UR_BODY_DIAGINERTIA[6][2];
+constexpr double PL_M = MJS_G2F85_MASS, PL_CY = MJS_UR_FLANGE_POS[1] + MJS_G2F85_IPOS[2];
+constexpr double PL_IXX = MJS_G2F85_DIAGINERTIA[0], PL_IYY = MJS_G2F85_DIAGINERTIA[2], PL_IZZ = MJS_G2F85_DIAGINERTIA[1];
+constexpr double L6_M = W3_M + PL_M;
+constexpr double L6_CY = (W3_M * W3_CY + PL_M * PL_CY) / L6_M;
+constexpr double L6_D1 = W3_CY - L6_CY, L6_D2 = PL_CY - L6_CY;
+constexpr double L6_IXX = W3_IXX + PL_IXX + W3_M * L6_D1 * L6_D1 + PL_M * L6_D2 * L6_D2;
+constexpr double L6_IYY = W3_IYY + PL_IYY;
+constexpr double L6_IZZ = W3_IZZ + PL_IZZ + W3_M * L6_D1 * L6_D1 + PL_M * L6_D2 * L6_D2;
+constexpr double TCP_OFFSET = MJS_UR_FLANGE_POS[1] + MJS_G2F85_TCP_Z;  // along wrist_3 local y
+
+struct Chain {
+  V3 p[7];  // body origins, 0 = base .. 6 = wrist_3
+  M3 R[7];
+};
+
+// mj_kinematics specialised to the UR5e tree (include/mjs_scene_spec.h MJS_UR_BODY_*)
+MJS_DEV void fk(const double* q, Chain& c) {
+  double s, co;
+  c.R[0] = M3{v3(-1, 0, 0), v3(0, -1, 0), v3(0, 0, 1)};  // base quat (0,0,0,-1): Rz(180deg), robot.py:320
+  c.p[0] = v3(0, 0, 0);
+  sincos(q[0], &s, &co);  // shoulder: hinge z
+  c.p[1] = madd(c.p[0], MJS_UR_BODY_POS[1][2], c.R[0].cz);
+  c.R[1] = mul_rot_z(c.R[0], co, s);
+  sincos(q[1], &s, &co);  // upper arm: Ry(90) then hinge y
+  c.p[2] = madd(c.p[1], MJS_UR_BODY_POS[2][1], c.R[1].cy);
+  c.R[2] = mul_rot_y(mul_quarter_y(c.R[1]), co, s);
+  sincos(q[2], &s, &co);  // forearm: hinge y
+  c.p[3] = madd(madd(c.p[2], MJS_UR_BODY_POS[3][1], c.R[2].cy), MJS_UR_BODY_POS[3][2], c.R[2].cz);
+  c.R[3] = mul_rot_y(c.R[2], co, s);
+  sincos(q[3], &s, &co);  // wrist 1: Ry(90) then hinge y
+  c.p[4] = madd(c.p[3], MJS_UR_BODY_POS[4][2], c.R[3].cz);
+  c.R[4] = mul_rot_y(mul_quarter_y(c.R[3]), co, s);
+  sincos(q[4], &s, &co);  // wrist 2: hinge z
+  c.p[5] = madd(c.p[4], MJS_UR_BODY_POS[5][1], c.R[4].cy);
+  c.R[5] = mul_rot_z(c.R[4], co, s);
+  sincos(q[5], &s, &co);  // wrist 3: hinge y
+  c.p[6] = madd(c.p[5], MJS_UR_BODY_POS[6][2], c.R[5].cz);
+  c.R[6] = mul_rot_y(c.R[5], co, s);
+}
+MJS_DEV V3 joint_axis(const Chain& c, int j) {  // j = 0..5, joint j on body j+1
+  return (j == 0 || j == 4) ? c.R[j + 1].cz : c.R[j + 1].cy;
+}
+MJS_DEV V3 tcp_position(const Chain& c) { return madd(c.p[6], TCP_OFFSET, c.R[6].cy); }
+
+// spatial inertia about the world origin: axisymmetric-about-local-z tensor (a,a,cz) at COM com
+MJS_DEV SI si_axisym(V3 axis, V3 com, double mass, double a, double cz) {
+  double k = cz - a, c2 = dot(com, com);
+  SI I;
+  I.xx = a + k * axis.x * axis.x + mass * (c2 - com.x * com.x);
+  I.xy = k * axis.x * axis.y - mass * com.x * com.y;
+  I.xz = k * axis.x * axis.z - mass * com.x * com.z;
+  I.yy = a + k * axis.y * axis.y + mass * (c2 - com.y * com.y);
+  I.yz = k * axis.y * axis.z - mass * com.y * com.z;
+  I.zz = a + k * axis.z * axis.z + mass * (c2 - com.z * com.z);
+  I.h = mass * com;
+  I.m = mass;
+  return I;
+}
+MJS_DEV SI si_diag(M3 R, V3 com, double mass, double dx, double dy, double dz) {
+  double c2 = dot(com, com);
+  SI I;
+  I.xx = dx * R.cx.x * R.cx.x + dy * R.cy.x * R.cy.x + dz * R.cz.x * R.cz.x + mass * (c2 - com.x * com.x);
+  I.xy = dx * R.cx.x * R.cx.y + dy * R.cy.x * R.cy.y + dz * R.cz.x * R.cz.y - mass * com.x * com.y;
+  I.xz = dx * R.cx.x * R.cx.z + dy * R.cy.x * R.cy.z + dz * R.cz.x * R.cz.z - mass * com.x * com.z;
+  I.yy = dx * R.cx.y * R.cx.y + dy * R.cy.y * R.cy.y + dz * R.cz.y * R.cz.y + mass * (c2 - com.y * com.y);
+  I.yz = dx * R.cx.y * R.cx.z + dy * R.cy.y * R.cy.z + dz * R.cz.y * R.cz.z - mass * com.y * com.z;
+  I.zz = dx * R.cx.z * R.cx.z + dy * R.cy.z * R.cy.z + dz * R.cz.z * R.cz.z + mass * (c2 - com.z * com.z);
+  I.h = mass * com;
+  I.m = mass;
+  return I;
+}
+
+// One forward-dynamics evaluation + implicitfast solve: returns the acceleration that the
+// integrator applies, (M - dt*dF/dv)^-1 (qfrc_smooth) with no constraint rows active.
+MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, double* qacc_int) {
+  Chain c;
+  fk(q, c);
+  // motion subspaces about the world origin
+  SV S[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    V3 ax = joint_axis(c, j);
+    S[j] = SV{ax, cross(c.p[j + 1], ax)};
+  }
+  // body inertias (bodies 1..6), all links axisymmetric about local z except the merged last link
+  SI I[NJ];
+  I[0] = si_axisym(c.R[1].cz, c.p[1], MJS_UR_BODY_MASS[1], MJS_UR_BODY_DIAGINERTIA[1][0], MJS_UR_BODY_DIAGINERTIA[1][2]);
+  I[1] = si_axisym(c.R[2].cz, madd(c.p[2], MJS_UR_BODY_IPOS[2][2], c.R[2].cz), MJS_UR_BODY_MASS[2], MJS_UR_BODY_DIAGINERTIA[2][0], MJS_UR_BODY_DIAGINERTIA[2][2]);
+  I[2] = si_axisym(c.R[3].cz, madd(c.p[3], MJS_UR_BODY_IPOS[3][2], c.R[3].cz), MJS_UR_BODY_MASS[3], MJS_UR_BODY_DIAGINERTIA[3][0], MJS_UR_BODY_DIAGINERTIA[3][2]);
+  I[3] = si_axisym(c.R[4].cz, madd(c.p[4], MJS_UR_BODY_IPOS[4][1], c.R[4].cy), MJS_UR_BODY_MASS[4], MJS_UR_BODY_DIAGINERTIA[4][0], MJS_UR_BODY_DIAGINERTIA[4][2]);
+  I[4] = si_axisym(c.R[5].cz, madd(c.p[5], MJS_UR_BODY_IPOS[5][2], c.R[5].cz), MJS_UR_BODY_MASS[5], MJS_UR_BODY_DIAGINERTIA[5][0], MJS_UR_BODY_DIAGINERTIA[5][2]);
+  I[5] = si_diag(c.R[6], madd(c.p[6], L6_CY, c.R[6].cy), L6_M, L6_IXX, L6_IYY, L6_IZZ);
+  // velocities and Coriolis accelerations (mj_comVel, mj_rne forward pass without gravity)
+  SV vel[NJ], acc[NJ], F[NJ];
+  {
+    SV vp = SV{v3(0, 0, 0), v3(0, 0, 0)}, ap = vp;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      acc[j] = ap + v[j] * cross_motion(vp, S[j]);
+      vel[j] = vp + v[j] * S[j];
+      vp = vel[j];
+      ap = acc[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) F[j] = si_mul(I[j], acc[j]) + cross_force(vel[j], si_mul(I[j], vel[j]));
+  // gravity: compensated on the arm bodies, acting on the payload only
+  {
+    V3 cpl = madd(c.p[6], PL_CY, c.R[6].cy);
+    V3 W = v3(0, 0, PL_M * MJS_GRAVITY_Z);
+    F[5].w = F[5].w - cross(cpl, W);
+    F[5].v = F[5].v - W;
+  }
+#pragma unroll
+  for (int j = NJ - 2; j >= 0; j--) F[j] = F[j] + F[j + 1];
+  // composite inertias and the joint-space inertia matrix (mj_crb), lower triangle
+#pragma unroll
+  for (int j = NJ - 2; j >= 0; j--) I[j] = I[j] + I[j + 1];
+  double A[NJ][NJ], rhs[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+    SV f = si_mul(I[i], S[i]);
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = dot(S[j], f);
+  }
+  // actuators (mj_fwdActuation) and the implicitfast system matrix
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    double cj = clampd(ctrl[j], MJS_UR_ACT_CTRLRANGE[j][0], MJS_UR_ACT_CTRLRANGE[j][1]);
+    double f = MJS_UR_ACT_KP[j] * cj + 0.0 + (-MJS_UR_ACT_KP[j]) * q[j] + (-MJS_UR_ACT_KD[j]) * v[j];
+    double fc = clampd(f, -MJS_UR_ACT_FRC[j], MJS_UR_ACT_FRC[j]);
+    bool clamped = (fc <= -MJS_UR_ACT_FRC[j]) || (fc >= MJS_UR_ACT_FRC[j]);
+    rhs[j] = -dot(S[j], F[j]) + fc;  // qfrc_smooth = passive - bias + actuator
+    A[j][j] += MJS_UR_ARMATURE;
+    if (!clamped) A[j][j] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j];  // -dt * d(actuator)/dv
+  }
+  // LDL^T factorisation and solve, fully unrolled (L overwrites the strict lower triangle of A)
+  double Dg[NJ], Dinv[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j < i; j++) {
+      double s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k] * Dg[k];
+      A[i][j] = s * Dinv[j];
+    }
+    double d = A[i][i];
+#pragma unroll
+    for (int k = 0; k < i; k++) d -= A[i][k] * A[i][k] * Dg[k];
+    Dg[i] = d;
+    Dinv[i] = 1.0 / d;
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int k = 0; k < i; k++) rhs[i] -= A[i][k] * rhs[k];
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) rhs[i] *= Dinv[i];
+#pragma unroll
+  for (int i = NJ - 1; i >= 0; i--) {
+#pragma unroll
+    for (int k = i + 1; k < NJ; k++) rhs[i] -= A[k][i] * rhs[k];
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
+}
+
+// ------------------------------------------------------------------------- analytic IK
+// (third-party ur_analytic_ik, call site robot.py:33-37; Hawkins 2013; same decision logic as
+// oracle/om_ik.c). Pose = rotation R (row-major r[9]) + translation of the FLANGE.
+MJS_DEV double wrap_pi(double x) {
+  while (x > PI) x -= 2 * PI;
+  while (x <= -PI) x += 2 * PI;
+  return x;
+}
+MJS_DEV double clamp_unit(double x, bool& ok) {
+  if (x > 1.0) { if (x > 1.0 + 1e-9) ok = false; return 1.0; }
+  if (x < -1.0) { if (x < -1.0 - 1e-9) ok = false; return -1.0; }
+  return x;
+}
+struct Aff {
+  double r[9];
+  double t[3];
+};
+MJS_DEV Aff aff_mul(const Aff& a, const Aff& b) {
+  Aff o;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) o.r[3 * i + j] = a.r[3 * i] * b.r[j] + a.r[3 * i + 1] * b.r[3 + j] + a.r[3 * i + 2] * b.r[6 + j];
+    o.t[i] = a.r[3 * i] * b.t[0] + a.r[3 * i + 1] * b.t[1] + a.r[3 * i + 2] * b.t[2] + a.t[i];
+  }
+  return o;
+}
+MJS_DEV Aff aff_inv(const Aff& a) {
+  Aff o;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+#pragma unroll
+    for (int j = 0; j < 3; j++) o.r[3 * i + j] = a.r[3 * j + i];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) o.t[i] = -(o.r[3 * i] * a.t[0] + o.r[3 * i + 1] * a.t[1] + o.r[3 * i + 2] * a.t[2]);
+  return o;
+}
+// DH transform Rz(th) Tz(d) Tx(a) Rx(al), al in {+pi/2, 0, -pi/2} given by (ca, sa)
+MJS_DEV Aff dh(double th, double d, double a, double ca, double sa) {
+  double st, ct;
+  sincos(th, &st, &ct);
+  Aff o;
+  o.r[0] = ct; o.r[1] = -st * ca; o.r[2] = st * sa;
+  o.r[3] = st; o.r[4] = ct * ca; o.r[5] = -ct * sa;
+  o.r[6] = 0; o.r[7] = sa; o.r[8] = ca;
+  o.t[0] = a * ct; o.t[1] = a * st; o.t[2] = d;
+  return o;
+}
+
+// returns false when no solution exists; q_out = solution closest to q_guess
+__device__ __noinline__ bool ik_closest(const Aff& T, const double* q_guess, double* q_out) {
+  const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
+  double p05x = T.t[0] - d6 * T.r[2], p05y = T.t[1] - d6 * T.r[5];
+  double rxy = sqrt(p05x * p05x + p05y * p05y);
+  if (rxy < fabs(d4)) return false;
+  double psi = atan2(p05y, p05x), phi = acos(d4 / rxy);
+  Aff Tinv = aff_inv(T);
+  double best = INFINITY;
+  bool found = false;
+#pragma unroll 1
+  for (int s1 = 0; s1 < 2; s1++) {
+    double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
+    double sn1, c1;
+    sincos(th1, &sn1, &c1);
+    bool ok5 = true;
+    double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
+    if (!ok5) continue;
+#pragma unroll 1
+    for (int s5 = 0; s5 < 2; s5++) {
+      double th5 = (s5 ? -1.0 : 1.0) * acos(c5);
+      double sn5 = sin(th5), th6;
+      if (fabs(sn5) < 1e-12) th6 = 0;
+      else {
+        double X60x = Tinv.r[0], X60y = Tinv.r[3], Y60x = Tinv.r[1], Y60y = Tinv.r[4];
+        th6 = atan2((-X60y * sn1 + Y60y * c1) / sn5, (X60x * sn1 - Y60x * c1) / sn5);
+      }
+      Aff T01 = dh(th1, d1, 0, 0, 1), T45 = dh(th5, d5, 0, 0, -1), T56 = dh(th6, d6, 0, 1, 0);
+      Aff T14 = aff_mul(aff_mul(aff_inv(T01), T), aff_inv(aff_mul(T45, T56)));
+      double px = T14.t[0], py = T14.t[1];
+      double r2 = px * px + py * py;
+      bool ok3 = true;
+      double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
+      if (!ok3) continue;
+#pragma unroll 1
+      for (int s3 = 0; s3 < 2; s3++) {
+        double th3 = (s3 ? -1.0 : 1.0) * acos(c3);
+        double sn3, cs3;
+        sincos(th3, &sn3, &cs3);
+        double th2 = atan2(py, px) - atan2(a3 * sn3, a2 + a3 * cs3);
+        Aff T13 = aff_mul(dh(th2, 0, a2, 1, 0), dh(th3, 0, a3, 1, 0));
+        Aff T34 = aff_mul(aff_inv(T13), T14);
+        double th4 = atan2(T34.r[3], T34.r[0]);
+        double qs[6] = {wrap_pi(th1), wrap_pi(th2), wrap_pi(th3), wrap_pi(th4), wrap_pi(th5), wrap_pi(th6)};
+        bool finite = true;
+        double dist = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          finite = finite && isfinite(qs[j]);
+          double alt = qs[j] + (q_guess[j] > qs[j] ? 2 * PI : -2 * PI);
+          if (fabs(alt - q_guess[j]) < fabs(qs[j] - q_guess[j]) && fabs(alt) <= 2 * PI) qs[j] = alt;
+          dist += (qs[j] - q_guess[j]) * (qs[j] - q_guess[j]);
+        }
+        if (finite && dist < best) {
+          best = dist;
+          found = true;
+#pragma unroll
+          for (int j = 0; j < 6; j++) q_out[j] = qs[j];
+        }
+      }
+    }
+  }
+  return found;
+}
+
+// TCP pose (position + scalar-LAST quaternion, type_aliases.py:6-10) -> joints (robot.py:113-121,138-151)
+MJS_DEV bool tcp_pose_to_joints(const double* pos, const double* q_guess, double* q_out) {
+  double x = MJS_TOP_DOWN_QUAT_XYZW[0], y = MJS_TOP_DOWN_QUAT_XYZW[1], z = MJS_TOP_DOWN_QUAT_XYZW[2], w = MJS_TOP_DOWN_QUAT_XYZW[3];
+  double n = sqrt(x * x + y * y + z * z + w * w);
+  x /= n; y /= n; z /= n; w /= n;
+  Aff T;
+  T.r[0] = 1 - 2 * (y * y + z * z); T.r[1] = 2 * (x * y - z * w); T.r[2] = 2 * (x * z + y * w);
+  T.r[3] = 2 * (x * y + z * w); T.r[4] = 1 - 2 * (x * x + z * z); T.r[5] = 2 * (y * z - x * w);
+  T.r[6] = 2 * (x * z - y * w); T.r[7] = 2 * (y * z + x * w); T.r[8] = 1 - 2 * (x * x + y * y);
+  T.t[0] = pos[0] - T.r[2] * MJS_G2F85_TCP_Z;
+  T.t[1] = pos[1] - T.r[5] * MJS_G2F85_TCP_Z;
+  T.t[2] = pos[2] - T.r[8] * MJS_G2F85_TCP_Z;
+  return ik_closest(T, q_guess, q_out);
+}
+
+// ----------------------------------------------------------------- contact detection
+// floor plane z = 0 vs the arm's collision proxies (MJS_UR_COL_*): number of contacts MuJoCo
+// would list (capsule: one per end sphere; cylinder: mjc_PlaneCylinder up to 4)
+__device__ __noinline__ int count_floor_contacts(const Chain& c) {
+  int n = 0;
+#pragma unroll
+  for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
+    const int b = MJS_UR_COL_BODY[g];
+    const M3 R = c.R[b];
+    V3 gp = madd(madd(madd(c.p[b], MJS_UR_COL_POS[g][0], R.cx), MJS_UR_COL_POS[g][1], R.cy), MJS_UR_COL_POS[g][2], R.cz);
+    // local quat is identity or (1,1,0,0) = Rx(90deg): geom z axis = -body y, geom x axis = body x
+    const bool rot = MJS_UR_COL_QUAT[g][1] != 0.0;
+    V3 axis = rot ? -R.cy : R.cz;
+    const double rad = MJS_UR_COL_SIZE[g][0], half = MJS_UR_COL_SIZE[g][1];
+    if (MJS_UR_COL_TYPE[g] == 3) {
+      n += (gp.z - half * axis.z <= rad);
+      n += (gp.z + half * axis.z <= rad);
+    } else {
+      // mjc_PlaneCylinder with plane normal (0,0,1) through the origin
+      V3 nrm = v3(0, 0, 1);
+      double dist0 = gp.z, prjaxis = axis.z;
+      if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
+      V3 vec = prjaxis * axis - nrm;
+      double len = sqrt(dot(vec, vec));
+      if (len < 1e-12) vec = rad * R.cx;
+      else vec = (rad / len) * vec;
+      double prjvec = vec.z;
+      axis = half * axis;
+      prjaxis *= half;
+      if (dist0 + prjaxis + prjvec > 0) continue;
+      n += 1;
+      n += (dist0 - prjaxis + prjvec <= 0);
+      V3 side = cross(vec, axis);
+      if (sqrt(dot(side, side)) > 1e-12 && dist0 + prjaxis - 0.5 * prjvec <= 0) n += 2;
+    }
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------------------- kernel
+struct State {
+  double q[NJ], v[NJ], time, target[3];
+};
+MJS_DEV State load_state(const KernelParams& p, int i) {
+  State st;
+  const double* s = p.state + i;
+  const size_t N = p.N;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st.q[j] = s[(S_Q + j) * N]; st.v[j] = s[(S_V + j) * N]; }
+  st.time = s[S_TIME * N];
+#pragma unroll
+  for (int k = 0; k < 3; k++) st.target[k] = s[(S_TARGET + k) * N];
+  return st;
+}
+MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
+  double* s = p.state + i;
+  const size_t N = p.N;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { s[(S_Q + j) * N] = st.q[j]; s[(S_V + j) * N] = st.v[j]; }
+  s[S_TIME * N] = st.time;
+#pragma unroll
+  for (int k = 0; k < 3; k++) s[(S_TARGET + k) * N] = st.target[k];
+}
+
+// initialize_episode (robot_reach.py:143-150): robot xyz -> IK from qpos0 = 0 -> set joints;
+// then target xyz. Returns the per-episode ik_failed flag (always clear after a reset).
+MJS_DEV void episode_init(const KernelParams& p, int i, State& st) {
+  RngCursor c = rng_open(p.rng, i);
+  double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(p.rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+  bool ok = tcp_pose_to_joints(rp, zeros, q);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st.q[j] = ok ? q[j] : 0.0; st.v[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) st.target[k] = rng_uniform(p.rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+  rng_close(p.rng, i, c);
+  st.time = 0;
+}
+
+MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
+  V3 tcp = tcp_position(c);
+  obs[0] = tcp.x; obs[1] = tcp.y; obs[2] = tcp.z;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) obs[3 + j] = st.q[j];
+#pragma unroll
+  for (int k = 0; k < 3; k++) obs[9 + k] = st.target[k];
+}
+
+template <bool IS_RESET>
+__global__ __launch_bounds__(64) void kernel(KernelParams p) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N) return;
+  uint8_t flags = p.flags[i];
+  double obs[OBS_DIM];
+  Chain c;
+  if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
+    State st;
+    episode_init(p, i, st);
+    store_state(p, i, st);
+    p.flags[i] = 0;
+    fk(st.q, c);
+    make_obs(st, c, obs);
+    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, count_floor_contacts(c));
+    return;
+  }
+  State st = load_state(p, i);
+  // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
+  double q0[NJ], q1[NJ], act[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) q0[j] = st.q[j];
+  if (!tcp_pose_to_joints(act, q0, q1)) {
+    flags |= FLAG_IK_FAILED;  // reference raises ValueError; batched: flag + hold position (D-4)
+#pragma unroll
+    for (int j = 0; j < NJ; j++) q1[j] = q0[j];
+  }
+  const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
+  bool bad = false;
+#pragma unroll 1
+  for (int s = 0; s < MJS_RR_NSUB; s++) {
+    // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
+    double t = fmin(fmax(st.time, t0), t1);
+    double ctrl[NJ], qacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) / (t1 - t0);
+    dynamics(st.q, st.v, ctrl, qacc);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      bad = bad || bad_value(qacc[j]) || bad_value(st.q[j]) || bad_value(st.v[j]);
+      st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+      st.q[j] += MJS_RR_PHYSICS_DT * st.v[j];
+    }
+    st.time += MJS_RR_PHYSICS_DT;
+  }
+  // observables, reward, termination
+  fk(st.q, c);
+  make_obs(st, c, obs);
+  double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
+  double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  bool success = dist < MJS_RR_GOAL_THRESHOLD;
+  double reward = (p.reward_type == MJS_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist;
+  double discount = 1.0;
+  bool terminate = false;
+  if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
+  if (bad) { reward = 0; discount = 0; terminate = true; }
+  if (st.time >= p.time_limit) terminate = true;
+  int ncon = count_floor_contacts(c);
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0);
+  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
+    if (p.out.terminal_obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    episode_init(p, i, st);
+    newflags = 0;
+    fk(st.q, c);
+    make_obs(st, c, obs);
+  }
+  store_state(p, i, st);
+  p.flags[i] = newflags;
+  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+}
+
+}  // namespace rr

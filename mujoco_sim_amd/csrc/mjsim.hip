@@ -1,0 +1,247 @@
+// mjsim.hip — libmjsim.so: C ABI (include/mjsim.h) + kernel launches. gfx950 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "../../include/mjsim.h"
+#include "mjs_kernel_common.h"
+#include "mjs_pointmass.h"
+#include "mjs_reach.h"
+
+struct mjs_handle {
+  mjs_config cfg;
+  int state_dim, obs_dim, act_dim;
+  double* state;     // [state_dim][N]
+  uint8_t* flags;    // [N]
+  uint32_t* rng_mt;  // [624][N]
+  int32_t* rng_pos;  // [N]
+  std::string err;
+};
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(mjs_handle* h, int code, const std::string& msg) {
+  if (h) h->err = msg;
+  g_err = msg;
+  return code;
+}
+int hip_fail(mjs_handle* h, hipError_t e, const char* what) {
+  return fail(h, MJS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(h, expr)                                   \
+  do {                                                     \
+    hipError_t e_ = (expr);                                \
+    if (e_ != hipSuccess) return hip_fail(h, e_, #expr);   \
+  } while (0)
+
+double default_time_limit(int task) {
+  return task == MJS_TASK_POINTMASS_REACH ? MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT  // mujoco_sim/__init__.py:21,28
+                                          : MJS_RR_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT; // BASELINE config 3
+}
+int default_reward(int task) { return task == MJS_TASK_POINTMASS_REACH ? MJS_REW_DENSE_BIASED_NEG_DISTANCE : MJS_REW_DENSE_NEG_DISTANCE; }
+
+__global__ __launch_bounds__(64) void seed_kernel(DevRng rng, uint32_t base_seed, int offset) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rng.N) return;
+  rng_seed_lane(rng, i, base_seed + (uint32_t)(offset + i));
+}
+
+// Pointmass bookkeeping starts at 1.0 at construction (point_reach.py:112-113); flags = reset pending
+__global__ void init_kernel(double* state, uint8_t* flags, int N, int task) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  flags[i] = FLAG_RESET_PENDING;
+  if (task == MJS_TASK_POINTMASS_REACH) {
+    state[(size_t)pm::S_DIST * N + i] = 1.0;
+    state[(size_t)pm::S_PREV * N + i] = 1.0;
+  }
+}
+
+__global__ void get_state_kernel(const double* state, const uint8_t* flags, double* out, int N, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < S; k++) out[(size_t)k * N + i] = state[(size_t)k * N + i];
+  out[(size_t)S * N + i] = (double)flags[i];
+}
+__global__ void set_state_kernel(double* state, uint8_t* flags, const double* in, int N, int S) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  for (int k = 0; k < S; k++) state[(size_t)k * N + i] = in[(size_t)k * N + i];
+  flags[i] = (uint8_t)in[(size_t)S * N + i];
+}
+
+KernelParams make_params(const mjs_handle* h, const double* actions, const uint8_t* mask, const mjs_outputs* out) {
+  KernelParams p;
+  p.N = h->cfg.num_envs;
+  p.reward_type = h->cfg.reward_type;
+  p.autoreset = h->cfg.autoreset;
+  p.terminate_on_success = h->cfg.terminate_on_success;
+  p.time_limit = h->cfg.time_limit;
+  p.state = h->state;
+  p.flags = h->flags;
+  p.rng = DevRng{h->rng_mt, h->rng_pos, h->cfg.num_envs};
+  p.actions = actions;
+  p.reset_mask = mask;
+  if (out) p.out = *out; else std::memset(&p.out, 0, sizeof p.out);
+  return p;
+}
+
+constexpr int BLOCK = 64;  // one wavefront per workgroup: N/64 workgroups spread over the CUs
+inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
+
+template <bool IS_RESET>
+int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
+  if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else rr::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  HIP_TRY(h, hipGetLastError());
+  return MJS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mjs_version(void) { return "mjsim-hip 0.1 (gfx950, abi 1)"; }
+
+int mjs_obs_dim(int task) { return task == MJS_TASK_POINTMASS_REACH ? pm::OBS_DIM : task == MJS_TASK_ROBOT_REACH ? rr::OBS_DIM : -1; }
+int mjs_action_dim(int task) { return task == MJS_TASK_POINTMASS_REACH ? pm::ACT_DIM : task == MJS_TASK_ROBOT_REACH ? rr::ACT_DIM : -1; }
+int mjs_state_dim(int task) { return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : -1; }
+int mjs_substeps(int task) { return task == MJS_TASK_POINTMASS_REACH ? MJS_PM_NSUB : task == MJS_TASK_ROBOT_REACH ? MJS_RR_NSUB : -1; }
+
+int mjs_algorithmic_bytes_per_env_step(int task) {
+  // state read + state written + flag byte r/w + action + obs + reward + discount + 5 flag bytes + ncon
+  const int out_fixed = 8 + 8 + 5 + 4;
+  if (task == MJS_TASK_POINTMASS_REACH)
+    return 8 * pm::STATE_DIM /*R*/ + 8 * (pm::STATE_DIM - 2) /*W: target unchanged*/ + 2 + 8 * pm::ACT_DIM + 8 * pm::OBS_DIM + out_fixed;
+  if (task == MJS_TASK_ROBOT_REACH)
+    return 8 * rr::STATE_DIM /*R*/ + 8 * (rr::STATE_DIM - 3) /*W: target unchanged*/ + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;
+  return -1;
+}
+
+const char* mjs_last_error(const mjs_handle* h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+int mjs_create(const mjs_config* cfg, mjs_handle** out) {
+  if (!cfg || !out) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: null argument");
+  *out = nullptr;
+  if (cfg->task != MJS_TASK_POINTMASS_REACH && cfg->task != MJS_TASK_ROBOT_REACH)
+    return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: unknown task id");
+  if (cfg->num_envs <= 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: num_envs must be positive");
+  if (cfg->autoreset < MJS_AUTORESET_NEXT_STEP || cfg->autoreset > MJS_AUTORESET_DISABLED)
+    return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad autoreset mode");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, MJS_ERR_NO_DEVICE, "mjs_create: no HIP device visible (this library has no CPU path)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: device ordinal out of range");
+  mjs_handle* h = new (std::nothrow) mjs_handle();
+  if (!h) return fail(nullptr, MJS_ERR_ALLOC, "mjs_create: out of host memory");
+  h->cfg = *cfg;
+  if (h->cfg.reward_type < 0) h->cfg.reward_type = default_reward(cfg->task);
+  if (!(h->cfg.time_limit > 0)) h->cfg.time_limit = default_time_limit(cfg->task);
+  h->state_dim = mjs_state_dim(cfg->task) - 1;
+  h->obs_dim = mjs_obs_dim(cfg->task);
+  h->act_dim = mjs_action_dim(cfg->task);
+  h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr;
+  const size_t N = (size_t)cfg->num_envs;
+  hipError_t e = hipSetDevice(cfg->device);
+  if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(double) * h->state_dim * N);
+  if (e == hipSuccess) e = hipMalloc(&h->flags, N);
+  if (e == hipSuccess) e = hipMalloc(&h->rng_mt, sizeof(uint32_t) * 624 * N);
+  if (e == hipSuccess) e = hipMalloc(&h->rng_pos, sizeof(int32_t) * N);
+  if (e == hipSuccess) e = hipMemset(h->state, 0, sizeof(double) * h->state_dim * N);
+  if (e != hipSuccess) {
+    int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
+    mjs_destroy(h);
+    return rc;
+  }
+  init_kernel<<<grid_for((int)N), BLOCK>>>(h->state, h->flags, (int)N, cfg->task);
+  seed_kernel<<<grid_for((int)N), BLOCK>>>(DevRng{h->rng_mt, h->rng_pos, (int)N}, 0u, cfg->env_index_offset);
+  e = hipDeviceSynchronize();
+  if (e != hipSuccess) {
+    int rc = hip_fail(nullptr, e, "mjs_create: init kernels");
+    mjs_destroy(h);
+    return rc;
+  }
+  *out = h;
+  return MJS_OK;
+}
+
+void mjs_destroy(mjs_handle* h) {
+  if (!h) return;
+  if (h->state) (void)hipFree(h->state);
+  if (h->flags) (void)hipFree(h->flags);
+  if (h->rng_mt) (void)hipFree(h->rng_mt);
+  if (h->rng_pos) (void)hipFree(h->rng_pos);
+  delete h;
+}
+
+int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream) {
+  if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_seed: null handle");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  seed_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(DevRng{h->rng_mt, h->rng_pos, h->cfg.num_envs}, base_seed,
+                                                                           h->cfg.env_index_offset);
+  HIP_TRY(h, hipGetLastError());
+  return MJS_OK;
+}
+
+int mjs_reset(mjs_handle* h, const uint8_t* mask_dev, const mjs_outputs* out, void* stream) {
+  if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_reset: null handle");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return launch<true>(h, make_params(h, nullptr, mask_dev, out), (hipStream_t)stream);
+}
+
+int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, void* stream) {
+  if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_step: null handle");
+  if (!actions_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_step: actions_dev is null");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return launch<false>(h, make_params(h, actions_dev, nullptr, out), (hipStream_t)stream);
+}
+
+int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_outputs* out, void* stream) {
+  if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_rollout: null handle");
+  if (!actions_dev || T < 0) return fail(h, MJS_ERR_INVALID_ARG, "mjs_rollout: bad arguments");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t N = (size_t)h->cfg.num_envs;
+  for (int32_t t = 0; t < T; t++) {
+    mjs_outputs o;
+    std::memset(&o, 0, sizeof o);
+    if (out) {
+      o = *out;
+      if (o.obs) o.obs += (size_t)t * N * h->obs_dim;
+      if (o.terminal_obs) o.terminal_obs += (size_t)t * N * h->obs_dim;
+      if (o.reward) o.reward += t * N;
+      if (o.discount) o.discount += t * N;
+      if (o.terminated) o.terminated += t * N;
+      if (o.truncated) o.truncated += t * N;
+      if (o.is_success) o.is_success += t * N;
+      if (o.step_type) o.step_type += t * N;
+      if (o.fault) o.fault += t * N;
+      if (o.ncon) o.ncon += t * N;
+    }
+    int rc = launch<false>(h, make_params(h, actions_dev + (size_t)t * N * h->act_dim, nullptr, &o), (hipStream_t)stream);
+    if (rc != MJS_OK) return rc;
+  }
+  return MJS_OK;
+}
+
+int mjs_get_state(mjs_handle* h, double* state_dev, void* stream) {
+  if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_get_state: null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  get_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
+  HIP_TRY(h, hipGetLastError());
+  return MJS_OK;
+}
+
+int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
+  if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_set_state: null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
+  HIP_TRY(h, hipGetLastError());
+  return MJS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,204 @@
+"""HipVectorEnv — N environments of one task stepped by one HIP kernel per control step.
+
+Host-side mirror of the reference's step/reset boundary
+(mujoco_sim/environments/dmc2gym.py:133-163) with a gymnasium ``VectorEnv``-shaped surface:
+``reset(seed=...) -> (obs, info)``, ``step(actions) -> (obs, reward, terminated, truncated,
+info)``; everything stays on the GPU as torch tensors (float64 like MuJoCo's mjtNum).
+PyTorch is plumbing only (device memory + streams); the arithmetic is libmjsim.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from .spaces import Box, Dict, batch_box
+
+# reward / observation type strings of the reference (point_reach.py:11-17, robot_reach.py:37-41)
+SPARSE_REWARD = "sparse_reward"
+DENSE_POTENTIAL_REWARD = "dense_potential_reward"
+DENSE_NEG_DISTANCE_REWARD = "dense_negative_distance_reward"
+DENSE_BIASED_NEG_DISTANCE_REWARD = "dense_biased_negative_distance_reward"
+STATE_OBS = "state_observations"
+VISUAL_OBS = "visual_observations"
+
+_REWARD_IDS = {
+    SPARSE_REWARD: nat.REW_SPARSE,
+    DENSE_POTENTIAL_REWARD: nat.REW_DENSE_POTENTIAL,
+    DENSE_NEG_DISTANCE_REWARD: nat.REW_DENSE_NEG_DISTANCE,
+    DENSE_BIASED_NEG_DISTANCE_REWARD: nat.REW_DENSE_BIASED_NEG_DISTANCE,
+}
+_AUTORESET_IDS = {"next_step": nat.AUTORESET_NEXT_STEP, "same_step": nat.AUTORESET_SAME_STEP, "disabled": nat.AUTORESET_DISABLED}
+
+
+@dataclass(frozen=True)
+class TaskSpec:
+    name: str
+    task_id: int
+    obs_layout: tuple  # ((key, start, length), ...) in the reference's observation-dict order
+    action_low: tuple
+    action_high: tuple
+    action_dtype: type  # dtype of the dm_env action spec
+    reward_types: tuple
+    control_timestep: float
+    physics_timestep: float
+    max_control_steps: int
+
+
+TASKS = {
+    # point_reach.py:115-118 (STATE_OBS), :204-209 action spec, :24-28 timing
+    "point_mass_reach": TaskSpec(
+        "point_mass_reach", nat.TASK_POINTMASS_REACH,
+        (("pointmass/position", 0, 2), ("goal_position", 2, 2)),
+        (-0.05, -0.05), (0.05, 0.05), np.float32,
+        (SPARSE_REWARD, DENSE_POTENTIAL_REWARD, DENSE_NEG_DISTANCE_REWARD, DENSE_BIASED_NEG_DISTANCE_REWARD),
+        0.1, 0.02, 50),
+    # robot_reach.py:134-137 + robot.py:296-298 (BASELINE "joint-space obs"), :187-201 action spec, :59-64 timing
+    "robot_reach": TaskSpec(
+        "robot_reach", nat.TASK_ROBOT_REACH,
+        (("ur5e/tcp_position", 0, 3), ("ur5e/joint_configuration", 3, 6), ("target_position", 9, 3)),
+        (-0.1, -0.6, 0.02), (0.1, -0.4, 0.2), np.float64,
+        (SPARSE_REWARD, DENSE_NEG_DISTANCE_REWARD),
+        0.1, 0.005, 100),
+}
+
+
+def _as_uint8_ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class HipVectorEnv:
+    """Batched environment on one GPU. One handle = one process = one device."""
+
+    def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
+                 autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
+                 terminate_on_success: bool = False, env_index_offset: int = 0):
+        if task not in TASKS:
+            raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
+        self.spec = TASKS[task]
+        if reward_type is not None and reward_type not in self.spec.reward_types:
+            raise AssertionError(f"reward_type {reward_type!r} not in {self.spec.reward_types}")  # reference asserts (point_reach.py:68)
+        if autoreset not in _AUTORESET_IDS:
+            raise ValueError(f"autoreset must be one of {sorted(_AUTORESET_IDS)}")
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        if self.device.type != "cuda" or not torch.cuda.is_available():
+            raise nat.MjsError("HipVectorEnv needs a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self.num_envs = int(num_envs)
+        self.autoreset = autoreset
+        self.env_index_offset = int(env_index_offset)
+        self._lib = nat.lib()
+        cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self.device.index or 0,
+                            reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
+                            terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, reserved=0,
+                            time_limit=float(time_limit) if time_limit is not None else -1.0)
+        h = C.c_void_p()
+        nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+        self.obs_dim = self._lib.mjs_obs_dim(self.spec.task_id)
+        self.action_dim = self._lib.mjs_action_dim(self.spec.task_id)
+        self.state_dim = self._lib.mjs_state_dim(self.spec.task_id)
+        self.algorithmic_bytes_per_env_step = self._lib.mjs_algorithmic_bytes_per_env_step(self.spec.task_id)
+        N, dev = self.num_envs, self.device
+        self._buf = {
+            "obs": torch.zeros(N, self.obs_dim, dtype=torch.float64, device=dev),
+            "terminal_obs": torch.zeros(N, self.obs_dim, dtype=torch.float64, device=dev),
+            "reward": torch.zeros(N, dtype=torch.float64, device=dev),
+            "discount": torch.ones(N, dtype=torch.float64, device=dev),
+            "terminated": torch.zeros(N, dtype=torch.uint8, device=dev),
+            "truncated": torch.zeros(N, dtype=torch.uint8, device=dev),
+            "is_success": torch.zeros(N, dtype=torch.uint8, device=dev),
+            "step_type": torch.zeros(N, dtype=torch.uint8, device=dev),
+            "fault": torch.zeros(N, dtype=torch.uint8, device=dev),
+            "ncon": torch.zeros(N, dtype=torch.int32, device=dev),
+        }
+        self._out = self._make_outputs(self._buf)
+        # spaces (dmc2gym.py:55-63,90,99-101)
+        self.single_observation_space = Dict(OrderedDict(
+            (k, Box(-np.inf, np.inf, shape=(n,), dtype=np.float64)) for k, _, n in self.spec.obs_layout))
+        self.single_action_space = Box(np.asarray(self.spec.action_low, dtype=np.float32), np.asarray(self.spec.action_high, dtype=np.float32), dtype=np.float32)
+        self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
+        self.action_space = batch_box(self.single_action_space, N)
+        if seed is not None:
+            self.seed(seed)
+
+    # ------------------------------------------------------------------ plumbing
+    @staticmethod
+    def _make_outputs(buf) -> nat.MjsOutputs:
+        return nat.MjsOutputs(**{k: C.c_void_p(v.data_ptr()) if v is not None else None for k, v in buf.items()})
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _obs_dict(self, flat):
+        return OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout)
+
+    def _info(self, b):
+        return {"is_success": b["is_success"], "discount": b["discount"], "step_type": b["step_type"], "fault": b["fault"],
+                "ncon": b["ncon"], "terminal_observation": self._obs_dict(b["terminal_obs"])}
+
+    # ----------------------------------------------------------------------- API
+    def seed(self, seed: int):
+        """env i <- np.random.RandomState(seed + env_index_offset + i) (dmc2gym.py:126-131; reach_sac.py:84)."""
+        nat.check(self._lib.mjs_seed(self._h, C.c_uint32(int(seed) & 0xFFFFFFFF), self._stream()), self._h)
+
+    def reset(self, seed: int | None = None, options: dict | None = None, mask: torch.Tensor | None = None):
+        if seed is not None:
+            self.seed(seed)
+        m = None
+        if mask is not None:
+            m = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+        nat.check(self._lib.mjs_reset(self._h, _as_uint8_ptr(m), C.byref(self._out), self._stream()), self._h)
+        return self._obs_dict(self._buf["obs"]), {}
+
+    def step(self, actions):
+        a = torch.as_tensor(actions, device=self.device).to(torch.float64).contiguous()
+        if a.shape != (self.num_envs, self.action_dim):
+            raise AssertionError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")  # cf. point_reach.py:158
+        nat.check(self._lib.mjs_step(self._h, C.c_void_p(a.data_ptr()), C.byref(self._out), self._stream()), self._h)
+        b = self._buf
+        return self._obs_dict(b["obs"]), b["reward"], b["terminated"].bool(), b["truncated"].bool(), self._info(b)
+
+    def step_flat(self, actions_f64: torch.Tensor):
+        """Zero-overhead variant: float64 CUDA actions in, raw output buffers out (no copies)."""
+        nat.check(self._lib.mjs_step(self._h, C.c_void_p(actions_f64.data_ptr()), C.byref(self._out), self._stream()), self._h)
+        return self._buf
+
+    def rollout(self, actions: torch.Tensor, keep: tuple = ("obs", "reward", "terminated", "truncated", "is_success", "step_type", "fault", "ncon", "discount")):
+        """Open-loop rollout of T control steps: actions [T, N, A] -> dict of [T, N, ...] tensors."""
+        a = torch.as_tensor(actions, device=self.device).to(torch.float64).contiguous()
+        T = a.shape[0]
+        assert a.shape == (T, self.num_envs, self.action_dim)
+        buf = {k: (torch.zeros((T,) + tuple(v.shape), dtype=v.dtype, device=self.device) if k in keep else None) for k, v in self._buf.items()}
+        out = self._make_outputs(buf)
+        nat.check(self._lib.mjs_rollout(self._h, C.c_void_p(a.data_ptr()), T, C.byref(out), self._stream()), self._h)
+        return {k: v for k, v in buf.items() if v is not None}
+
+    def get_state(self) -> torch.Tensor:
+        s = torch.empty(self.state_dim, self.num_envs, dtype=torch.float64, device=self.device)
+        nat.check(self._lib.mjs_get_state(self._h, C.c_void_p(s.data_ptr()), self._stream()), self._h)
+        return s
+
+    def set_state(self, state: torch.Tensor):
+        s = state.to(device=self.device, dtype=torch.float64).contiguous()
+        assert s.shape == (self.state_dim, self.num_envs)
+        nat.check(self._lib.mjs_set_state(self._h, C.c_void_p(s.data_ptr()), self._stream()), self._h)
+
+    @property
+    def flat_obs(self) -> torch.Tensor:
+        return self._buf["obs"]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            torch.cuda.synchronize(self.device)
+            self._lib.mjs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -1,0 +1,72 @@
+"""C-ABI checks that need no GPU: the library builds, loads and exports every symbol
+include/mjsim.h declares; on a GPU-less host the product fails loudly (no CPU fallback)."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+@pytest.fixture(scope="module")
+def native():
+    from mujoco_sim_amd import _native
+
+    _native.build()
+    return _native
+
+
+def test_library_exports_every_declared_symbol(native):
+    header = (ROOT / "include" / "mjsim.h").read_text()
+    declared = set(re.findall(r"\b(mjs_[a-z_]+)\s*\(", header))
+    assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
+    L = C.CDLL(str(native.LIB_PATH))
+    for name in sorted(declared):
+        assert hasattr(L, name), f"libmjsim.so does not export {name}"
+
+
+def test_static_queries(native):
+    L = native.lib()
+    assert L.mjs_version().startswith(b"mjsim-hip")
+    assert (L.mjs_obs_dim(0), L.mjs_action_dim(0), L.mjs_substeps(0)) == (4, 2, 5)
+    assert (L.mjs_obs_dim(1), L.mjs_action_dim(1), L.mjs_substeps(1)) == (12, 3, 20)
+    assert L.mjs_obs_dim(99) == -1
+    # algorithmic bytes per env-step, recomputed from the SoA layout
+    assert L.mjs_algorithmic_bytes_per_env_step(0) == 8 * 13 + 8 * 11 + 2 + 16 + 32 + 25
+    assert L.mjs_algorithmic_bytes_per_env_step(1) == 8 * 16 + 8 * 13 + 2 + 24 + 96 + 25
+
+
+def test_create_rejects_bad_arguments(native):
+    L = native.lib()
+    h = C.c_void_p()
+    cfg = native.MjsConfig(task=7, num_envs=4, device=0, reward_type=-1, autoreset=0)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -5  # MJS_ERR_UNSUPPORTED
+    cfg = native.MjsConfig(task=0, num_envs=0, device=0, reward_type=-1, autoreset=0)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1  # MJS_ERR_INVALID_ARG
+    assert L.mjs_create(None, C.byref(h)) == -1
+    assert b"num_envs" in L.mjs_last_error(None) or b"null" in L.mjs_last_error(None)
+
+
+def test_no_cpu_fallback_without_gpu(native):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import mujoco_sim_amd as m
+
+    with pytest.raises(m.MjsError):
+        m.HipVectorEnv("robot_reach", 4)
+    L = native.lib()
+    h = C.c_void_p()
+    cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=0)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -2  # MJS_ERR_NO_DEVICE
+    assert b"no CPU path" in L.mjs_last_error(None)
+
+
+def test_product_never_imports_oracle():
+    # the oracle is test infrastructure: nothing under mujoco_sim_amd/ may reference it
+    for p in (ROOT / "mujoco_sim_amd").rglob("*"):
+        if p.is_file() and p.suffix in {".py", ".h", ".hip", ".cpp"}:
+            txt = p.read_text()
+            assert "import oracle" not in txt and "from oracle" not in txt and "mjs_oracle.h" not in txt, p

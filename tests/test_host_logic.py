@@ -1,0 +1,110 @@
+"""Host-side logic that needs no GPU: spaces, task descriptions, registry, sharding and the
+world_size-2 gloo gather of rollout blocks."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def test_task_descriptions_mirror_reference_defaults():
+    from mujoco_sim_amd.environments.tasks.point_reach import (CONTROL_TIMESTEP, GOAL_DISTANCE_THRESHOLD, MAX_STEP_SIZE,
+                                                               PHYSICS_TIMESTEP, PointMassReachTask)
+    from mujoco_sim_amd.environments.tasks.robot_reach import RobotReachConfig, RobotReachTask
+
+    t = PointMassReachTask()
+    assert (t.reward_type, t.observation_type, t.image_resolution) == ("dense_biased_negative_distance_reward", "visual_observations", 64)
+    assert (PHYSICS_TIMESTEP, CONTROL_TIMESTEP, GOAL_DISTANCE_THRESHOLD, MAX_STEP_SIZE) == (0.02, 0.1, 0.02, 0.05)
+    spec = t.action_spec()
+    assert spec.shape == (2,) and spec.dtype == np.float32 and np.allclose(spec.maximum, 0.05)
+    with pytest.raises(AssertionError):
+        PointMassReachTask(reward_type="nope")
+    c = RobotReachConfig()
+    assert (c.reward_type, c.observation_type, c.action_type) == ("dense_negative_distance_reward", "state_observations", "absolute_eef_action")
+    assert (c.physics_timestep, c.control_timestep, c.max_control_steps_per_episode, c.goal_distance_threshold) == (0.005, 0.1, 100, 0.02)
+    spec = RobotReachTask(c).action_spec()
+    assert spec.dtype == np.float64 and np.allclose(spec.minimum, [-0.1, -0.6, 0.02]) and np.allclose(spec.maximum, [0.1, -0.4, 0.2])
+    with pytest.raises(NotImplementedError):
+        RobotReachTask(RobotReachConfig(action_type=RobotReachConfig.ABS_JOIN_ACTION))
+
+
+def test_spaces_and_registry():
+    import mujoco_sim_amd as m
+    from mujoco_sim_amd.environments.dmc2gym import _convert_specs_to_flattened_box, _flatten_obs, convert_spec_to_box
+    from mujoco_sim_amd.environments.tasks.point_reach import ArraySpec, BoundedArraySpec
+
+    assert "mujoco_sim/point_mass_reach-v0" in m.registry  # reference id (mujoco_sim/__init__.py:26-30)
+    box = _convert_specs_to_flattened_box([BoundedArraySpec((2,), np.float32, [-1, -2], [1, 2]), ArraySpec((2, 2), np.float64)], np.float64)
+    assert box.shape == (6,) and box.dtype == np.float32 and np.isinf(box.high[2:]).all()
+    b = convert_spec_to_box(BoundedArraySpec((3,), np.float64, -1, 1))
+    assert b.dtype == np.float64 and b.shape == (3,)
+    flat = _flatten_obs({"a": np.arange(2.0), "b": np.arange(6.0).reshape(2, 3)})
+    assert flat.shape == (8,)
+    with pytest.raises(KeyError):
+        m.make("mujoco_sim/nope-v0")
+
+
+def test_shard_range():
+    from mujoco_sim_amd.distributed import shard_range
+
+    assert [shard_range(4096, 8, r) for r in (0, 1, 7)] == [(0, 512), (512, 1024), (3584, 4096)]
+    with pytest.raises(ValueError):
+        shard_range(10, 4, 0)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    sys.path.insert(0, str(ROOT))
+    import oracle
+    from mujoco_sim_amd import distributed as D
+
+    D.init_process_group("gloo")
+    N, T = 8, 6
+    lo, hi = D.shard_range(N, world, rank)
+    # each rank steps ITS shard (oracle stands in for the GPU engine on this CPU-only test) with global seeds
+    b = oracle.OracleBatch(oracle.TASK_POINTMASS, hi - lo, 2025 + lo)
+    b.reset()
+    acts = np.random.RandomState(1).uniform(-0.05, 0.05, (T, N, 2))
+    obs = np.stack([b.step(acts[t, lo:hi])["obs"] for t in range(T)])  # [T, n_local, 4]
+    full = D.gather_rollout(torch.from_numpy(obs))
+    t = D.max_over_ranks(float(rank + 1))
+    D.barrier()
+    if rank == 0:
+        q.put((full.numpy(), t))
+    torch.distributed.destroy_process_group()
+
+
+def test_gloo_world2_gather_matches_single_process():
+    import torch.multiprocessing as mp
+
+    import oracle
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    full, tmax = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    # single-process reference: identical results for any world size (envs are independent, seeds global)
+    N, T = 8, 6
+    b = oracle.OracleBatch(oracle.TASK_POINTMASS, N, 2025)
+    b.reset()
+    acts = np.random.RandomState(1).uniform(-0.05, 0.05, (T, N, 2))
+    ref = np.stack([b.step(acts[t])["obs"] for t in range(T)])
+    assert full.shape == (T, N, 4) and np.array_equal(full, ref)
+    assert tmax == 2.0

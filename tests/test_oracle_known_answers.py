@@ -1,0 +1,218 @@
+"""Pins for the CPU oracle (no GPU needed).
+
+The physics of the reference lives in absent third-party wheels, so the oracle is pinned by
+everything that CAN be checked here:
+  * numpy's RandomState itself (the reference seeds with it, dmc2gym.py:126-131),
+  * float64 time-limit crossings of the composer loop,
+  * the reference's own test tolerances re-expressed against the oracle
+    (test/test_ur_frame_matches_real.py:29, test/test_ur_control_api.py:26-28,80-82,
+    test/test_gym_envs.py:21-36),
+  * closed-form answers (weld spring response, servo interpolation),
+  * committed golden vectors (regression).
+"""
+import numpy as np
+import pytest
+
+GOLDEN = __import__("pathlib").Path(__file__).parent / "golden"
+
+
+# ---------------------------------------------------------------- RNG: pinned against numpy
+@pytest.mark.parametrize("seed", [0, 1, 2024, 2025, 123456789, 2**32 - 1])
+def test_rng_matches_numpy_randomstate(oracle_mod, seed):
+    r = oracle_mod.OracleRng(seed)
+    rs = np.random.RandomState(seed)
+    # > 624 words so that the state regeneration (twist) is exercised twice
+    ours = [r.uniform(-0.45, 0.45) for _ in range(700)]
+    ref = [rs.uniform(-0.45, 0.45) for _ in range(700)]
+    assert ours == ref
+
+
+def test_reset_draws_known_answers(oracle_mod):
+    # SURVEY.md App. A.6 (computed there with numpy only): goal_x, goal_y, point_x, point_y
+    expect = {
+        2025: (-0.3280606526898344, 0.34906653245734015, 0.3893450758978522, -0.048988652357164375),
+        2024: (0.07921306700585812, 0.1791978729134242, -0.2806632359653446, -0.4105722926278217),
+        0: (0.04393215353459229, 0.1936704297351775, 0.09248703846447953, 0.040394864697207156),
+    }
+    for seed, (gx, gy, px, py) in expect.items():
+        b = oracle_mod.OracleBatch(oracle_mod.TASK_POINTMASS, 1, seed)
+        obs = b.reset()["obs"][0]
+        assert tuple(obs) == (px, py, gx, gy)
+    # Robot-Reach: robot xyz then target xyz over the spawn box (robot_reach.py:143-150)
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, 1, 2025)
+    obs = b.reset()["obs"][0]
+    assert tuple(obs[9:12]) == (-0.010886367190480972, -0.5223528907772035, 0.06636735835420862)
+    # TCP lands on the sampled robot position up to the DH-vs-model offset (~1 mm; reference tolerance 1e-2)
+    assert np.allclose(obs[0:3], (-0.07290236726440764, -0.4224296594539244, 0.18786901517957044), atol=1e-2)
+    assert not np.allclose(obs[0:3], (-0.07290236726440764, -0.4224296594539244, 0.18786901517957044), atol=1e-5)
+
+
+# ------------------------------------------------------ composer loop: time-limit crossings
+def test_time_limit_crossing_pointmass(oracle_mod):
+    # time += 0.02 five times per step: 4.99999... after 50 steps -> truncation at control step 51
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_POINTMASS, 1, 3, reward_type=2)
+    b.reset()
+    # keep far from the goal so that only the time limit can end the episode
+    steps = 0
+    while True:
+        r = b.step(np.zeros((1, 2)))
+        steps += 1
+        if r["step_type"][0] == 2:
+            break
+        assert steps < 60
+    assert steps == 51 and r["truncated"][0] and not r["terminated"][0] and r["discount"][0] == 1.0
+    # next step is the auto-reset: FIRST, action ignored
+    r = b.step(np.full((1, 2), 0.05))
+    assert r["step_type"][0] == 0 and not r["truncated"][0] and not r["terminated"][0]
+
+
+def test_time_limit_crossing_robot(oracle_mod):
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, 1, 3)
+    obs = b.reset()["obs"]
+    a = obs[:, 0:3].copy()
+    for k in range(1, 101):
+        r = b.step(a)
+        if k < 100:
+            assert r["step_type"][0] == 1, k
+    assert r["step_type"][0] == 2 and r["truncated"][0] and not r["terminated"][0]
+
+
+# --------------------------------------------- reference test re-expressions (UR kinematics)
+
+
+def test_sim_ur_frame_matches_real(oracle_mod):
+    # test/test_ur_frame_matches_real.py: at q=0 the model's attachment_site == analytic FK (atol 1e-2).
+    # The model chain (include/mjs_scene_spec.h) is evaluated here independently with numpy.
+    import re
+
+    spec = (GOLDEN.parents[1] / "include" / "mjs_scene_spec.h").read_text()
+
+    def arr(name, shape):
+        m = re.search(name + r"\[[^=]*=\s*\{(.*?)\};", spec, re.S)
+        vals = [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S))]
+        return np.array(vals).reshape(shape)
+
+    pos, quat = arr("MJS_UR_BODY_POS", (7, 3)), arr("MJS_UR_BODY_QUAT", (7, 4))
+    fpos, fquat = arr(r"MJS_UR_FLANGE_POS", (3,)), arr(r"MJS_UR_FLANGE_QUAT", (4,))
+
+    def q2m(q):
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    T = np.eye(4)
+    for b in range(7):
+        A = np.eye(4)
+        A[:3, :3], A[:3, 3] = q2m(quat[b]), pos[b]
+        T = T @ A  # joint angles are zero
+    A = np.eye(4)
+    A[:3, :3], A[:3, 3] = q2m(fquat), fpos
+    T = T @ A
+    FK = oracle_mod.ur5e_fk_dh(np.zeros(6))
+    assert np.allclose(T, FK, atol=1e-2), f"{T}\nvs\n{FK}"
+    # known answer of the real UR5e DH table at q = 0
+    assert np.allclose(FK[:3, 3], [-0.8172, -0.2329, 0.0628], atol=1e-12)
+
+
+def test_ik_round_trip_and_closest(oracle_mod):
+    rs = np.random.RandomState(7)
+    for _ in range(500):
+        q = rs.uniform(-3.0, 3.0, 6)
+        T = oracle_mod.ur5e_fk_dh(q)
+        sols = oracle_mod.ur5e_ik_all(T)
+        assert len(sols) >= 1
+        for s in sols:  # every returned solution reproduces the pose
+            assert np.abs(oracle_mod.ur5e_fk_dh(s) - T).max() < 1e-9
+        qc = oracle_mod.ur5e_ik_closest(T, q)
+        assert np.abs(qc - q).max() < 1e-6  # the generating configuration is its own closest solution
+    # unreachable pose -> no solution (robot.py:119-120 returns None)
+    T = np.eye(4)
+    T[:3, 3] = [2.0, 0.0, 0.5]
+    assert oracle_mod.ur5e_ik_closest(T, np.zeros(6)) is None
+
+
+def test_servoL_converges_like_reference_test(oracle_mod):
+    # test/test_ur_control_api.py:57-82 re-expressed through the task: repeated servoL to a fixed TCP
+    # target converges within the reference's atol=1e-2 (pose error incl. the ~1 mm DH/model offset
+    # and the sag from the un-compensated gripper payload).
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, 1, 11)
+    b.reset()
+    target = np.array([[0.05, -0.45, 0.1]])
+    for _ in range(40):
+        r = b.step(target)
+    assert np.allclose(r["obs"][0, 0:3], target[0], atol=1e-2)
+    assert r["ncon"][0] == 0 and not r["fault"][0] and not r["ik_failed"][0]
+
+
+def test_determinism_of_env(oracle_mod):
+    # test/test_gym_envs.py:21-36: same seed -> same reset obs (atol 1e-6); different seed differs
+    for task in (oracle_mod.TASK_POINTMASS, oracle_mod.TASK_ROBOT_REACH):
+        b = oracle_mod.OracleBatch(task, 1, 0)
+        b.seed(2025)
+        o1 = b.reset()["obs"]
+        b.seed(2025)
+        o2 = b.reset()["obs"]
+        b.seed(2024)
+        o3 = b.reset()["obs"]
+        assert np.allclose(o1, o2, atol=1e-6) and (o1 == o2).all()
+        assert not np.allclose(o1, o3, atol=1e-6)
+
+
+# ------------------------------------------------------------------ closed-form physics answers
+def test_weld_first_substep_closed_form(oracle_mod):
+    # One env, zero action for a step (body == mocap -> nothing moves), then a 0.05 step in x only:
+    # first-substep acceleration a = D*K*imp*r/(m + D), D = 1/R, R = (1-imp)/imp * invweight,
+    # invweight = (1/m + 1/m + 0)/3, refsafe time constant 2*dt (SURVEY.md App. A.2 with the
+    # body_invweight0 averaging of mj_setConst).
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_POINTMASS, 1, 5, reward_type=2)
+    o0 = b.reset()["obs"][0].copy()
+    r = b.step(np.zeros((1, 2)))
+    assert (r["obs"][0, :2] == o0[:2]).all()
+    assert r["reward"][0] == -np.hypot(o0[0] - o0[2], o0[1] - o0[3])
+    m, dt, rr = 0.1, 0.02, 0.05
+    imp, dmax, tc = 0.95, 0.95, 2 * dt
+    K, Bc = 1 / (dmax**2 * tc**2), 2 / (dmax * tc)
+    D = 1 / ((1 - imp) / imp * (2 / m / 3))
+    x, v = 0.0, 0.0
+    # dm_control legacy stepping (mj_step2 then mj_step1): the first substep after before_step still
+    # uses the constraint rows built from the OLD mocap position (residual 0 here) -> 4 driven substeps
+    for sub in range(5):
+        aref = -Bc * (-v) - K * imp * ((rr if sub > 0 else 0.0) - x)
+        a = -D * aref / (m + D)  # row J = -1: minimise m a^2/2 + D (-a - aref)^2/2
+        v += dt * a
+        x += dt * v
+    # only valid while |r| > solimp width (impedance saturated at 0.95) and away from the walls
+    if abs(o0[0]) < 0.35:
+        r = b.step(np.array([[rr, 0.0]]))
+        assert np.isclose(r["obs"][0, 0] - o0[0], x, rtol=0, atol=1e-12)
+        assert r["obs"][0, 1] == o0[1]
+
+
+def test_pointmass_wall_contacts_detected(oracle_mod):
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_POINTMASS, 4, 2025, reward_type=2, time_limit=1e9)
+    r = b.reset()
+    assert (r["ncon"] == 1).all()  # sphere resting exactly on the ground plane: detected, not active
+    for _ in range(40):
+        r = b.step(np.tile([[0.05, 0.05]], (4, 1)))
+    # pushed into the +x/+y corner: ground + two walls; the soft wall contacts balance the soft weld
+    # (same solref/solimp) half-way between the wall surface (0.45) and the clipped mocap target (0.5)
+    assert (r["ncon"] == 3).all()
+    assert np.allclose(r["obs"][:, :2], 0.475, atol=1e-5)
+
+
+# ------------------------------------------------------------------------- golden regression
+@pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", 0), ("robot_reach_n8_t110_seed2025", 1)])
+def test_oracle_matches_golden(oracle_mod, name, task):
+    g = np.load(GOLDEN / f"{name}.npz")
+    N, T = g["actions"].shape[1], g["actions"].shape[0]
+    b = oracle_mod.OracleBatch(task, N, 2025)
+    r0 = b.reset()
+    assert np.array_equal(r0["obs"], g["reset_obs"])
+    for t in range(T):
+        r = b.step(g["actions"][t])
+        np.testing.assert_allclose(r["obs"], g["obs"][t], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(r["reward"], g["reward"][t], rtol=0, atol=1e-12)
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(r[k], g[k][t]), (k, t)
+    assert (g["step_type"] == 2).any() and (g["step_type"] == 0).any()  # fixtures cover episode ends + auto-resets
