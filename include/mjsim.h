@@ -116,9 +116,13 @@ int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, v
  * leading T axis. Open-loop rollouts (random / scripted policies, point_reach.py:218-240). */
 int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_outputs* out, void* stream);
 
-/* checkpoint / resume of the physics+task state (not the RNG): float64 [state_dim, N] */
+/* checkpoint / resume of the physics+task state: float64 [state_dim, N] ... */
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream);
+/* ... and of the per-env MT19937 streams: mt_dev uint32 [624, N], pos_dev int32 [N]
+ * (what pickling env._random_state would capture in the reference, dmc2gym.py:129) */
+int mjs_get_rng_state(mjs_handle* h, uint32_t* mt_dev, int32_t* pos_dev, void* stream);
+int mjs_set_rng_state(mjs_handle* h, const uint32_t* mt_dev, const int32_t* pos_dev, void* stream);
 
 #ifdef __cplusplus
 }

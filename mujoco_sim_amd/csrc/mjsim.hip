@@ -244,4 +244,22 @@ int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
   return MJS_OK;
 }
 
+int mjs_get_rng_state(mjs_handle* h, uint32_t* mt_dev, int32_t* pos_dev, void* stream) {
+  if (!h || !mt_dev || !pos_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_get_rng_state: null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t N = (size_t)h->cfg.num_envs;
+  HIP_TRY(h, hipMemcpyAsync(mt_dev, h->rng_mt, sizeof(uint32_t) * 624 * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(h, hipMemcpyAsync(pos_dev, h->rng_pos, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MJS_OK;
+}
+
+int mjs_set_rng_state(mjs_handle* h, const uint32_t* mt_dev, const int32_t* pos_dev, void* stream) {
+  if (!h || !mt_dev || !pos_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_set_rng_state: null argument");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  const size_t N = (size_t)h->cfg.num_envs;
+  HIP_TRY(h, hipMemcpyAsync(h->rng_mt, mt_dev, sizeof(uint32_t) * 624 * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(h, hipMemcpyAsync(h->rng_pos, pos_dev, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return MJS_OK;
+}
+
 }  // extern "C"

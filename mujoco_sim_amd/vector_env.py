@@ -187,6 +187,18 @@ class HipVectorEnv:
         assert s.shape == (self.state_dim, self.num_envs)
         nat.check(self._lib.mjs_set_state(self._h, C.c_void_p(s.data_ptr()), self._stream()), self._h)
 
+    def get_rng_state(self):
+        """(mt uint32 [624, N], pos int32 [N]) — the per-env numpy-legacy MT19937 streams."""
+        mt = torch.empty(624, self.num_envs, dtype=torch.int32, device=self.device)
+        pos = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        nat.check(self._lib.mjs_get_rng_state(self._h, C.c_void_p(mt.data_ptr()), C.c_void_p(pos.data_ptr()), self._stream()), self._h)
+        return mt, pos
+
+    def set_rng_state(self, rng_state):
+        mt, pos = (t.to(device=self.device, dtype=torch.int32).contiguous() for t in rng_state)
+        assert mt.shape == (624, self.num_envs) and pos.shape == (self.num_envs,)
+        nat.check(self._lib.mjs_set_rng_state(self._h, C.c_void_p(mt.data_ptr()), C.c_void_p(pos.data_ptr()), self._stream()), self._h)
+
     @property
     def flat_obs(self) -> torch.Tensor:
         return self._buf["obs"]

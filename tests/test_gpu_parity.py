@@ -127,13 +127,12 @@ def test_full_size_properties(task):
     out2 = again.rollout(acts)
     assert all(torch.equal(out2[k], ref[k]) for k in ref)
     # checkpoint / resume
-    state = again.get_state()
-    a_next = acts[0]
-    again.step(a_next)
-    obs_a = again.flat_obs.clone()
+    state, rng = again.get_state(), again.get_rng_state()
+    obs_a = [again.step_flat(acts[t])["obs"].clone() for t in range(T)]  # crosses episode ends -> RNG draws
     again.set_state(state)
-    again.step(a_next)
-    assert torch.equal(again.flat_obs, obs_a)
+    again.set_rng_state(rng)
+    obs_b = [again.step_flat(acts[t])["obs"].clone() for t in range(T)]
+    assert all(torch.equal(a, b) for a, b in zip(obs_a, obs_b))
     assert int(ref["fault"].max()) == 0
     full.close()
     again.close()
