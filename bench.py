@@ -50,11 +50,24 @@ def make_actions(task, T, N, device, seed):
     return torch.from_numpy(a).to(device)
 
 
+def host_cores():
+    """Threads for the CPU leg: affinity, capped by the cgroup CPU quota and by the GPU box's
+    per-GPU CPU share (16; override with MJS_BENCH_CORES)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:  # noqa: BLE001
+        pass
+    return max(1, min(n, int(os.environ.get("MJS_BENCH_CORES", "16"))))
+
+
 def cpu_baseline(task, n_envs, seconds):
     import oracle
 
     tid = oracle.TASK_ROBOT_REACH if task == "robot_reach" else oracle.TASK_POINTMASS
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores)
     b.reset()
     acts = make_actions(task, 8, n_envs, "cpu", 12345).numpy()
