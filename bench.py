@@ -77,7 +77,7 @@ def cpu_baseline(task, n_envs, seconds):
         b.step(acts[steps % 8])
         steps += 1
         dt = time.perf_counter() - t0
-        if dt >= seconds or steps >= 400:
+        if dt >= seconds or steps >= 20000:
             break
     return {"value": steps * n_envs / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{n_envs} envs x {steps} control steps ({dt:.1f} s), oracle/ C restatement, OpenMP over envs"}

@@ -13,7 +13,7 @@ from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
-LIB_PATH = _PKG / "lib" / "libmjsim.so"
+LIB_PATH = Path(os.environ["MJS_LIB"]) if os.environ.get("MJS_LIB") else _PKG / "lib" / "libmjsim.so"  # MJS_LIB: diagnostic builds
 _SOURCES = [*sorted((_PKG / "csrc").glob("*")), _ROOT / "include" / "mjsim.h", _ROOT / "include" / "mjs_scene_spec.h"]
 
 TASK_POINTMASS_REACH, TASK_ROBOT_REACH = 0, 1

@@ -23,7 +23,23 @@ struct KernelParams {
   const double* actions;      // [N, A] (step) or nullptr (reset)
   const uint8_t* reset_mask;  // reset kernel only; nullptr = all
   mjs_outputs out;
+  unsigned long long* stamps;  // diagnostic builds only (-DMJS_STAMPS): [wave][8] shader-clock stamps
 };
+
+// In-kernel phase stamps for a SEPARATE diagnostic build (never in the shipped library): the real
+// kernel executes no stamp. s_memtime + lgkmcnt(0) as one asm statement (guide section 7).
+#ifdef MJS_STAMPS
+#define MJS_STAMP(p, slot)                                                                  \
+  do {                                                                                      \
+    unsigned long long t_;                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
+    __builtin_amdgcn_sched_barrier(0);                                                      \
+    if ((p).stamps && (threadIdx.x & 63) == 0) (p).stamps[(size_t)blockIdx.x * 8 + (slot)] = t_; \
+  } while (0)
+#else
+#define MJS_STAMP(p, slot) do { } while (0)
+#endif
 
 template <int OBS>
 __device__ __forceinline__ void write_outputs(const KernelParams& p, int i, const double* obs, double reward, double discount,

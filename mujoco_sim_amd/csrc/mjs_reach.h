@@ -22,6 +22,11 @@
 // payload's weight survives). Bound: per-lane FP64 dependency chains, not HBM.
 #pragma once
 #include "mjs_kernel_common.h"
+#include "mjs_ur5e_dyn_gen.h"
+
+#ifndef MJS_REACH_GENERIC_DYNAMICS
+#define MJS_REACH_GENERIC_DYNAMICS 0  // 1 = first-version world-frame CRBA/RNE (kept for A/B profiles)
+#endif
 
 namespace rr {
 
@@ -51,26 +56,33 @@ struct Chain {
 };
 
 // mj_kinematics specialised to the UR5e tree (include/mjs_scene_spec.h MJS_UR_BODY_*)
+MJS_DEV void fk_cs(const double* cs, const double* sn, Chain& c);
 MJS_DEV void fk(const double* q, Chain& c) {
+  double cs[6], sn[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) sincos(q[j], &sn[j], &cs[j]);
+  fk_cs(cs, sn, c);
+}
+MJS_DEV void fk_cs(const double* cs, const double* sn, Chain& c) {
   double s, co;
   c.R[0] = M3{v3(-1, 0, 0), v3(0, -1, 0), v3(0, 0, 1)};  // base quat (0,0,0,-1): Rz(180deg), robot.py:320
   c.p[0] = v3(0, 0, 0);
-  sincos(q[0], &s, &co);  // shoulder: hinge z
+  s = sn[0]; co = cs[0];  // shoulder: hinge z
   c.p[1] = madd(c.p[0], MJS_UR_BODY_POS[1][2], c.R[0].cz);
   c.R[1] = mul_rot_z(c.R[0], co, s);
-  sincos(q[1], &s, &co);  // upper arm: Ry(90) then hinge y
+  s = sn[1]; co = cs[1];  // upper arm: Ry(90) then hinge y
   c.p[2] = madd(c.p[1], MJS_UR_BODY_POS[2][1], c.R[1].cy);
   c.R[2] = mul_rot_y(mul_quarter_y(c.R[1]), co, s);
-  sincos(q[2], &s, &co);  // forearm: hinge y
+  s = sn[2]; co = cs[2];  // forearm: hinge y
   c.p[3] = madd(madd(c.p[2], MJS_UR_BODY_POS[3][1], c.R[2].cy), MJS_UR_BODY_POS[3][2], c.R[2].cz);
   c.R[3] = mul_rot_y(c.R[2], co, s);
-  sincos(q[3], &s, &co);  // wrist 1: Ry(90) then hinge y
+  s = sn[3]; co = cs[3];  // wrist 1: Ry(90) then hinge y
   c.p[4] = madd(c.p[3], MJS_UR_BODY_POS[4][2], c.R[3].cz);
   c.R[4] = mul_rot_y(mul_quarter_y(c.R[3]), co, s);
-  sincos(q[4], &s, &co);  // wrist 2: hinge z
+  s = sn[4]; co = cs[4];  // wrist 2: hinge z
   c.p[5] = madd(c.p[4], MJS_UR_BODY_POS[5][1], c.R[4].cy);
   c.R[5] = mul_rot_z(c.R[4], co, s);
-  sincos(q[5], &s, &co);  // wrist 3: hinge y
+  s = sn[5]; co = cs[5];  // wrist 3: hinge y
   c.p[6] = madd(c.p[5], MJS_UR_BODY_POS[6][2], c.R[5].cz);
   c.R[6] = mul_rot_y(c.R[5], co, s);
 }
@@ -109,7 +121,7 @@ MJS_DEV SI si_diag(M3 R, V3 com, double mass, double dx, double dy, double dz) {
 
 // One forward-dynamics evaluation + implicitfast solve: returns the acceleration that the
 // integrator applies, (M - dt*dF/dv)^-1 (qfrc_smooth) with no constraint rows active.
-MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, double* qacc_int) {
+MJS_DEV void dynamics_generic(const double* q, const double* v, const double* ctrl, double* qacc_int) {
   Chain c;
   fk(q, c);
   // motion subspaces about the world origin
@@ -204,6 +216,87 @@ MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, doub
   for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
 }
 
+
+// Actuators + implicitfast system solve shared by both dynamics variants.
+// A: lower triangle of M (no armature) in A[i][j], j <= i; rhs in: -bias.
+MJS_DEV void actuate_and_solve(const double* q, const double* v, const double* ctrl, double A[NJ][NJ], double* rhs) {
+  // actuators (mj_fwdActuation) and the implicitfast system matrix
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    double cj = clampd(ctrl[j], MJS_UR_ACT_CTRLRANGE[j][0], MJS_UR_ACT_CTRLRANGE[j][1]);
+    double f = MJS_UR_ACT_KP[j] * cj + 0.0 + (-MJS_UR_ACT_KP[j]) * q[j] + (-MJS_UR_ACT_KD[j]) * v[j];
+    double fc = clampd(f, -MJS_UR_ACT_FRC[j], MJS_UR_ACT_FRC[j]);
+    bool clamped = (fc <= -MJS_UR_ACT_FRC[j]) || (fc >= MJS_UR_ACT_FRC[j]);
+    rhs[j] += fc;  // qfrc_smooth = passive - bias + actuator
+    A[j][j] += MJS_UR_ARMATURE;
+    if (!clamped) A[j][j] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j];  // -dt * d(actuator)/dv
+  }
+  // LDL^T factorisation and solve, fully unrolled (L overwrites the strict lower triangle of A)
+  double Dg[NJ], Dinv[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j < i; j++) {
+      double s = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k] * Dg[k];
+      A[i][j] = s * Dinv[j];
+    }
+    double d = A[i][i];
+#pragma unroll
+    for (int k = 0; k < i; k++) d -= A[i][k] * A[i][k] * Dg[k];
+    Dg[i] = d;
+    Dinv[i] = 1.0 / d;
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int k = 0; k < i; k++) rhs[i] -= A[i][k] * rhs[k];
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) rhs[i] *= Dinv[i];
+#pragma unroll
+  for (int i = NJ - 1; i >= 0; i--) {
+#pragma unroll
+    for (int k = i + 1; k < NJ; k++) rhs[i] -= A[k][i] * rhs[k];
+  }
+}
+
+// One forward-dynamics evaluation + implicitfast solve: (M - dt*dF/dv)^-1 qfrc_smooth, no
+// constraint rows active. M(q) and the bias forces come from the generated straight-line code
+// (tools/gen_ur5e_dynamics.py: link-local CRBA + RNE with every structural zero folded).
+MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, double* qacc_int) {
+#if MJS_REACH_GENERIC_DYNAMICS
+  dynamics_generic(q, v, ctrl, qacc_int);
+#else
+  double M[21], bias[NJ], A[NJ][NJ], rhs[NJ];
+  ur5e_dynamics_gen(cs, sn, v, M, bias);
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
+    rhs[i] = -bias[i];
+  }
+  actuate_and_solve(q, v, ctrl, A, rhs);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
+#endif
+}
+
+// cos/sin of q + d from cos/sin of q by the angle-addition formulas with a short Taylor kernel
+// for the increment (|d| = dt*|qdot| is ~1e-2 at most; truncation error < 1e-18 for |d| <= 0.1).
+// The exact sincos is re-evaluated at the start of every control step, so rounding drift is
+// bounded by 20 substeps (~1e-15). Returns false when the increment is too large for the kernel.
+MJS_DEV bool rotate_small(double& c, double& s, double d) {
+  double z = d * d;
+  double sd = d * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880)))));
+  double cd = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800)))));
+  double c2 = c * cd - s * sd, s2 = s * cd + c * sd;
+  c = c2;
+  s = s2;
+  return fabs(d) <= 0.1;
+}
+
 // ------------------------------------------------------------------------- analytic IK
 // (third-party ur_analytic_ik, call site robot.py:33-37; Hawkins 2013; same decision logic as
 // oracle/om_ik.c). Pose = rotation R (row-major r[9]) + translation of the FLANGE.
@@ -254,66 +347,127 @@ MJS_DEV Aff dh(double th, double d, double a, double ca, double sa) {
   return o;
 }
 
-// returns false when no solution exists; q_out = solution closest to q_guess
-__device__ __noinline__ bool ik_closest(const Aff& T, const double* q_guess, double* q_out) {
+// squared distance of one joint after mapping it to the 2*pi-equivalent nearest the guess
+MJS_DEV double joint_dist2(double& qj, double guess) {
+  double alt = qj + (guess > qj ? 2 * PI : -2 * PI);
+  if (fabs(alt - guess) < fabs(qj - guess) && fabs(alt) <= 2 * PI) qj = alt;
+  return (qj - guess) * (qj - guess);
+}
+
+struct IkCommon {
+  Aff T, Tinv;
+  double psi, phi;
+};
+
+// DH transform with the joint's cos/sin already known
+MJS_DEV Aff dh_cs(double ct, double st, double d, double a, double ca, double sa) {
+  Aff o;
+  o.r[0] = ct; o.r[1] = -st * ca; o.r[2] = st * sa;
+  o.r[3] = st; o.r[4] = ct * ca; o.r[5] = -ct * sa;
+  o.r[6] = 0; o.r[7] = sa; o.r[8] = ca;
+  o.t[0] = a * ct; o.t[1] = a * st; o.t[2] = d;
+  return o;
+}
+
+// One of the 8 closed-form candidates (sign choices s1, s5, s3). Returns its squared joint distance
+// to the guess, accumulated in the oracle's joint order 0..5, or +inf when the candidate does not
+// exist or when a partial sum already exceeds `ub` (then it cannot be the closest one).
+// Sines/cosines that are already known are reused instead of re-evaluated (sin(acos(c)) =
+// sqrt(1-c^2), cos/sin(atan2(y,x)) = (x,y)/hypot) and theta4 = theta234 - theta2 - theta3.
+MJS_DEV double ik_candidate(const IkCommon& k, int s1, int s5, int s3, const double* g, double ub, double* qs) {
   const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
+  const Aff& T = k.T;
+  double th1 = k.psi + (s1 ? -k.phi : k.phi) + 0.5 * PI;
+  qs[0] = wrap_pi(th1);
+  double p0 = joint_dist2(qs[0], g[0]);
+  if (p0 > ub) return INFINITY;
+  double sn1, c1;
+  sincos(th1, &sn1, &c1);
+  bool ok5 = true;
+  double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
+  if (!ok5) return INFINITY;
+  double th5 = (s5 ? -1.0 : 1.0) * acos(c5);
+  qs[4] = wrap_pi(th5);
+  double p4 = joint_dist2(qs[4], g[4]);
+  if (p0 + p4 > ub) return INFINITY;
+  double sn5 = (s5 ? -1.0 : 1.0) * sqrt(fmax(0.0, 1.0 - c5 * c5)), th6, c6 = 1.0, sn6 = 0.0;
+  if (fabs(sn5) < 1e-12) th6 = 0;
+  else {
+    double X60x = k.Tinv.r[0], X60y = k.Tinv.r[3], Y60x = k.Tinv.r[1], Y60y = k.Tinv.r[4];
+    double y6 = (-X60y * sn1 + Y60y * c1) / sn5, x6 = (X60x * sn1 - Y60x * c1) / sn5;
+    th6 = atan2(y6, x6);
+    double h6 = sqrt(x6 * x6 + y6 * y6);
+    if (h6 > 0) { c6 = x6 / h6; sn6 = y6 / h6; }
+  }
+  qs[5] = wrap_pi(th6);
+  double p5 = joint_dist2(qs[5], g[5]);
+  if (p0 + p4 + p5 > ub) return INFINITY;
+  Aff T01 = dh_cs(c1, sn1, d1, 0, 0, 1), T45 = dh_cs(c5, sn5, d5, 0, 0, -1), T56 = dh_cs(c6, sn6, d6, 0, 1, 0);
+  Aff T14 = aff_mul(aff_mul(aff_inv(T01), T), aff_inv(aff_mul(T45, T56)));
+  double px = T14.t[0], py = T14.t[1];
+  double r2 = px * px + py * py;
+  bool ok3 = true;
+  double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
+  if (!ok3) return INFINITY;
+  double th3 = (s3 ? -1.0 : 1.0) * acos(c3);
+  qs[2] = wrap_pi(th3);
+  double p2 = joint_dist2(qs[2], g[2]);
+  if (p0 + p4 + p5 + p2 > ub) return INFINITY;
+  double sn3 = (s3 ? -1.0 : 1.0) * sqrt(fmax(0.0, 1.0 - c3 * c3));
+  double th2 = atan2(py, px) - atan2(a3 * sn3, a2 + a3 * c3);
+  double th4 = atan2(T14.r[3], T14.r[0]) - th2 - th3;  // rotation of frame 1->4 is Rz(th2+th3+th4)
+  qs[1] = wrap_pi(th2);
+  qs[3] = wrap_pi(th4);
+  bool finite = isfinite(qs[0]) && isfinite(qs[1]) && isfinite(qs[2]) && isfinite(qs[3]) && isfinite(qs[4]) && isfinite(qs[5]);
+  if (!finite) return INFINITY;
+  // same summation order as the exhaustive evaluation: joints 0..5
+  double dist = p0;
+  dist += joint_dist2(qs[1], g[1]);
+  dist += p2;
+  dist += joint_dist2(qs[3], g[3]);
+  dist += p4;
+  dist += p5;
+  return dist;
+}
+
+// returns false when no solution exists; q_out = solution closest to q_guess. Exhaustive over the 8
+// candidates in the oracle's order (first strict minimum wins), but the candidate on the guess's own
+// branch is evaluated first (and cached) to obtain an upper bound that prunes the others after 1-3
+// joints.
+__device__ __noinline__ bool ik_closest(const Aff& T, const double* q_guess, double* q_out) {
+  const double d4 = MJS_UR_DH_D4, d6 = MJS_UR_DH_D6;
   double p05x = T.t[0] - d6 * T.r[2], p05y = T.t[1] - d6 * T.r[5];
   double rxy = sqrt(p05x * p05x + p05y * p05y);
   if (rxy < fabs(d4)) return false;
-  double psi = atan2(p05y, p05x), phi = acos(d4 / rxy);
-  Aff Tinv = aff_inv(T);
+  IkCommon k;
+  k.T = T;
+  k.Tinv = aff_inv(T);
+  k.psi = atan2(p05y, p05x);
+  k.phi = acos(d4 / rxy);
+  // branch of the guess: nearer theta1 candidate, signs of theta5 and theta3
+  double ta = wrap_pi(k.psi + k.phi + 0.5 * PI), tb = wrap_pi(k.psi - k.phi + 0.5 * PI);
+  int s1p = joint_dist2(tb, q_guess[0]) < joint_dist2(ta, q_guess[0]) ? 1 : 0;
+  int s5p = wrap_pi(q_guess[4]) < 0 ? 1 : 0, s3p = wrap_pi(q_guess[2]) < 0 ? 1 : 0;
+  const int pref = (s1p << 2) | (s5p << 1) | s3p;
+  double qp[6], qs[6];
+  const double dpref = ik_candidate(k, s1p, s5p, s3p, q_guess, INFINITY, qp);
   double best = INFINITY;
   bool found = false;
 #pragma unroll 1
-  for (int s1 = 0; s1 < 2; s1++) {
-    double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
-    double sn1, c1;
-    sincos(th1, &sn1, &c1);
-    bool ok5 = true;
-    double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
-    if (!ok5) continue;
-#pragma unroll 1
-    for (int s5 = 0; s5 < 2; s5++) {
-      double th5 = (s5 ? -1.0 : 1.0) * acos(c5);
-      double sn5 = sin(th5), th6;
-      if (fabs(sn5) < 1e-12) th6 = 0;
-      else {
-        double X60x = Tinv.r[0], X60y = Tinv.r[3], Y60x = Tinv.r[1], Y60y = Tinv.r[4];
-        th6 = atan2((-X60y * sn1 + Y60y * c1) / sn5, (X60x * sn1 - Y60x * c1) / sn5);
-      }
-      Aff T01 = dh(th1, d1, 0, 0, 1), T45 = dh(th5, d5, 0, 0, -1), T56 = dh(th6, d6, 0, 1, 0);
-      Aff T14 = aff_mul(aff_mul(aff_inv(T01), T), aff_inv(aff_mul(T45, T56)));
-      double px = T14.t[0], py = T14.t[1];
-      double r2 = px * px + py * py;
-      bool ok3 = true;
-      double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
-      if (!ok3) continue;
-#pragma unroll 1
-      for (int s3 = 0; s3 < 2; s3++) {
-        double th3 = (s3 ? -1.0 : 1.0) * acos(c3);
-        double sn3, cs3;
-        sincos(th3, &sn3, &cs3);
-        double th2 = atan2(py, px) - atan2(a3 * sn3, a2 + a3 * cs3);
-        Aff T13 = aff_mul(dh(th2, 0, a2, 1, 0), dh(th3, 0, a3, 1, 0));
-        Aff T34 = aff_mul(aff_inv(T13), T14);
-        double th4 = atan2(T34.r[3], T34.r[0]);
-        double qs[6] = {wrap_pi(th1), wrap_pi(th2), wrap_pi(th3), wrap_pi(th4), wrap_pi(th5), wrap_pi(th6)};
-        bool finite = true;
-        double dist = 0;
+  for (int idx = 0; idx < 8; idx++) {
+    double dist;
+    if (idx == pref) {
+      dist = dpref;
 #pragma unroll
-        for (int j = 0; j < 6; j++) {
-          finite = finite && isfinite(qs[j]);
-          double alt = qs[j] + (q_guess[j] > qs[j] ? 2 * PI : -2 * PI);
-          if (fabs(alt - q_guess[j]) < fabs(qs[j] - q_guess[j]) && fabs(alt) <= 2 * PI) qs[j] = alt;
-          dist += (qs[j] - q_guess[j]) * (qs[j] - q_guess[j]);
-        }
-        if (finite && dist < best) {
-          best = dist;
-          found = true;
+      for (int j = 0; j < 6; j++) qs[j] = qp[j];
+    } else {
+      dist = ik_candidate(k, idx >> 2, (idx >> 1) & 1, idx & 1, q_guess, dpref, qs);
+    }
+    if (dist < best) {
+      best = dist;
+      found = true;
 #pragma unroll
-          for (int j = 0; j < 6; j++) q_out[j] = qs[j];
-        }
-      }
+      for (int j = 0; j < 6; j++) q_out[j] = qs[j];
     }
   }
   return found;
@@ -441,6 +595,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
     write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, count_floor_contacts(c));
     return;
   }
+  MJS_STAMP(p, 0);
   State st = load_state(p, i);
   // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
   double q0[NJ], q1[NJ], act[3];
@@ -453,26 +608,39 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) q1[j] = q0[j];
   }
+  MJS_STAMP(p, 1);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
+  const double inv_span = 1.0 / (t1 - t0);
   bool bad = false;
+  double cs[NJ], sn[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
 #pragma unroll 1
   for (int s = 0; s < MJS_RR_NSUB; s++) {
     // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
     double t = fmin(fmax(st.time, t0), t1);
     double ctrl[NJ], qacc[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) / (t1 - t0);
-    dynamics(st.q, st.v, ctrl, qacc);
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    dynamics(st.q, st.v, ctrl, cs, sn, qacc);
+    bool small = true;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       bad = bad || bad_value(qacc[j]) || bad_value(st.q[j]) || bad_value(st.v[j]);
       st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
-      st.q[j] += MJS_RR_PHYSICS_DT * st.v[j];
+      double dq = MJS_RR_PHYSICS_DT * st.v[j];
+      st.q[j] += dq;
+      small = rotate_small(cs[j], sn[j], dq) && small;
+    }
+    if (!small) {  // |dq| > 0.1 rad in one substep (runaway state): fall back to the exact functions
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
     }
     st.time += MJS_RR_PHYSICS_DT;
   }
-  // observables, reward, termination
-  fk(st.q, c);
+  MJS_STAMP(p, 2);
+  // observables, reward, termination (cos/sin carried from the last substep, <= 1e-15 from exact)
+  fk_cs(cs, sn, c);
   make_obs(st, c, obs);
   double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
   double dist = sqrt(dx * dx + dy * dy + dz * dz);
@@ -483,7 +651,9 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
   if (bad) { reward = 0; discount = 0; terminate = true; }
   if (st.time >= p.time_limit) terminate = true;
+  MJS_STAMP(p, 3);
   int ncon = count_floor_contacts(c);
+  MJS_STAMP(p, 4);
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
@@ -500,6 +670,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   store_state(p, i, st);
   p.flags[i] = newflags;
   write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+  MJS_STAMP(p, 5);
 }
 
 }  // namespace rr

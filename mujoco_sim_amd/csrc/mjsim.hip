@@ -18,6 +18,7 @@ struct mjs_handle {
   uint8_t* flags;    // [N]
   uint32_t* rng_mt;  // [624][N]
   int32_t* rng_pos;  // [N]
+  unsigned long long* stamps;  // diagnostic builds only
   std::string err;
 };
 
@@ -88,6 +89,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.actions = actions;
   p.reset_mask = mask;
   if (out) p.out = *out; else std::memset(&p.out, 0, sizeof p.out);
+  p.stamps = h->stamps;
   return p;
 }
 
@@ -145,7 +147,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);
   h->act_dim = mjs_action_dim(cfg->task);
-  h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr;
+  h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr;
   const size_t N = (size_t)cfg->num_envs;
   hipError_t e = hipSetDevice(cfg->device);
   if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(double) * h->state_dim * N);
@@ -153,6 +155,10 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->rng_mt, sizeof(uint32_t) * 624 * N);
   if (e == hipSuccess) e = hipMalloc(&h->rng_pos, sizeof(int32_t) * N);
   if (e == hipSuccess) e = hipMemset(h->state, 0, sizeof(double) * h->state_dim * N);
+#ifdef MJS_STAMPS
+  if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 8 * ((N + 63) / 64));
+  if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 8 * ((N + 63) / 64));
+#endif
   if (e != hipSuccess) {
     int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
     mjs_destroy(h);
@@ -172,6 +178,20 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
 
 void mjs_destroy(mjs_handle* h) {
   if (!h) return;
+#ifdef MJS_STAMPS
+  if (h->stamps) {  // diagnostic build: mean phase lengths (shader cycles) of the LAST step launch
+    const int W = (h->cfg.num_envs + 63) / 64;
+    unsigned long long* host = new unsigned long long[8 * W];
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpy(host, h->stamps, sizeof(unsigned long long) * 8 * W, hipMemcpyDeviceToHost);
+    double d[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < W; w++)
+      for (int k = 0; k < 5; k++) d[k] += (double)(host[8 * w + k + 1] - host[8 * w + k]) / W;
+    std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
+    delete[] host;
+    (void)hipFree(h->stamps);
+  }
+#endif
   if (h->state) (void)hipFree(h->state);
   if (h->flags) (void)hipFree(h->flags);
   if (h->rng_mt) (void)hipFree(h->rng_mt);

@@ -373,6 +373,23 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
   }
 }
 
+/* debug hook for tests: joint-space inertia (incl. armature) and qfrc_bias - qfrc_passive of the
+ * Robot-Reach model at (q, v) */
+void om_debug_reach_dynamics(const double* q, const double* v, double* M_out /*36*/, double* bias_out /*6*/) {
+  static __thread om_model m;
+  static __thread om_data d;
+  static __thread int built = 0;
+  if (!built) { build_robot(&m, 1); built = 1; }
+  om_reset_data(&m, &d);
+  memcpy(d.qpos, q, sizeof(double) * 6);
+  memcpy(d.qvel, v, sizeof(double) * 6);
+  om_step1(&m, &d);
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) M_out[6 * i + j] = d.M[i][j];
+    bias_out[i] = d.qfrc_bias[i] - d.qfrc_passive[i];
+  }
+}
+
 /* ---------------------------------------------------------------- batch */
 struct om_batch { int n; om_env* envs; };
 
