@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time box of the CPU oracle sample")
     return ap.parse_args()
 
@@ -97,7 +98,7 @@ def main():
 
     n_local = args.envs_per_gpu
     n_global = n_local * world
-    venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local)
+    venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant)
     venv.reset()
     chunk = 64  # distinct action slabs resident in HBM, cycled
     acts = make_actions(args.task, chunk, n_local, device, 12345 + rank)

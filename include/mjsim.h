@@ -34,6 +34,8 @@ enum { MJS_STEP_FIRST = 0, MJS_STEP_MID = 1, MJS_STEP_LAST = 2 };
  * action and returns the reset observation); SAME_STEP is what SB3 VecEnv expects
  * (scripts/sb3/reach_sac.py:93-96): reset immediately, expose `terminal_obs`. */
 enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_DISABLED = 2 };
+/* kernel variants (results identical up to rounding; used for A/B profiles) */
+enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1 };
 /* mjs_outputs.fault bits */
 enum { MJS_FAULT_BAD_STATE = 1, MJS_FAULT_IK_FAILED = 2, MJS_FAULT_LIMIT_COLDSTART = 4 };
 
@@ -56,7 +58,7 @@ typedef struct {
   int32_t autoreset;            /* MJS_AUTORESET_* */
   int32_t terminate_on_success; /* Robot-Reach opt-in; ignored by Pointmass */
   int32_t env_index_offset;     /* global index of local env 0 (multi-GPU shards keep global seeds) */
-  int32_t reserved;
+  int32_t kernel_variant;       /* MJS_VARIANT_*: 0 = default (tuned); others for A/B profiling */
   double time_limit;            /* composer.Environment(time_limit=...) (__init__.py:21); <=0 = task default */
 } mjs_config;
 

@@ -33,7 +33,7 @@ class MjsConfig(C.Structure):
     _fields_ = [
         ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
-        ("reserved", C.c_int32), ("time_limit", C.c_double),
+        ("kernel_variant", C.c_int32), ("time_limit", C.c_double),
     ]
 
 
@@ -55,7 +55,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # max-ilp: the kernels run one wavefront per SIMD, so schedule for ILP, not occupancy (+2% measured)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp",
            "-o", str(LIB_PATH), str(_PKG / "csrc" / "mjsim.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

@@ -23,7 +23,7 @@ struct KernelParams {
   const double* actions;      // [N, A] (step) or nullptr (reset)
   const uint8_t* reset_mask;  // reset kernel only; nullptr = all
   mjs_outputs out;
-  unsigned long long* stamps;  // diagnostic builds only (-DMJS_STAMPS): [wave][8] shader-clock stamps
+  unsigned long long* stamps;  // diagnostic builds only (-DMJS_STAMPS): [workgroup][16] shader-clock stamps
 };
 
 // In-kernel phase stamps for a SEPARATE diagnostic build (never in the shipped library): the real
@@ -35,7 +35,7 @@ struct KernelParams {
     __builtin_amdgcn_sched_barrier(0);                                                      \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");              \
     __builtin_amdgcn_sched_barrier(0);                                                      \
-    if ((p).stamps && (threadIdx.x & 63) == 0) (p).stamps[(size_t)blockIdx.x * 8 + (slot)] = t_; \
+    if ((p).stamps && threadIdx.x == 0) (p).stamps[(size_t)blockIdx.x * 16 + (slot)] = t_; \
   } while (0)
 #else
 #define MJS_STAMP(p, slot) do { } while (0)

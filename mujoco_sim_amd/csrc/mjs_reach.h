@@ -217,49 +217,116 @@ MJS_DEV void dynamics_generic(const double* q, const double* v, const double* ct
 }
 
 
-// Actuators + implicitfast system solve shared by both dynamics variants.
-// A: lower triangle of M (no armature) in A[i][j], j <= i; rhs in: -bias.
-MJS_DEV void actuate_and_solve(const double* q, const double* v, const double* ctrl, double A[NJ][NJ], double* rhs) {
-  // actuators (mj_fwdActuation) and the implicitfast system matrix
+// 1/x from the hardware estimate plus two Newton steps (error ~1 ulp): half the dependent-chain
+// length of the IEEE division sequence, and the 6 pivot reciprocals of the LDL^T are serial.
+MJS_DEV double rcp_fast(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// actuator forces (mj_fwdActuation): fixed gain + affine bias, ctrl and force clamps; returns the
+// bit mask of force-clamped actuators (their velocity derivative is dropped by implicitfast)
+MJS_DEV int actuator_forces(const double* q, const double* v, const double* ctrl, double* fact) {
+  int clamped = 0;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     double cj = clampd(ctrl[j], MJS_UR_ACT_CTRLRANGE[j][0], MJS_UR_ACT_CTRLRANGE[j][1]);
     double f = MJS_UR_ACT_KP[j] * cj + 0.0 + (-MJS_UR_ACT_KP[j]) * q[j] + (-MJS_UR_ACT_KD[j]) * v[j];
     double fc = clampd(f, -MJS_UR_ACT_FRC[j], MJS_UR_ACT_FRC[j]);
-    bool clamped = (fc <= -MJS_UR_ACT_FRC[j]) || (fc >= MJS_UR_ACT_FRC[j]);
-    rhs[j] += fc;  // qfrc_smooth = passive - bias + actuator
+    if ((fc <= -MJS_UR_ACT_FRC[j]) || (fc >= MJS_UR_ACT_FRC[j])) clamped |= 1 << j;
+    fact[j] = fc;
+  }
+  return clamped;
+}
+
+// implicitfast system matrix A = M + armature - dt * d(actuator)/dv and its factorisation
+// A = U D U^T with U unit UPPER triangular, eliminating from the wrist end (joint 5) towards the
+// base: the CRBA produces the wrist rows of M first, so the serial pivot chain overlaps the rest of
+// the CRBA instead of starting after it (MuJoCo's L^T D L has the same order for sparsity).
+// Storage: symmetric entry (i,j), i < j, lives in A[j][i]; on return U(i,j) is in A[j][i], 1/D in Dinv.
+MJS_DEV void factor_system(double A[NJ][NJ], int clamped, double* Dinv) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
     A[j][j] += MJS_UR_ARMATURE;
-    if (!clamped) A[j][j] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j];  // -dt * d(actuator)/dv
+    if (!((clamped >> j) & 1)) A[j][j] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j];
   }
-  // LDL^T factorisation and solve, fully unrolled (L overwrites the strict lower triangle of A)
-  double Dg[NJ], Dinv[NJ];
+  double Dg[NJ];
 #pragma unroll
-  for (int i = 0; i < NJ; i++) {
+  for (int j = NJ - 1; j >= 0; j--) {
+    double d = A[j][j];
 #pragma unroll
-    for (int j = 0; j < i; j++) {
-      double s = A[i][j];
+    for (int m = j + 1; m < NJ; m++) d -= A[m][j] * A[m][j] * Dg[m];
+    Dg[j] = d;
+    Dinv[j] = rcp_fast(d);
 #pragma unroll
-      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k] * Dg[k];
-      A[i][j] = s * Dinv[j];
+    for (int i = 0; i < j; i++) {
+      double s = A[j][i];
+#pragma unroll
+      for (int m = j + 1; m < NJ; m++) s -= A[m][i] * A[m][j] * Dg[m];
+      A[j][i] = s * Dinv[j];
     }
-    double d = A[i][i];
+  }
+}
+MJS_DEV void actuate_and_factor(const double* q, const double* v, const double* ctrl, double A[NJ][NJ], double* Dinv, double* fact) {
+  int clamped = actuator_forces(q, v, ctrl, fact);
+  factor_system(A, clamped, Dinv);
+}
+// explicit inverse of the unit upper-triangular factor: V = U^-1 (V(i,j), i < j, stored in W[j][i]),
+// so that x = V^T (Dinv .* (V b)) is two shallow mat-vecs (dependency depth ~5 each) instead of the
+// ~25 serial steps of forward/backward substitution. Used where the solve is on the critical path.
+MJS_DEV void invert_unit_upper(const double A[NJ][NJ], double W[NJ][NJ]) {
 #pragma unroll
-    for (int k = 0; k < i; k++) d -= A[i][k] * A[i][k] * Dg[k];
-    Dg[i] = d;
-    Dinv[i] = 1.0 / d;
+  for (int j = NJ - 1; j >= 1; j--) {
+#pragma unroll
+    for (int i = j - 1; i >= 0; i--) {
+      double s = A[j][i];  // U(i,j)
+#pragma unroll
+      for (int k = i + 1; k < j; k++) s += A[k][i] * W[j][k];  // U(i,k) * V(k,j)
+      W[j][i] = -s;
+    }
+  }
+}
+MJS_DEV void apply_inverse(const double W[NJ][NJ], const double* Dinv, const double* b, double* x) {
+  double z[NJ];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+    double y = b[i];
+#pragma unroll
+    for (int j = i + 1; j < NJ; j++) y += W[j][i] * b[j];  // (V b)_i
+    z[i] = y * Dinv[i];
   }
 #pragma unroll
   for (int i = 0; i < NJ; i++) {
+    double v = z[i];
 #pragma unroll
-    for (int k = 0; k < i; k++) rhs[i] -= A[i][k] * rhs[k];
+    for (int k = 0; k < i; k++) v += W[i][k] * z[k];  // (V^T z)_i
+    x[i] = v;
+  }
+}
+
+// solve U D U^T x = rhs in place
+MJS_DEV void udu_solve(const double A[NJ][NJ], const double* Dinv, double* rhs) {
+#pragma unroll
+  for (int i = NJ - 1; i >= 0; i--) {
+#pragma unroll
+    for (int m = i + 1; m < NJ; m++) rhs[i] -= A[m][i] * rhs[m];
   }
 #pragma unroll
   for (int i = 0; i < NJ; i++) rhs[i] *= Dinv[i];
 #pragma unroll
-  for (int i = NJ - 1; i >= 0; i--) {
+  for (int i = 0; i < NJ; i++) {
 #pragma unroll
-    for (int k = i + 1; k < NJ; k++) rhs[i] -= A[k][i] * rhs[k];
+    for (int m = 0; m < i; m++) rhs[i] -= A[i][m] * rhs[m];
   }
+}
+MJS_DEV void actuate_and_solve(const double* q, const double* v, const double* ctrl, double A[NJ][NJ], double* rhs) {
+  double Dinv[NJ], fact[NJ];
+  actuate_and_factor(q, v, ctrl, A, Dinv, fact);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) rhs[j] += fact[j];  // qfrc_smooth = passive - bias + actuator
+  udu_solve(A, Dinv, rhs);
 }
 
 // One forward-dynamics evaluation + implicitfast solve: (M - dt*dF/dv)^-1 qfrc_smooth, no
@@ -286,15 +353,14 @@ MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, cons
 // cos/sin of q + d from cos/sin of q by the angle-addition formulas with a short Taylor kernel
 // for the increment (|d| = dt*|qdot| is ~1e-2 at most; truncation error < 1e-18 for |d| <= 0.1).
 // The exact sincos is re-evaluated at the start of every control step, so rounding drift is
-// bounded by 20 substeps (~1e-15). Returns false when the increment is too large for the kernel.
-MJS_DEV bool rotate_small(double& c, double& s, double d) {
+// bounded by 20 substeps (~1e-15). The caller falls back to sincos when sum(d^2) > 0.01.
+MJS_DEV void rotate_small(double& c, double& s, double d) {
   double z = d * d;
   double sd = d * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880)))));
   double cd = 1.0 + z * (-0.5 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800)))));
   double c2 = c * cd - s * sd, s2 = s * cd + c * sd;
   c = c2;
   s = s2;
-  return fabs(d) <= 0.1;
 }
 
 // ------------------------------------------------------------------------- analytic IK
@@ -577,14 +643,27 @@ MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
   for (int k = 0; k < 3; k++) obs[9 + k] = st.target[k];
 }
 
-template <bool IS_RESET>
-__global__ __launch_bounds__(64) void kernel(KernelParams p) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;
+// ROLES == 1: one wavefront steps 64 envs. ROLES == 2 (default for stepping): two wavefronts of
+// one workgroup, placed on different SIMDs of the CU, step the same 64 envs: role 0 builds M(q),
+// factorises the implicitfast matrix (U D U^T) and inverts U while role 1 evaluates the servo
+// set-point, actuator forces and bias forces; they exchange 6 doubles per lane through LDS twice
+// per substep (qfrc_smooth ->, <- qacc) and integrate redundantly. Measured alternatives (same
+// session A/B, profiles/r01_c_ab_roles.txt): one barrier per substep with both roles applying the
+// inverse (+2.0 us), contact detection on role 1 (+1.1 us), single wavefront (+5.0 us). Only role 0 touches HBM outputs and the RNG. The per-SIMD FP64 issue
+// rate is what bounds this kernel, so splitting the substep across SIMDs is the lever at
+// N = 4096 (64 env groups on a 1024-SIMD chip).
+template <bool IS_RESET, int ROLES>
+__global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
+  const int lane = threadIdx.x & 63;
+  const int role = (ROLES == 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  const int i = blockIdx.x * 64 + lane;
+  __shared__ double xch[1][ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
   double obs[OBS_DIM];
   Chain c;
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
     State st;
     episode_init(p, i, st);
@@ -597,7 +676,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   }
   MJS_STAMP(p, 0);
   State st = load_state(p, i);
-  // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
+  // before_step: servoL (robot_reach.py:169 -> robot.py:218-259); evaluated by both roles (same result)
   double q0[NJ], q1[NJ], act[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
@@ -617,27 +696,85 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
 #pragma unroll 1
   for (int s = 0; s < MJS_RR_NSUB; s++) {
-    // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
-    double t = fmin(fmax(st.time, t0), t1);
-    double ctrl[NJ], qacc[NJ];
+    double qacc[NJ];
+    if (ROLES == 1) {
+      // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
+      double t = fmin(fmax(st.time, t0), t1);
+      double ctrl[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    dynamics(st.q, st.v, ctrl, cs, sn, qacc);
-    bool small = true;
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+      dynamics(st.q, st.v, ctrl, cs, sn, qacc);
+    } else if (role == 1) {
+      // role 1: servo set-point, actuator forces and bias forces -> qfrc_smooth
+      double t = fmin(fmax(st.time, t0), t1);
+      double ctrl[NJ], bias[NJ], fact[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+      actuator_forces(st.q, st.v, ctrl, fact);
+      ur5e_bias_gen(cs, sn, st.v, bias);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) xch[0][j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+      __syncthreads();  // qfrc_smooth published
+      __syncthreads();  // qacc published
+#pragma unroll
+      for (int j = 0; j < NJ; j++) qacc[j] = xch[0][6 + j][lane];
+    } else {
+      // role 0: joint-space inertia, implicitfast matrix, U D U^T and U^-1, all before the barrier
+      // (overlapping role 1); the clamp mask is recomputed here (cheap)
+      if (s == 10) MJS_STAMP(p, 8);
+      double t = fmin(fmax(st.time, t0), t1);
+      double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+      int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
+      ur5e_M_gen(cs, sn, M);
+#pragma unroll
+      for (int r = 0; r < NJ; r++) {
+#pragma unroll
+        for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+      }
+      factor_system(A, clamped, Dinv);
+      invert_unit_upper(A, W);
+      // opaque register uses pin the whole factorisation before the barrier
+#pragma unroll
+      for (int r = 0; r < NJ; r++) {
+        asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+        for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+      }
+      if (s == 10) MJS_STAMP(p, 9);
+      __syncthreads();  // qfrc_smooth published
+      if (s == 10) MJS_STAMP(p, 10);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) rhs[j] = xch[0][j][lane];
+      apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) xch[0][6 + j][lane] = qacc[j];
+      __syncthreads();  // qacc published
+      if (s == 10) MJS_STAMP(p, 11);
+    }
+    // mj_checkAcc: NaN / inf / |qacc| > 1e10 all make the sum of squares fail this one test
+    double acc2 = 0, dq2 = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      bad = bad || bad_value(qacc[j]) || bad_value(st.q[j]) || bad_value(st.v[j]);
+      acc2 = fma(qacc[j], qacc[j], acc2);
       st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
       double dq = MJS_RR_PHYSICS_DT * st.v[j];
       st.q[j] += dq;
-      small = rotate_small(cs[j], sn[j], dq) && small;
+      dq2 = fma(dq, dq, dq2);
+      rotate_small(cs[j], sn[j], dq);
     }
-    if (!small) {  // |dq| > 0.1 rad in one substep (runaway state): fall back to the exact functions
+    bad = bad || !(acc2 <= 1e20);
+    if (!(dq2 <= 0.01)) {  // some |dq| may exceed 0.1 rad (runaway state): fall back to the exact functions
 #pragma unroll
       for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
     }
     st.time += MJS_RR_PHYSICS_DT;
+    if (ROLES == 2 && role == 0 && s == 10) MJS_STAMP(p, 12);
   }
+  if (role != 0) return;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);  // mj_checkPos / mj_checkVel
   MJS_STAMP(p, 2);
   // observables, reward, termination (cos/sin carried from the last substep, <= 1e-15 from exact)
   fk_cs(cs, sn, c);

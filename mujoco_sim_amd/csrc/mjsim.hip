@@ -99,7 +99,8 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else rr::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);  // two role-specialised waves per 64 envs
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }
@@ -156,8 +157,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess) e = hipMalloc(&h->rng_pos, sizeof(int32_t) * N);
   if (e == hipSuccess) e = hipMemset(h->state, 0, sizeof(double) * h->state_dim * N);
 #ifdef MJS_STAMPS
-  if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 8 * ((N + 63) / 64));
-  if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 8 * ((N + 63) / 64));
+  if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
+  if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
 #endif
   if (e != hipSuccess) {
     int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
@@ -181,13 +182,16 @@ void mjs_destroy(mjs_handle* h) {
 #ifdef MJS_STAMPS
   if (h->stamps) {  // diagnostic build: mean phase lengths (shader cycles) of the LAST step launch
     const int W = (h->cfg.num_envs + 63) / 64;
-    unsigned long long* host = new unsigned long long[8 * W];
+    unsigned long long* host = new unsigned long long[16 * W];
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host, h->stamps, sizeof(unsigned long long) * 8 * W, hipMemcpyDeviceToHost);
-    double d[5] = {0, 0, 0, 0, 0};
-    for (int w = 0; w < W; w++)
-      for (int k = 0; k < 5; k++) d[k] += (double)(host[8 * w + k + 1] - host[8 * w + k]) / W;
+    (void)hipMemcpy(host, h->stamps, sizeof(unsigned long long) * 16 * W, hipMemcpyDeviceToHost);
+    double d[5] = {0, 0, 0, 0, 0}, e[5] = {0, 0, 0, 0, 0};
+    for (int w = 0; w < W; w++) {
+      for (int k = 0; k < 5; k++) d[k] += (double)(host[16 * w + k + 1] - host[16 * w + k]) / W;
+      for (int k = 0; k < 5; k++) e[k] += (double)(host[16 * w + 8 + k + 1] - host[16 * w + 8 + k]) / W;
+    }
     std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
+    std::fprintf(stderr, "[MJS_STAMPS] role-0 substep 10: CRBA+factor+invert %.0f | barrier %.0f | apply inverse+publish+barrier %.0f | integrate %.0f\n", e[0], e[1], e[2], e[3]);
     delete[] host;
     (void)hipFree(h->stamps);
   }

@@ -76,7 +76,7 @@ class HipVectorEnv:
 
     def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
-                 terminate_on_success: bool = False, env_index_offset: int = 0):
+                 terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -93,7 +93,7 @@ class HipVectorEnv:
         self._lib = nat.lib()
         cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self.device.index or 0,
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
-                            terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, reserved=0,
+                            terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
                             time_limit=float(time_limit) if time_limit is not None else -1.0)
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))

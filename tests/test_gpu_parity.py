@@ -177,3 +177,24 @@ def test_single_env_adapter_matches_reference_semantics(oracle_mod):
     with pytest.raises(NotImplementedError):
         m.make("mujoco_sim/point_mass_reach-v0")  # registered VISUAL variant: render kernel not built yet
     env.close()
+
+
+def test_kernel_variants_agree():
+    """The role-specialised two-wavefront Robot-Reach kernel (default) and the single-wavefront
+    variant run the same arithmetic; the compiler contracts FMAs differently in the two code
+    shapes, so they agree to rounding (1e-10 over 130 steps), flags exactly."""
+    import mujoco_sim_amd as m
+
+    N, T = 1024, 130
+    acts = torch.from_numpy(_actions("robot_reach", T, N)).cuda()
+    outs = []
+    for variant in (0, 1):
+        venv = m.HipVectorEnv("robot_reach", N, seed=99, kernel_variant=variant)
+        venv.reset()
+        outs.append(venv.rollout(acts))
+        venv.close()
+    for k in outs[0]:
+        if outs[0][k].dtype == torch.float64:
+            assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-10), k
+        else:
+            assert torch.equal(outs[0][k], outs[1][k]), k

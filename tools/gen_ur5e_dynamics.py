@@ -339,9 +339,8 @@ def build():
     return tau, M
 
 
-def emit(tau, M):
-    outputs = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
-    outputs += [(f"M[{i * (i + 1) // 2 + j}]", M[i][j]) for i in range(NJ) for j in range(i + 1)]
+def emit(outputs):
+    """straight-line code for the given (name, value) outputs; returns (lines, op counts)"""
     needed, stack = set(), [v.id for _, v in outputs if not v.is_const]
     while stack:
         k = stack.pop()
@@ -383,26 +382,44 @@ def emit(tau, M):
 
 def main():
     tau, M = build()
-    lines, counts = emit(tau, M)
-    total = sum(counts.values())
+    out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
+    out_M = [(f"M[{i * (i + 1) // 2 + j}]", M[i][j]) for i in range(NJ) for j in range(i + 1)]
+    lb, cb = emit(out_bias)
+    lm, cm = emit(out_M)
+    nb, nm = sum(cb.values()), sum(cm.values())
     header = f"""// mjs_ur5e_dyn_gen.h — GENERATED by tools/gen_ur5e_dynamics.py from include/mjs_scene_spec.h.
 // DO NOT EDIT. Straight-line float64 code for the UR5e (+ lumped gripper payload, D-1):
-//   M[21]   lower triangle (row-major, M[i*(i+1)/2+j], j<=i) of the joint-space inertia matrix
-//           WITHOUT joint armature (role of mj_crb; reference path: Physics.step, SURVEY App. B)
-//   bias[6] Coriolis/centrifugal forces of the whole arm minus the joint torque of the payload's
-//           weight, i.e. qfrc_bias - qfrc_gravcomp of MuJoCo (gravcomp=1 on the arm bodies only,
-//           entities/robots/robot.py:80-82), so that qfrc_smooth = -bias + actuator force
-// inputs: c[j] = cos(q_j), s[j] = sin(q_j), qd[j] = joint velocity.
-// operation count: {total} ({counts['mul'] + counts['mulc']} mul, {counts['add'] + counts['sub'] + counts['addc']} add/sub) before FMA fusion.
+//   ur5e_M_gen:    M[21], lower triangle (row-major, M[i*(i+1)/2+j], j<=i) of the joint-space inertia
+//                  matrix WITHOUT joint armature (role of mj_crb; reference path: Physics.step,
+//                  SURVEY App. B).                                  {nm} ops before FMA fusion
+//   ur5e_bias_gen: bias[6], Coriolis/centrifugal forces of the whole arm minus the joint torque of
+//                  the payload's weight, i.e. qfrc_bias - qfrc_gravcomp of MuJoCo (gravcomp=1 on the
+//                  arm bodies only, entities/robots/robot.py:80-82), so that
+//                  qfrc_smooth = -bias + actuator force.             {nb} ops before FMA fusion
+// inputs: c[j] = cos(q_j), s[j] = sin(q_j), qd[j] = joint velocity. The two functions share no
+// sub-expression, which is what lets the kernel run them on two different wavefronts.
 #pragma once
 #ifndef MJS_DEV
 #define MJS_DEV __device__ __forceinline__
 #endif
 
-MJS_DEV void ur5e_dynamics_gen(const double* c, const double* s, const double* qd, double* M, double* bias) {{
+MJS_DEV void ur5e_M_gen(const double* c, const double* s, double* M) {{
 """
-    OUT.write_text(header + "\n".join(lines) + "\n}\n")
-    print(f"wrote {OUT} : {total} ops {counts}")
+    mid = """
+}
+
+MJS_DEV void ur5e_bias_gen(const double* c, const double* s, const double* qd, double* bias) {
+"""
+    tail = """
+}
+
+MJS_DEV void ur5e_dynamics_gen(const double* c, const double* s, const double* qd, double* M, double* bias) {
+  ur5e_M_gen(c, s, M);
+  ur5e_bias_gen(c, s, qd, bias);
+}
+"""
+    OUT.write_text(header + "\n".join(lm) + mid + "\n".join(lb) + tail)
+    print(f"wrote {OUT} : M {nm} ops {cm} | bias {nb} ops {cb}")
 
 
 if __name__ == "__main__":
