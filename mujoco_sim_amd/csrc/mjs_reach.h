@@ -420,11 +420,6 @@ MJS_DEV double joint_dist2(double& qj, double guess) {
   return (qj - guess) * (qj - guess);
 }
 
-struct IkCommon {
-  Aff T, Tinv;
-  double psi, phi;
-};
-
 // DH transform with the joint's cos/sin already known
 MJS_DEV Aff dh_cs(double ct, double st, double d, double a, double ca, double sa) {
   Aff o;
@@ -435,108 +430,96 @@ MJS_DEV Aff dh_cs(double ct, double st, double d, double a, double ca, double sa
   return o;
 }
 
-// One of the 8 closed-form candidates (sign choices s1, s5, s3). Returns its squared joint distance
-// to the guess, accumulated in the oracle's joint order 0..5, or +inf when the candidate does not
-// exist or when a partial sum already exceeds `ub` (then it cannot be the closest one).
-// Sines/cosines that are already known are reused instead of re-evaluated (sin(acos(c)) =
-// sqrt(1-c^2), cos/sin(atan2(y,x)) = (x,y)/hypot) and theta4 = theta234 - theta2 - theta3.
-MJS_DEV double ik_candidate(const IkCommon& k, int s1, int s5, int s3, const double* g, double ub, double* qs) {
+// Closest of the (up to) 8 closed-form solutions to q_guess; false when none exists.
+// Same winner as the oracle's exhaustive loop (oracle/om_ik.c: first strict minimum in index order
+// idx = s1*4 + s5*2 + s3): exact ties are broken by the smaller idx, so the visiting order is free.
+// The branch the guess itself lies on is visited first; every other candidate is abandoned as soon
+// as the squared distance of the joints computed so far exceeds the best complete candidate.
+// Intermediates are shared per theta1 and per (theta1, theta5) exactly as in the nested loops of
+// the oracle; known sines/cosines are reused (sin(acos c) = sqrt(1-c^2), cos/sin(atan2(y,x)) =
+// (x,y)/hypot, atan2(-y,x) = -atan2(y,x)) and theta4 = theta234 - theta2 - theta3.
+MJS_DEV bool ik_closest(const Aff& T, const double* g, double* q_out) {
   const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
-  const Aff& T = k.T;
-  double th1 = k.psi + (s1 ? -k.phi : k.phi) + 0.5 * PI;
-  qs[0] = wrap_pi(th1);
-  double p0 = joint_dist2(qs[0], g[0]);
-  if (p0 > ub) return INFINITY;
-  double sn1, c1;
-  sincos(th1, &sn1, &c1);
-  bool ok5 = true;
-  double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
-  if (!ok5) return INFINITY;
-  double th5 = (s5 ? -1.0 : 1.0) * acos(c5);
-  qs[4] = wrap_pi(th5);
-  double p4 = joint_dist2(qs[4], g[4]);
-  if (p0 + p4 > ub) return INFINITY;
-  double sn5 = (s5 ? -1.0 : 1.0) * sqrt(fmax(0.0, 1.0 - c5 * c5)), th6, c6 = 1.0, sn6 = 0.0;
-  if (fabs(sn5) < 1e-12) th6 = 0;
-  else {
-    double X60x = k.Tinv.r[0], X60y = k.Tinv.r[3], Y60x = k.Tinv.r[1], Y60y = k.Tinv.r[4];
-    double y6 = (-X60y * sn1 + Y60y * c1) / sn5, x6 = (X60x * sn1 - Y60x * c1) / sn5;
-    th6 = atan2(y6, x6);
-    double h6 = sqrt(x6 * x6 + y6 * y6);
-    if (h6 > 0) { c6 = x6 / h6; sn6 = y6 / h6; }
-  }
-  qs[5] = wrap_pi(th6);
-  double p5 = joint_dist2(qs[5], g[5]);
-  if (p0 + p4 + p5 > ub) return INFINITY;
-  Aff T01 = dh_cs(c1, sn1, d1, 0, 0, 1), T45 = dh_cs(c5, sn5, d5, 0, 0, -1), T56 = dh_cs(c6, sn6, d6, 0, 1, 0);
-  Aff T14 = aff_mul(aff_mul(aff_inv(T01), T), aff_inv(aff_mul(T45, T56)));
-  double px = T14.t[0], py = T14.t[1];
-  double r2 = px * px + py * py;
-  bool ok3 = true;
-  double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
-  if (!ok3) return INFINITY;
-  double th3 = (s3 ? -1.0 : 1.0) * acos(c3);
-  qs[2] = wrap_pi(th3);
-  double p2 = joint_dist2(qs[2], g[2]);
-  if (p0 + p4 + p5 + p2 > ub) return INFINITY;
-  double sn3 = (s3 ? -1.0 : 1.0) * sqrt(fmax(0.0, 1.0 - c3 * c3));
-  double th2 = atan2(py, px) - atan2(a3 * sn3, a2 + a3 * c3);
-  double th4 = atan2(T14.r[3], T14.r[0]) - th2 - th3;  // rotation of frame 1->4 is Rz(th2+th3+th4)
-  qs[1] = wrap_pi(th2);
-  qs[3] = wrap_pi(th4);
-  bool finite = isfinite(qs[0]) && isfinite(qs[1]) && isfinite(qs[2]) && isfinite(qs[3]) && isfinite(qs[4]) && isfinite(qs[5]);
-  if (!finite) return INFINITY;
-  // same summation order as the exhaustive evaluation: joints 0..5
-  double dist = p0;
-  dist += joint_dist2(qs[1], g[1]);
-  dist += p2;
-  dist += joint_dist2(qs[3], g[3]);
-  dist += p4;
-  dist += p5;
-  return dist;
-}
-
-// returns false when no solution exists; q_out = solution closest to q_guess. Exhaustive over the 8
-// candidates in the oracle's order (first strict minimum wins), but the candidate on the guess's own
-// branch is evaluated first (and cached) to obtain an upper bound that prunes the others after 1-3
-// joints.
-__device__ __noinline__ bool ik_closest(const Aff& T, const double* q_guess, double* q_out) {
-  const double d4 = MJS_UR_DH_D4, d6 = MJS_UR_DH_D6;
   double p05x = T.t[0] - d6 * T.r[2], p05y = T.t[1] - d6 * T.r[5];
   double rxy = sqrt(p05x * p05x + p05y * p05y);
   if (rxy < fabs(d4)) return false;
-  IkCommon k;
-  k.T = T;
-  k.Tinv = aff_inv(T);
-  k.psi = atan2(p05y, p05x);
-  k.phi = acos(d4 / rxy);
-  // branch of the guess: nearer theta1 candidate, signs of theta5 and theta3
-  double ta = wrap_pi(k.psi + k.phi + 0.5 * PI), tb = wrap_pi(k.psi - k.phi + 0.5 * PI);
-  int s1p = joint_dist2(tb, q_guess[0]) < joint_dist2(ta, q_guess[0]) ? 1 : 0;
-  int s5p = wrap_pi(q_guess[4]) < 0 ? 1 : 0, s3p = wrap_pi(q_guess[2]) < 0 ? 1 : 0;
-  const int pref = (s1p << 2) | (s5p << 1) | s3p;
-  double qp[6], qs[6];
-  const double dpref = ik_candidate(k, s1p, s5p, s3p, q_guess, INFINITY, qp);
+  const double psi = atan2(p05y, p05x), phi = acos(d4 / rxy);
+  // R60 = R06^T: X60 = (r0, r1), Y60 = (r3, r4) read column-wise from T
+  const double X60x = T.r[0], X60y = T.r[1], Y60x = T.r[3], Y60y = T.r[4];
+  // branch of the guess
+  double ta = wrap_pi(psi + phi + 0.5 * PI), tb = wrap_pi(psi - phi + 0.5 * PI);
+  const int s1p = joint_dist2(tb, g[0]) < joint_dist2(ta, g[0]) ? 1 : 0;
+  const int s5p = wrap_pi(g[4]) < 0 ? 1 : 0, s3p = wrap_pi(g[2]) < 0 ? 1 : 0;
   double best = INFINITY;
-  bool found = false;
+  int best_idx = 8;
 #pragma unroll 1
-  for (int idx = 0; idx < 8; idx++) {
-    double dist;
-    if (idx == pref) {
-      dist = dpref;
-#pragma unroll
-      for (int j = 0; j < 6; j++) qs[j] = qp[j];
-    } else {
-      dist = ik_candidate(k, idx >> 2, (idx >> 1) & 1, idx & 1, q_guess, dpref, qs);
-    }
-    if (dist < best) {
-      best = dist;
-      found = true;
-#pragma unroll
-      for (int j = 0; j < 6; j++) q_out[j] = qs[j];
+  for (int a = 0; a < 2; a++) {
+    const int s1 = s1p ^ a;
+    double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
+    double q0 = wrap_pi(th1);
+    const double p0 = joint_dist2(q0, g[0]);
+    if (p0 > best) continue;
+    double sn1, c1;
+    sincos(th1, &sn1, &c1);
+    bool ok5 = true;
+    const double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
+    if (!ok5) continue;
+    const double ac5 = acos(c5), root5 = sqrt(fmax(0.0, 1.0 - c5 * c5));
+    const Aff T01i_T = aff_mul(aff_inv(dh_cs(c1, sn1, d1, 0, 0, 1)), T);
+#pragma unroll 1
+    for (int b = 0; b < 2; b++) {
+      const int s5 = s5p ^ b;
+      const double sg5 = s5 ? -1.0 : 1.0;
+      double q4 = wrap_pi(sg5 * ac5);
+      const double p4 = joint_dist2(q4, g[4]);
+      if (p0 + p4 > best) continue;
+      const double sn5 = sg5 * root5;
+      double th6 = 0, c6 = 1.0, sn6 = 0.0;
+      if (!(fabs(sn5) < 1e-12)) {
+        double y6 = (-X60y * sn1 + Y60y * c1) / sn5, x6 = (X60x * sn1 - Y60x * c1) / sn5;
+        th6 = atan2(y6, x6);
+        double h6 = sqrt(x6 * x6 + y6 * y6);
+        if (h6 > 0) { c6 = x6 / h6; sn6 = y6 / h6; }
+      }
+      double q5 = wrap_pi(th6);
+      const double p5 = joint_dist2(q5, g[5]);
+      if (p0 + p4 + p5 > best) continue;
+      const Aff T14 = aff_mul(T01i_T, aff_inv(aff_mul(dh_cs(c5, sn5, d5, 0, 0, -1), dh_cs(c6, sn6, d6, 0, 1, 0))));
+      const double px = T14.t[0], py = T14.t[1], r2 = px * px + py * py;
+      bool ok3 = true;
+      const double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
+      if (!ok3) continue;
+      const double ac3 = acos(c3), root3 = sqrt(fmax(0.0, 1.0 - c3 * c3));
+      const double base2 = atan2(py, px), at3 = atan2(a3 * root3, a2 + a3 * c3), th234 = atan2(T14.r[3], T14.r[0]);
+#pragma unroll 1
+      for (int c = 0; c < 2; c++) {
+        const int s3 = s3p ^ c;
+        const double sg3 = s3 ? -1.0 : 1.0;
+        const double th3 = sg3 * ac3;
+        double q2 = wrap_pi(th3);
+        const double p2 = joint_dist2(q2, g[2]);
+        if (p0 + p4 + p5 + p2 > best) continue;
+        const double th2 = base2 - sg3 * at3;
+        const double th4 = th234 - th2 - th3;  // rotation of frame 1->4 is Rz(th2+th3+th4)
+        double q1 = wrap_pi(th2), q3 = wrap_pi(th4);
+        if (!(isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3) && isfinite(q4) && isfinite(q5))) continue;
+        // same summation order as the exhaustive evaluation: joints 0..5
+        double dist = p0;
+        dist += joint_dist2(q1, g[1]);
+        dist += p2;
+        dist += joint_dist2(q3, g[3]);
+        dist += p4;
+        dist += p5;
+        const int idx = (s1 << 2) | (s5 << 1) | s3;
+        if (dist < best || (dist == best && idx < best_idx)) {
+          best = dist;
+          best_idx = idx;
+          q_out[0] = q0; q_out[1] = q1; q_out[2] = q2; q_out[3] = q3; q_out[4] = q4; q_out[5] = q5;
+        }
+      }
     }
   }
-  return found;
+  return best_idx < 8;
 }
 
 // TCP pose (position + scalar-LAST quaternion, type_aliases.py:6-10) -> joints (robot.py:113-121,138-151)
@@ -557,7 +540,7 @@ MJS_DEV bool tcp_pose_to_joints(const double* pos, const double* q_guess, double
 // ----------------------------------------------------------------- contact detection
 // floor plane z = 0 vs the arm's collision proxies (MJS_UR_COL_*): number of contacts MuJoCo
 // would list (capsule: one per end sphere; cylinder: mjc_PlaneCylinder up to 4)
-__device__ __noinline__ int count_floor_contacts(const Chain& c) {
+MJS_DEV int count_floor_contacts(const Chain& c) {
   int n = 0;
 #pragma unroll
   for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
@@ -620,7 +603,10 @@ MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
 
 // initialize_episode (robot_reach.py:143-150): robot xyz -> IK from qpos0 = 0 -> set joints;
 // then target xyz. Returns the per-episode ik_failed flag (always clear after a reset).
-MJS_DEV void episode_init(const KernelParams& p, int i, State& st) {
+// (noinline + by-value result: the rare reset path keeps its own IK copy out of the hot code and the
+// long-lived state of the step path never has its address taken)
+__device__ __noinline__ State episode_init(const KernelParams& p, int i) {
+  State st;
   RngCursor c = rng_open(p.rng, i);
   double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -632,6 +618,7 @@ MJS_DEV void episode_init(const KernelParams& p, int i, State& st) {
   for (int k = 0; k < 3; k++) st.target[k] = rng_uniform(p.rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
   rng_close(p.rng, i, c);
   st.time = 0;
+  return st;
 }
 
 MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
@@ -665,8 +652,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
     if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    State st;
-    episode_init(p, i, st);
+    State st = episode_init(p, i);
     store_state(p, i, st);
     p.flags[i] = 0;
     fk(st.q, c);
@@ -794,19 +780,27 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+  // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
+  // has to stay live across that call
+  store_state(p, i, st);
+  p.flags[i] = newflags;
+  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
   if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
     if (p.out.terminal_obs) {
 #pragma unroll
       for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
     }
-    episode_init(p, i, st);
-    newflags = 0;
-    fk(st.q, c);
-    make_obs(st, c, obs);
+    State fresh = episode_init(p, i);
+    store_state(p, i, fresh);
+    p.flags[i] = 0;
+    fk(fresh.q, c);
+    make_obs(fresh, c, obs);
+    if (p.out.obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    if (p.out.ncon) p.out.ncon[i] = count_floor_contacts(c);
   }
-  store_state(p, i, st);
-  p.flags[i] = newflags;
-  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
   MJS_STAMP(p, 5);
 }
 
