@@ -75,10 +75,11 @@ __device__ __forceinline__ void set_contact(Rows& r, double dist, double vx, dou
 
 // value of the constraint+Gauss cost, forces and active set (mj_constraintUpdate), nv = 2,
 // M = m*I, qfrc_smooth = qacc_smooth = 0
+template <int NS>
 __device__ __forceinline__ double cost_update(const Rows& r, const double* jar, double ax, double ay, double Max, double May, bool* active, double* force) {
   double cost = 0;
 #pragma unroll
-  for (int k = 0; k < NSLOT; k++) {
+  for (int k = 0; k < NS; k++) {
     bool act = r.on[k] && (k < 2 || jar[k] < 0);
     active[k] = act;
     force[k] = act ? -r.D[k] * jar[k] : 0.0;
@@ -88,20 +89,22 @@ __device__ __forceinline__ double cost_update(const Rows& r, const double* jar, 
   return cost + 0.5 * gauss;
 }
 
-// exact 1-D minimiser of the piecewise-quadratic cost (role of MuJoCo's PrimalSearch)
-__device__ __forceinline__ double line_search(const Rows& r, const double* jar, const double* jv, double g1, double g2) {
+// 1-D Newton with bracketing on the piecewise-quadratic cost (role of MuJoCo's PrimalSearch)
+template <int NS>
+__device__ __forceinline__ double line_search(const Rows& r, const double* jar, const double* jv, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
 #pragma unroll 1
   for (int it = 0; it < 50; it++) {
     double d1 = g1 + alpha * g2, d2 = g2;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
+    for (int k = 0; k < NS; k++) {
       double x = jar[k] + alpha * jv[k];
       if (r.on[k] && (k < 2 || x < 0)) {
         d1 += r.D[k] * x * jv[k];
         d2 += r.D[k] * jv[k] * jv[k];
       }
     }
+    if (fabs(d1) < gtol) break;  // MuJoCo's PrimalSearch stop: tolerance * ls_tolerance * |search| / scale
     if (d1 < 0) lo = alpha; else hi = alpha;
     if (d2 <= 0) break;
     double next = alpha + (-d1 / d2);
@@ -113,6 +116,7 @@ __device__ __forceinline__ double line_search(const Rows& r, const double* jar, 
 }
 
 // primal Newton solver (mj_solPrimal with Newton), nv = 2
+template <int NS>
 __device__ __forceinline__ void solve(const Rows& r, double wx, double wy, double mass, double& ax_out, double& ay_out) {
   double jar[NSLOT], jv[NSLOT], force[NSLOT];
   bool active[NSLOT];
@@ -122,20 +126,20 @@ __device__ __forceinline__ void solve(const Rows& r, double wx, double wy, doubl
   for (int trial = 0; trial < 2; trial++) {
     double tx = trial == 0 ? wx : 0.0, ty = trial == 0 ? wy : 0.0;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) jar[k] = -r.aref[k] + JX[k] * tx + JY[k] * ty;
-    double c = cost_update(r, jar, tx, ty, mass * tx, mass * ty, active, force);
+    for (int k = 0; k < NS; k++) jar[k] = -r.aref[k] + JX[k] * tx + JY[k] * ty;
+    double c = cost_update<NS>(r, jar, tx, ty, mass * tx, mass * ty, active, force);
     if (c < best) { best = c; ax = tx; ay = ty; }
   }
 #pragma unroll
-  for (int k = 0; k < NSLOT; k++) jar[k] = -r.aref[k] + JX[k] * ax + JY[k] * ay;
+  for (int k = 0; k < NS; k++) jar[k] = -r.aref[k] + JX[k] * ax + JY[k] * ay;
   double Max = mass * ax, May = mass * ay;
-  double cost = cost_update(r, jar, ax, ay, Max, May, active, force);
+  double cost = cost_update<NS>(r, jar, ax, ay, Max, May, active, force);
   const double scale = 1 / (mass * 2);  // 1/(meaninertia * nv)
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     double gx = Max, gy = May, hxx = mass, hxy = 0, hyy = mass;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) {
+    for (int k = 0; k < NS; k++) {
       if (r.on[k]) {
         gx -= JX[k] * force[k];
         gy -= JY[k] * force[k];
@@ -157,18 +161,18 @@ __device__ __forceinline__ void solve(const Rows& r, double wx, double wy, doubl
     double g1 = sx * Max + sy * May, g2 = sx * Mvx + sy * Mvy, snorm = sx * sx + sy * sy;
     if (sqrt(snorm) < MJS_MINVAL) break;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) jv[k] = JX[k] * sx + JY[k] * sy;
-    double alpha = line_search(r, jar, jv, g1, g2);
+    for (int k = 0; k < NS; k++) jv[k] = JX[k] * sx + JY[k] * sy;
+    double alpha = line_search<NS>(r, jar, jv, g1, g2, MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale);
     if (alpha == 0) break;
     ax += alpha * sx; ay += alpha * sy;
     Max += alpha * Mvx; May += alpha * Mvy;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++) jar[k] += alpha * jv[k];
+    for (int k = 0; k < NS; k++) jar[k] += alpha * jv[k];
     double oldcost = cost;
-    cost = cost_update(r, jar, ax, ay, Max, May, active, force);
+    cost = cost_update<NS>(r, jar, ax, ay, Max, May, active, force);
     double ngx = Max, ngy = May;
 #pragma unroll
-    for (int k = 0; k < NSLOT; k++)
+    for (int k = 0; k < NS; k++)
       if (r.on[k]) { ngx -= JX[k] * force[k]; ngy -= JY[k] * force[k]; }
     double improvement = scale * (oldcost - cost), gradient = scale * sqrt(ngx * ngx + ngy * ngy);
     if (improvement < MJS_SOLVER_TOLERANCE || gradient < MJS_SOLVER_TOLERANCE) break;
@@ -201,8 +205,13 @@ __device__ __forceinline__ void physics_step(State& st, double mx, double my, bo
   set_contact<6>(r, (st.qy - MJS_PM_ARENA_LO) - radius, st.vx, st.vy, K, B, tran);
   set_contact<10>(r, -(st.qx - MJS_PM_ARENA_HI) - radius, st.vx, st.vy, K, B, tran);
   set_contact<14>(r, -(st.qy - MJS_PM_ARENA_HI) - radius, st.vx, st.vy, K, B, tran);
+  // Wave-uniform fast path: when no lane of this wavefront has an active wall contact, only the two
+  // weld rows exist. Row order and arithmetic are identical to the 18-slot path (inactive slots
+  // contribute nothing there), so a lane gets the same bits whichever path its wavefront takes.
+  const bool any_contact = r.on[2] || r.on[6] || r.on[10] || r.on[14];
   double ax, ay;
-  solve(r, st.wx, st.wy, mass, ax, ay);
+  if (__any(any_contact)) solve<NSLOT>(r, st.wx, st.wy, mass, ax, ay);
+  else solve<2>(r, st.wx, st.wy, mass, ax, ay);
   bad = bad || bad_value(ax) || bad_value(ay) || bad_value(st.qx) || bad_value(st.qy) || bad_value(st.vx) || bad_value(st.vy);
   st.wx = ax; st.wy = ay;
   st.vx += dt * ax; st.vy += dt * ay;

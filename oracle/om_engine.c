@@ -708,14 +708,24 @@ static double constraint_update(const om_model* m, om_data* d, const double* jar
 }
 
 /* exact minimiser of the piecewise-quadratic cost along `search` (role of PrimalSearch) */
-static double line_search(const om_model* m, const om_data* d, const double* jar, const double* jv, double g1, double g2) {
+/* debug statistics (tests / tuning only) */
+long om_dbg_ls_calls = 0, om_dbg_ls_iters = 0, om_dbg_ls_max = 0, om_dbg_newton_calls = 0, om_dbg_newton_iters = 0, om_dbg_newton_max = 0;
+
+/* 1-D Newton with bracketing on the piecewise-quadratic cost along `search`. Stops like MuJoCo's
+ * PrimalSearch: when the directional derivative drops below gtol = tolerance * ls_tolerance *
+ * |search| / scale (ls_tolerance = 0.01, at most ls_iterations = 50 evaluations). */
+static double line_search(const om_model* m, const om_data* d, const double* jar, const double* jv, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
+  om_dbg_ls_calls++;
   for (int it = 0; it < 50; it++) {
+    om_dbg_ls_iters++;
+    if (it + 1 > om_dbg_ls_max) om_dbg_ls_max = it + 1;
     double d1 = g1 + alpha * g2, d2 = g2;
     for (int i = 0; i < d->nefc; i++) {
       double x = jar[i] + alpha * jv[i];
       if (d->efc_type[i] == OM_CNSTR_EQUALITY || x < 0) { d1 += d->efc_D[i] * x * jv[i]; d2 += d->efc_D[i] * jv[i] * jv[i]; }
     }
+    if (fabs(d1) < gtol) break;
     if (d1 < 0) lo = alpha; else hi = alpha;
     if (d2 <= 0) break;
     double step = -d1 / d2;
@@ -776,7 +786,7 @@ static void om_solve_constraint(const om_model* m, om_data* d) {
     for (int i = 0; i < nv; i++) { g1 += search[i] * (Ma[i] - d->qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
     if (sqrt(snorm) < MJS_MINVAL) break;
     for (int r = 0; r < nefc; r++) { jv[r] = 0; for (int k = 0; k < nv; k++) jv[r] += d->efc_J[r][k] * search[k]; }
-    double alpha = line_search(m, d, jar, jv, g1, g2);
+    double alpha = line_search(m, d, jar, jv, g1, g2, m->tolerance * 0.01 * sqrt(snorm) / scale);
     if (alpha == 0) break;
     for (int i = 0; i < nv; i++) { qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
     for (int r = 0; r < nefc; r++) jar[r] += alpha * jv[r];
@@ -792,6 +802,7 @@ static void om_solve_constraint(const om_model* m, om_data* d) {
     if (improvement < m->tolerance || gradient < m->tolerance) { iter++; break; }
   }
   d->solver_niter = iter;
+  om_dbg_newton_calls++; om_dbg_newton_iters += iter; if (iter > om_dbg_newton_max) om_dbg_newton_max = iter;
   memcpy(d->qacc, qacc, sizeof(double) * nv);
   memcpy(d->efc_force, force, sizeof(double) * nefc);
   for (int i = 0; i < nv; i++) {
