@@ -28,6 +28,19 @@ sys.path.insert(0, str(ROOT))
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def measured_traffic(task, n_local):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, FETCH corrected x2 per the gfx950
+    calibration). Only valid for the configuration it was measured on; otherwise None."""
+    try:
+        d = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
+        if task == "robot_reach" and n_local == 4096:
+            return d["corrected_bytes_per_launch"]["total"]
+    except Exception:  # noqa: BLE001
+        pass
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -140,7 +153,7 @@ def main():
                                    f"state obs + joint_configuration, uniform workspace actions, next-step auto-reset",
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "traffic": measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }

@@ -603,20 +603,21 @@ MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
 
 // initialize_episode (robot_reach.py:143-150): robot xyz -> IK from qpos0 = 0 -> set joints;
 // then target xyz. Returns the per-episode ik_failed flag (always clear after a reset).
-// (noinline + by-value result: the rare reset path keeps its own IK copy out of the hot code and the
+// (noinline, RNG handle by value -- the kernel argument block must never have its address taken, or
+// every lane copies it to scratch at kernel entry -- and by-value result: the rare reset path keeps its own IK copy out of the hot code and the
 // long-lived state of the step path never has its address taken)
-__device__ __noinline__ State episode_init(const KernelParams& p, int i) {
+__device__ __noinline__ State episode_init(DevRng rng, int i) {
   State st;
-  RngCursor c = rng_open(p.rng, i);
+  RngCursor c = rng_open(rng, i);
   double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
-  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(p.rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
   bool ok = tcp_pose_to_joints(rp, zeros, q);
 #pragma unroll
   for (int j = 0; j < NJ; j++) { st.q[j] = ok ? q[j] : 0.0; st.v[j] = 0; }
 #pragma unroll
-  for (int k = 0; k < 3; k++) st.target[k] = rng_uniform(p.rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
-  rng_close(p.rng, i, c);
+  for (int k = 0; k < 3; k++) st.target[k] = rng_uniform(rng, i, c, MJS_RR_SPACE_LO[k], MJS_RR_SPACE_HI[k]);
+  rng_close(rng, i, c);
   st.time = 0;
   return st;
 }
@@ -645,6 +646,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const int role = (ROLES == 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   const int i = blockIdx.x * 64 + lane;
   __shared__ double xch[1][ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
+  __shared__ double obs_tile[IS_RESET ? 1 : OBS_DIM * 64];  // wave-private transpose buffer for coalesced obs stores
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
   double obs[OBS_DIM];
@@ -652,7 +654,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
     if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    State st = episode_init(p, i);
+    State st = episode_init(p.rng, i);
     store_state(p, i, st);
     p.flags[i] = 0;
     fk(st.q, c);
@@ -784,13 +786,33 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   // has to stay live across that call
   store_state(p, i, st);
   p.flags[i] = newflags;
-  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+  // observations [N, 12] row-major: a lane-per-env store is a 96-B-strided scatter (2.5x write
+  // amplification measured with WRITE_SIZE); transpose the wave's 64x12 block through LDS and write
+  // it as 12 fully coalesced 512-B stores instead. Only this wavefront touches obs_tile.
+  {
+    KernelParams pn = p;
+    pn.out.obs = nullptr;
+    write_outputs<OBS_DIM>(pn, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+    if (p.out.obs) {
+      if (__ballot(1) == ~0ull) {  // whole wavefront alive: cooperative block store
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) obs_tile[lane * OBS_DIM + k] = obs[k];
+        __builtin_amdgcn_wave_barrier();
+        double* dst = p.out.obs + (size_t)blockIdx.x * 64 * OBS_DIM;
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
+      } else {  // some lanes left earlier (auto-reset path, tail of the batch): each lane writes its own row
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+      }
+    }
+  }
   if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
     if (p.out.terminal_obs) {
 #pragma unroll
       for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
     }
-    State fresh = episode_init(p, i);
+    State fresh = episode_init(p.rng, i);
     store_state(p, i, fresh);
     p.flags[i] = 0;
     fk(fresh.q, c);
