@@ -198,3 +198,37 @@ def test_kernel_variants_agree():
             assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=1e-10), k
         else:
             assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_sb3_vec_env_surface(oracle_mod):
+    """scripts/sb3/reach_sac.py:93-131 usage: VecEnv construction, numpy dict obs, same-step
+    auto-reset with terminal_observation / TimeLimit.truncated, per-rank seeding seed + rank."""
+    from mujoco_sim_amd.sb3_vec_env import HipSB3VecEnv
+
+    N = 16
+    env = HipSB3VecEnv("robot_reach", N, seed=7, time_limit=0.5)  # 5 control steps per episode
+    ob = oracle_mod.OracleBatch(1, N, 7, autoreset=1, time_limit=0.5)
+    assert env.num_envs == N and env.action_space.shape == (3,) and set(env.observation_space.spaces) == {"ur5e/tcp_position", "ur5e/joint_configuration", "target_position"}
+    obs = env.reset()
+    o = ob.reset()
+    assert np.allclose(np.concatenate([obs[k] for k in obs], axis=1), o["obs"], atol=ATOL)
+    rs = np.random.RandomState(0)
+    n_done = 0
+    for t in range(12):
+        a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N, 3))
+        obs, rew, dones, infos = env.step(a)
+        o = ob.step(a)
+        assert obs["ur5e/tcp_position"].dtype == np.float64 and rew.dtype == np.float32 and dones.dtype == bool
+        assert np.allclose(np.concatenate([obs[k] for k in obs], axis=1), o["obs"], atol=ATOL)
+        assert np.array_equal(dones, o["truncated"] | o["terminated"])
+        for i in range(N):
+            if dones[i]:
+                n_done += 1
+                assert infos[i]["TimeLimit.truncated"] is True
+                term = np.concatenate([infos[i]["terminal_observation"][k] for k in obs])
+                assert np.allclose(term, o["terminal_obs"][i], atol=ATOL)
+            else:
+                assert "terminal_observation" not in infos[i]
+    assert n_done == 2 * N
+    assert env.env_is_wrapped(object) == [False] * N and len(env.get_attr("num_envs")) == N
+    env.close()
