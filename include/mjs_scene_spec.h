@@ -186,4 +186,36 @@ MJS_K double MJS_RR_TARGET_DEFAULT_POS[3] = {0.0, -0.5, 0.001};
 MJS_K double MJS_TOP_DOWN_QUAT_XYZW[4] = {1.0, 0.0, 0.0, 0.0};
 MJS_K double MJS_ROBOT_ARENA_HALF = 1.5;       /* EmptyRobotArena(3), empty_robot_arena.py:18-20 */
 
+/* --------------------------------------------------- rendering (a15) */
+/* Fixed cameras [REF]: MuJoCo camera convention = looks along its local -z, +x right, +y up;
+ * quaternions (w,x,y,z) as written in the task code; fovy in degrees. */
+MJS_K double MJS_PM_CAM_POS[3] = {0.0, 0.0, 2.4};            /* point_reach.py:22 TOP_DOWN_CAMERA_CONFIG */
+MJS_K double MJS_PM_CAM_QUAT[4] = {1.0, 0.0, 0.0, 0.0};
+MJS_K double MJS_PM_CAM_FOVY = 30.0;
+MJS_K double MJS_RR_CAM_POS[3] = {0.0, -1.1, 0.5};           /* robot_reach.py:52 FRONT_TILTED_CAMERA_CONFIG */
+MJS_K double MJS_RR_CAM_QUAT[4] = {-0.7, -0.35, 0.0, 0.0};
+MJS_K double MJS_RR_CAM_FOVY = 70.0;
+/* Pointmass scene appearance [REF]: mjcf/walled_pointmass_arena.xml:4-9,12-19 (checker texture,
+ * decoration material, two lights), pointmass.py:55 (sphere rgba, clamped to [0,1]),
+ * point_reach.py:91-93 (target site box), entities/utils.py:40 (mocap site). */
+MJS_K float MJS_PM_GRID_RGB1[3] = {0.1f, 0.2f, 0.3f};
+MJS_K float MJS_PM_GRID_RGB2[3] = {0.2f, 0.3f, 0.4f};
+MJS_K float MJS_PM_WALL_RGB[3] = {0.3f, 0.5f, 0.7f};
+MJS_K float MJS_PM_SPHERE_RGBA[4] = {1.0f, 0.0f, 0.0f, 0.5f};
+MJS_K float MJS_PM_TARGET_RGB[3] = {0.0f, 1.0f, 0.0f};
+MJS_K float MJS_PM_TARGET_HALF = 0.04f;
+MJS_K float MJS_PM_MOCAP_SITE_RADIUS = 0.005f;
+MJS_K float MJS_SITE_DEFAULT_RGB[3] = {0.5f, 0.5f, 0.5f};
+MJS_K float MJS_PM_LIGHT_POS[2][3] = {{0.25f, 0.25f, 1.0f}, {-0.25f, -0.25f, 1.0f}};
+/* [MJ] default light / headlight / material parameters */
+MJS_K float MJS_LIGHT_DIFFUSE = 0.7f;
+MJS_K float MJS_LIGHT_SPECULAR = 0.3f;
+MJS_K float MJS_LIGHT_CUTOFF_COS = 0.70710678f;  /* cutoff 45 deg */
+MJS_K int   MJS_LIGHT_EXPONENT = 10;
+MJS_K float MJS_HEADLIGHT_AMBIENT = 0.1f;
+MJS_K float MJS_HEADLIGHT_DIFFUSE = 0.4f;
+MJS_K float MJS_HEADLIGHT_SPECULAR = 0.5f;
+MJS_K float MJS_MATERIAL_SPECULAR = 0.5f;
+MJS_K int   MJS_MATERIAL_SHININESS_POW2 = 6;     /* shininess 0.5 -> GL exponent 64 = 2^6 */
+
 #endif /* MJS_SCENE_SPEC_H */

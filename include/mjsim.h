@@ -118,6 +118,13 @@ int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, v
  * leading T axis. Open-loop rollouts (random / scripted policies, point_reach.py:218-240). */
 int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_outputs* out, void* stream);
 
+/* Replaces Camera.get_rgb_image -> physics.render(height, width, camera_id) (entities/camera.py:94-103)
+ * and DMCEnvironmentAdapter.render (dmc2gym.py:165-168) for the task's scene camera
+ * (camera = MJS_CAMERA_SCENE): rgb_dev uint8 [N, height, width, 3]. Own ray caster, cannot match
+ * OpenGL pixels. */
+enum { MJS_CAMERA_SCENE = 0 };
+int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uint8_t* rgb_dev, void* stream);
+
 /* checkpoint / resume of the physics+task state: float64 [state_dim, N] ... */
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream);

@@ -33,10 +33,9 @@ def _make_robot_reach_env(max_steps=100, device="cuda:0", **kwargs):
     return DMCEnvironmentAdapter(env, flatten_observation_space=False)
 
 
-# registry ids of the reference (mujoco_sim/__init__.py:26-40). The reference registers the
-# VISUAL variant of point_mass_reach; camera rendering is not built yet, so that id raises
-# NotImplementedError unless observation_type="state_observations" is passed. The two *_state
-# ids are additions for the state-observation configs of BASELINE.json.
+# registry ids of the reference (mujoco_sim/__init__.py:26-40): point_mass_reach-v0 is the VISUAL
+# variant (64x64 top-down camera image + position). robot_push_button_visual-v0 is not built yet.
+# The two *_state ids are additions for the state-observation configs of BASELINE.json.
 registry = {
     "mujoco_sim/point_mass_reach-v0": (partial(make_point_mass_reach_env, PointMassReachTask, max_steps=50),
                                        {"observation_type": "visual_observations", "image_resolution": 64}),

@@ -1,0 +1,214 @@
+// mjs_render.h — fixed-camera RGB render kernels.
+//
+// Replaces Camera.get_rgb_image -> physics.render(height, width, camera_id) (reference:
+// entities/camera.py:94-103; observable spec uint8 (H, W, 3), camera.py:146-150) for the scene
+// cameras of the tasks. The reference renders with MuJoCo's OpenGL pipeline, which cannot be
+// reproduced pixel-for-pixel (deviation D-6): this is a ray caster over the scene's analytic
+// primitives with a Blinn-Phong model fed by MuJoCo's default light/material parameters.
+// One thread per pixel, one workgroup row per env; output [N, H, W, 3] uint8 is the HBM-write
+// stream that bounds the visual configs (BASELINE config 5: 12 KB per 64x64 image).
+//
+// Arithmetic is float32 restricted to + - * / sqrt and comparisons with FMA contraction disabled,
+// so the image is bit-identical to the independent CPU restatement in oracle/om_render.c.
+#pragma once
+#include "mjs_kernel_common.h"
+#include "mjs_pointmass.h"
+
+namespace rend {
+
+#pragma clang fp contract(off)
+
+struct Cam {
+  float pos[3];
+  float right[3], up[3], back[3];  // camera local +x, +y, +z axes in world coordinates
+  float tan_half;                  // tan(fovy / 2)
+};
+
+struct RenderParams {
+  int N, H, W;
+  const double* state;  // [state_dim][N]
+  Cam cam;
+  uint8_t* out;  // [N, H, W, 3]
+};
+
+struct F3 {
+  float x, y, z;
+};
+MJS_DEV F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+MJS_DEV F3 add(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MJS_DEV F3 sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MJS_DEV F3 mul(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
+MJS_DEV float dotf(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MJS_DEV F3 normalize(F3 a) {
+  float n = sqrtf(dotf(a, a));
+  return F3{a.x / n, a.y / n, a.z / n};
+}
+MJS_DEV float pow_pow2(float x, int k) {  // x^(2^k)
+  for (int i = 0; i < k; i++) x = x * x;
+  return x;
+}
+
+struct Surf {
+  float t;  // ray parameter of the nearest hit so far (or +inf)
+  F3 n;     // surface normal
+  F3 rgb;
+};
+
+MJS_DEV void hit_rect_z(F3 o, F3 d, float z0, float hx, float hy, F3 rgb, bool checker, Surf& s) {
+  // horizontal rectangle centred on the z axis at height z0
+  if (d.z == 0.0f) return;
+  float t = (z0 - o.z) / d.z;
+  if (!(t > 0.0f) || !(t < s.t)) return;
+  float x = o.x + t * d.x, y = o.y + t * d.y;
+  if (x < -hx || x > hx || y < -hy || y > hy) return;
+  s.t = t;
+  s.n = f3(0, 0, 1);
+  if (checker) {
+    // builtin 2x2 checker, one repeat per unit length (texuniform), centred on the plane
+    int cx = x >= 0.0f ? 1 : 0;
+    int cy = y >= 0.0f ? 1 : 0;
+    s.rgb = ((cx + cy) & 1) ? f3(MJS_PM_GRID_RGB2[0], MJS_PM_GRID_RGB2[1], MJS_PM_GRID_RGB2[2])
+                            : f3(MJS_PM_GRID_RGB1[0], MJS_PM_GRID_RGB1[1], MJS_PM_GRID_RGB1[2]);
+  } else
+    s.rgb = rgb;
+}
+// vertical wall rectangle: plane {axis coordinate == c} with normal sign*e_axis, extent |other| <= half, z in [z0, z1]
+MJS_DEV void hit_wall(F3 o, F3 d, int axis, float c, float sign, float half, float z0, float z1, F3 rgb, Surf& s) {
+  float oa = axis == 0 ? o.x : o.y, da = axis == 0 ? d.x : d.y;
+  if (da == 0.0f) return;
+  float t = (c - oa) / da;
+  if (!(t > 0.0f) || !(t < s.t)) return;
+  float other = axis == 0 ? o.y + t * d.y : o.x + t * d.x;
+  float z = o.z + t * d.z;
+  if (other < -half || other > half || z < z0 || z > z1) return;
+  s.t = t;
+  s.n = axis == 0 ? f3(sign, 0, 0) : f3(0, sign, 0);
+  s.rgb = rgb;
+}
+MJS_DEV void hit_sphere(F3 o, F3 d, F3 c, float r, F3 rgb, Surf& s) {
+  F3 oc = sub(o, c);
+  float b = dotf(oc, d), cc = dotf(oc, oc) - r * r;
+  float disc = b * b - cc;
+  if (disc < 0.0f) return;
+  float t = -b - sqrtf(disc);
+  if (!(t > 0.0f) || !(t < s.t)) return;
+  s.t = t;
+  F3 p = add(o, mul(t, d));
+  s.n = normalize(sub(p, c));
+  s.rgb = rgb;
+}
+MJS_DEV void hit_aabb(F3 o, F3 d, F3 c, float h, F3 rgb, Surf& s) {
+  // axis-aligned cube of half-size h: slab test, entry face gives the normal
+  float tmin = 0.0f, tmax = s.t;
+  int ax = -1;
+  float sg = 0.0f;
+  const float oo[3] = {o.x - c.x, o.y - c.y, o.z - c.z}, dd[3] = {d.x, d.y, d.z};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (dd[k] == 0.0f) {
+      if (oo[k] < -h || oo[k] > h) return;
+      continue;
+    }
+    float t1 = (-h - oo[k]) / dd[k], t2 = (h - oo[k]) / dd[k];
+    float sgn = -1.0f;
+    if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; sgn = 1.0f; }
+    if (t1 > tmin) { tmin = t1; ax = k; sg = sgn; }
+    if (t2 < tmax) tmax = t2;
+    if (tmin > tmax) return;
+  }
+  if (ax < 0 || !(tmin > 0.0f) || !(tmin < s.t)) return;
+  s.t = tmin;
+  s.n = ax == 0 ? f3(sg, 0, 0) : ax == 1 ? f3(0, sg, 0) : f3(0, 0, sg);
+  s.rgb = rgb;
+}
+
+// Blinn-Phong with MuJoCo's default headlight + the scene's positional spot lights (dir 0 0 -1)
+template <int NLIGHT>
+MJS_DEV F3 shade(F3 p, F3 n, F3 eye, F3 rgb, const float (*lights)[3]) {
+  F3 v = normalize(sub(eye, p));
+  if (dotf(n, v) < 0.0f) n = mul(-1.0f, n);
+  float diff = 0.0f, spec = 0.0f;
+  {  // headlight at the camera
+    float ndl = dotf(n, v);
+    if (ndl > 0.0f) {
+      diff = diff + MJS_HEADLIGHT_DIFFUSE * ndl;
+      spec = spec + MJS_HEADLIGHT_SPECULAR * pow_pow2(ndl, MJS_MATERIAL_SHININESS_POW2);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NLIGHT; k++) {
+    F3 l = normalize(sub(f3(lights[k][0], lights[k][1], lights[k][2]), p));
+    float spotcos = l.z;  // cos between -l and the light direction (0,0,-1)
+    if (spotcos < MJS_LIGHT_CUTOFF_COS) continue;
+    float spot = pow_pow2(spotcos, 3) * pow_pow2(spotcos, 1);  // exponent 10
+    float ndl = dotf(n, l);
+    if (ndl > 0.0f) {
+      diff = diff + MJS_LIGHT_DIFFUSE * ndl * spot;
+      F3 hv = normalize(add(l, v));
+      float ndh = dotf(n, hv);
+      if (ndh > 0.0f) spec = spec + MJS_LIGHT_SPECULAR * pow_pow2(ndh, MJS_MATERIAL_SHININESS_POW2) * spot;
+    }
+  }
+  float k = MJS_HEADLIGHT_AMBIENT + diff, sp = MJS_MATERIAL_SPECULAR * spec;
+  return F3{rgb.x * k + sp, rgb.y * k + sp, rgb.z * k + sp};
+}
+
+MJS_DEV uint8_t to_u8(float c) {
+  c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+  return (uint8_t)(int)(c * 255.0f + 0.5f);
+}
+
+MJS_DEV F3 pixel_ray(const RenderParams& p, int row, int col) {
+  float aspect = (float)p.W / (float)p.H;
+  float px = (2.0f * ((float)col + 0.5f) / (float)p.W - 1.0f) * p.cam.tan_half * aspect;
+  float py = (1.0f - 2.0f * ((float)row + 0.5f) / (float)p.H) * p.cam.tan_half;
+  F3 d = f3(px * p.cam.right[0] + py * p.cam.up[0] - p.cam.back[0], px * p.cam.right[1] + py * p.cam.up[1] - p.cam.back[1],
+            px * p.cam.right[2] + py * p.cam.up[2] - p.cam.back[2]);
+  return normalize(d);
+}
+
+// Pointmass-Reach scene: walled_pointmass_arena.xml:12-19 + pointmass sphere + target / mocap sites
+__global__ __launch_bounds__(256) void pointmass_kernel(RenderParams p) {
+  const int env = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.H * p.W) return;
+  const int row = pix / p.W, col = pix - row * p.W;
+  const size_t N = p.N;
+  const double* st = p.state + env;
+  const float qx = (float)st[pm::S_QX * N], qy = (float)st[pm::S_QY * N], tx = (float)st[pm::S_TX * N], ty = (float)st[pm::S_TY * N];
+  const float mx = (float)st[pm::S_MX * N], my = (float)st[pm::S_MY * N];
+  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+  const F3 d = pixel_ray(p, row, col);
+  const F3 wall = f3(MJS_PM_WALL_RGB[0], MJS_PM_WALL_RGB[1], MJS_PM_WALL_RGB[2]);
+  const float hi = (float)MJS_PM_ARENA_HI, wz = (float)MJS_PM_WALL_Z;
+  Surf s;
+  s.t = INFINITY;
+  s.n = f3(0, 0, 1);
+  s.rgb = f3(0, 0, 0);
+  hit_rect_z(eye, d, 0.0f, hi, hi, f3(0, 0, 0), true, s);
+  hit_wall(eye, d, 0, -hi, 1.0f, hi, 0.0f, 2.0f * wz, wall, s);
+  hit_wall(eye, d, 1, -hi, 1.0f, hi, 0.0f, 2.0f * wz, wall, s);
+  hit_wall(eye, d, 0, hi, -1.0f, hi, 0.0f, 2.0f * wz, wall, s);
+  hit_wall(eye, d, 1, hi, -1.0f, hi, 0.0f, 2.0f * wz, wall, s);
+  hit_aabb(eye, d, f3(tx, ty, (float)(MJS_PM_RADIUS / 2)), MJS_PM_TARGET_HALF, f3(MJS_PM_TARGET_RGB[0], MJS_PM_TARGET_RGB[1], MJS_PM_TARGET_RGB[2]), s);
+  hit_sphere(eye, d, f3(mx, my, 0.0f), MJS_PM_MOCAP_SITE_RADIUS, f3(MJS_SITE_DEFAULT_RGB[0], MJS_SITE_DEFAULT_RGB[1], MJS_SITE_DEFAULT_RGB[2]), s);
+  F3 c = f3(0, 0, 0);  // background
+  if (s.t < INFINITY) c = shade<2>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_PM_LIGHT_POS);
+  // translucent pointmass sphere blended over whatever is behind it
+  Surf b;
+  b.t = s.t;
+  b.n = f3(0, 0, 1);
+  b.rgb = f3(0, 0, 0);
+  hit_sphere(eye, d, f3(qx, qy, (float)MJS_PM_RADIUS), (float)MJS_PM_RADIUS, f3(MJS_PM_SPHERE_RGBA[0], MJS_PM_SPHERE_RGBA[1], MJS_PM_SPHERE_RGBA[2]), b);
+  if (b.t < s.t) {
+    F3 sc = shade<2>(add(eye, mul(b.t, d)), b.n, eye, b.rgb, MJS_PM_LIGHT_POS);
+    const float a = MJS_PM_SPHERE_RGBA[3];
+    c = F3{a * sc.x + (1.0f - a) * c.x, a * sc.y + (1.0f - a) * c.y, a * sc.z + (1.0f - a) * c.z};
+  }
+  uint8_t* o = p.out + ((size_t)env * p.H * p.W + pix) * 3;
+  o[0] = to_u8(c.x);
+  o[1] = to_u8(c.y);
+  o[2] = to_u8(c.z);
+}
+
+}  // namespace rend

@@ -10,6 +10,8 @@
 #include "mjs_kernel_common.h"
 #include "mjs_pointmass.h"
 #include "mjs_reach.h"
+#include "mjs_render.h"
+#include <cmath>
 
 struct mjs_handle {
   mjs_config cfg;
@@ -249,6 +251,32 @@ int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_o
     int rc = launch<false>(h, make_params(h, actions_dev + (size_t)t * N * h->act_dim, nullptr, &o), (hipStream_t)stream);
     if (rc != MJS_OK) return rc;
   }
+  return MJS_OK;
+}
+
+int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uint8_t* rgb_dev, void* stream) {
+  if (!h || !rgb_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: null argument");
+  if (camera != MJS_CAMERA_SCENE || height <= 0 || width <= 0) return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: bad camera or size");
+  if (h->cfg.task != MJS_TASK_POINTMASS_REACH) return fail(h, MJS_ERR_UNSUPPORTED, "mjs_render: scene not built for this task yet");
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  rend::RenderParams p;
+  p.N = h->cfg.num_envs; p.H = height; p.W = width; p.state = h->state; p.out = rgb_dev;
+  // camera frame from the MuJoCo quaternion (w,x,y,z): columns of R are the local x (right), y (up), z (back) axes
+  const double* q = MJS_PM_CAM_QUAT;
+  const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  for (int k = 0; k < 3; k++) {
+    p.cam.pos[k] = (float)MJS_PM_CAM_POS[k];
+    p.cam.right[k] = (float)R[3 * k + 0];
+    p.cam.up[k] = (float)R[3 * k + 1];
+    p.cam.back[k] = (float)R[3 * k + 2];
+  }
+  p.cam.tan_half = (float)std::tan(MJS_PM_CAM_FOVY * 3.14159265358979323846 / 360.0);
+  dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
+  rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }
 

@@ -17,7 +17,7 @@ import numpy as np
 from .. import _native as nat
 from ..spaces import Box, Dict
 from ..vector_env import STATE_OBS, HipVectorEnv
-from .tasks.point_reach import ArraySpec
+from .tasks.point_reach import ArraySpec, BoundedArraySpec
 
 try:  # pragma: no cover
     import gymnasium as _gym
@@ -48,15 +48,15 @@ class HipEnvironment:
 
     def __init__(self, task, time_limit: float = float("inf"), device="cuda:0", strip_singleton_obs_buffer_dim: bool = True,
                  random_state=None):
-        if getattr(task, "observation_type", STATE_OBS) != STATE_OBS:
-            raise NotImplementedError("visual observations (camera render) are not built yet; use observation_type='state_observations'")
         self.task = task
         self._time_limit = time_limit
         kwargs = {}
         if hasattr(task, "config") and getattr(task.config, "terminate_on_success", False):
             kwargs["terminate_on_success"] = True
         self._venv = HipVectorEnv(task.task_name, 1, device=device, autoreset="next_step", reward_type=task.reward_type,
-                                  time_limit=(1e300 if np.isinf(time_limit) else time_limit), **kwargs)
+                                  time_limit=(1e300 if np.isinf(time_limit) else time_limit),
+                                  observation_type=getattr(task, "observation_type", STATE_OBS),
+                                  image_resolution=getattr(task, "image_resolution", 64), **kwargs)
         self._random_state = None
         if random_state is not None:
             self.seed(random_state)
@@ -72,7 +72,13 @@ class HipEnvironment:
         return self.task.action_spec()
 
     def observation_spec(self):
-        return OrderedDict((k, ArraySpec((n,), np.float64, name=k)) for k, _, n in self._venv.spec.obs_layout)
+        spec = OrderedDict()
+        for k, box in self._venv.single_observation_space.items():
+            if box.dtype == np.uint8:  # RGBObservable.array_spec (entities/camera.py:146-150)
+                spec[k] = BoundedArraySpec(box.shape, np.uint8, 0, 255, name=k)
+            else:
+                spec[k] = ArraySpec(box.shape, np.float64, name=k)
+        return spec
 
     def _timestep(self) -> TimeStep:
         b = self._venv._buf
@@ -195,7 +201,11 @@ class DMCEnvironmentAdapter(_EnvBase):
         return self._get_obs(time_step), {}
 
     def render(self, mode="rgb_array"):
-        raise NotImplementedError("render (camera ray-cast kernel) is not built yet (SURVEY.md row a15)")
+        """dmc2gym.py:165-168. The reference renders camera `render_camera_id` (default -1: MuJoCo's free
+        camera); here every id maps to the task's scene camera (own ray caster)."""
+        assert mode == "rgb_array", "only support rgb_array mode, given %s" % mode
+        height, width = self.render_dims
+        return self._env._venv.render(height, width)[0].cpu().numpy()
 
     def close(self):
         self._env.close()

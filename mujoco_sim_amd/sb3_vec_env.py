@@ -108,7 +108,7 @@ class HipSB3VecEnv(_Base):
         return [indices] if isinstance(indices, int) else list(indices)
 
     def get_images(self):
-        raise NotImplementedError("camera render kernel not built yet")
+        return list(self.venv.render(256, 256).cpu().numpy())
 
     def render(self, mode=None):
-        raise NotImplementedError("camera render kernel not built yet")
+        return self.get_images()[0]

@@ -76,7 +76,8 @@ class HipVectorEnv:
 
     def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
-                 terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0):
+                 terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
+                 observation_type: str = STATE_OBS, image_resolution: int = 64):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -122,6 +123,22 @@ class HipVectorEnv:
         self.single_action_space = Box(np.asarray(self.spec.action_low, dtype=np.float32), np.asarray(self.spec.action_high, dtype=np.float32), dtype=np.float32)
         self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
         self.action_space = batch_box(self.single_action_space, N)
+        # visual observations (point_reach.py:119-121: camera image + pointmass position)
+        if observation_type not in (STATE_OBS, VISUAL_OBS):
+            raise AssertionError(f"observation_type must be one of {(STATE_OBS, VISUAL_OBS)}")
+        self.observation_type = observation_type
+        self.image_resolution = int(image_resolution)
+        self._img = None
+        if observation_type == VISUAL_OBS:
+            if task != "point_mass_reach":
+                raise NotImplementedError("visual observations are built for the Pointmass scene only so far")
+            r = self.image_resolution
+            self._img = torch.zeros(N, r, r, 3, dtype=torch.uint8, device=dev)
+            self._visual_keys = ("pointmass/position",)
+            self.single_observation_space = Dict(OrderedDict(
+                [("pointmass/position", Box(-np.inf, np.inf, shape=(2,), dtype=np.float64)),
+                 ("Camera/rgb_image", Box(0, 255, shape=(r, r, 3), dtype=np.uint8))]))
+            self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
         if seed is not None:
             self.seed(seed)
 
@@ -134,6 +151,12 @@ class HipVectorEnv:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _obs_dict(self, flat):
+        if self._img is not None and flat is self._buf["obs"]:
+            # entity observables first (pointmass position, camera image), as in the reference's dict order
+            self.render(self.image_resolution, self.image_resolution, out=self._img)
+            d = OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout if k in self._visual_keys)
+            d["Camera/rgb_image"] = self._img
+            return d
         return OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout)
 
     def _info(self, b):
@@ -186,6 +209,15 @@ class HipVectorEnv:
         s = state.to(device=self.device, dtype=torch.float64).contiguous()
         assert s.shape == (self.state_dim, self.num_envs)
         nat.check(self._lib.mjs_set_state(self._h, C.c_void_p(s.data_ptr()), self._stream()), self._h)
+
+    def render(self, height: int = 64, width: int = 64, out: torch.Tensor | None = None) -> torch.Tensor:
+        """Scene-camera RGB images of all envs, uint8 [N, H, W, 3] on the GPU (replaces
+        Camera.get_rgb_image / physics.render, entities/camera.py:94-103; own ray caster, D-6)."""
+        if out is None:
+            out = torch.empty(self.num_envs, height, width, 3, dtype=torch.uint8, device=self.device)
+        assert out.shape == (self.num_envs, height, width, 3) and out.dtype == torch.uint8 and out.is_contiguous()
+        nat.check(self._lib.mjs_render(self._h, 0, height, width, C.c_void_p(out.data_ptr()), self._stream()), self._h)
+        return out
 
     def get_rng_state(self):
         """(mt uint32 [624, N], pos int32 [N]) — the per-env numpy-legacy MT19937 streams."""

@@ -1,0 +1,152 @@
+/* om_render.c — ORACLE (test infrastructure): CPU restatement of the scene-camera render.
+ *
+ * The reference obtains images from MuJoCo's OpenGL renderer through
+ * Camera.get_rgb_image (entities/camera.py:94-103); that pipeline is third-party and cannot be
+ * reproduced here ("rendered images cannot match OpenGL output"). What this file
+ * pins is the build's OWN image definition — pinhole camera in MuJoCo's convention (looks along
+ * local -z, fovy vertical), the scene's analytic primitives from
+ * mjcf/walled_pointmass_arena.xml:12-19, entities/pointmass.py:52-55, point_reach.py:91-93,
+ * Blinn-Phong with MuJoCo's default headlight / light / material parameters — so that the HIP
+ * kernel can be checked bit-for-bit (float32, only + - * / sqrt, no FMA contraction).
+ * PARITY UNPINNED against the reference's pixels.
+ */
+#include <math.h>
+#include <string.h>
+
+#include "../include/mjs_scene_spec.h"
+#include "mjs_oracle.h"
+
+typedef struct { float x, y, z; } v3;
+static v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
+static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
+static v3 vmul(float s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }
+static float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+static v3 vnorm(v3 a) { float n = sqrtf(vdot(a, a)); return V(a.x / n, a.y / n, a.z / n); }
+static float pow2k(float x, int k) { for (int i = 0; i < k; i++) x = x * x; return x; }
+
+typedef struct { float t; v3 n, rgb; } surf;
+
+static void rect_z(v3 o, v3 d, float z0, float hx, float hy, v3 rgb, int checker, surf* s) {
+  if (d.z == 0.0f) return;
+  float t = (z0 - o.z) / d.z;
+  if (!(t > 0.0f) || !(t < s->t)) return;
+  float x = o.x + t * d.x, y = o.y + t * d.y;
+  if (x < -hx || x > hx || y < -hy || y > hy) return;
+  s->t = t; s->n = V(0, 0, 1);
+  if (checker) {
+    int cx = x >= 0.0f, cy = y >= 0.0f;
+    s->rgb = ((cx + cy) & 1) ? V(MJS_PM_GRID_RGB2[0], MJS_PM_GRID_RGB2[1], MJS_PM_GRID_RGB2[2]) : V(MJS_PM_GRID_RGB1[0], MJS_PM_GRID_RGB1[1], MJS_PM_GRID_RGB1[2]);
+  } else s->rgb = rgb;
+}
+static void wall(v3 o, v3 d, int axis, float c, float sign, float half, float z0, float z1, v3 rgb, surf* s) {
+  float oa = axis == 0 ? o.x : o.y, da = axis == 0 ? d.x : d.y;
+  if (da == 0.0f) return;
+  float t = (c - oa) / da;
+  if (!(t > 0.0f) || !(t < s->t)) return;
+  float other = axis == 0 ? o.y + t * d.y : o.x + t * d.x;
+  float z = o.z + t * d.z;
+  if (other < -half || other > half || z < z0 || z > z1) return;
+  s->t = t; s->n = axis == 0 ? V(sign, 0, 0) : V(0, sign, 0); s->rgb = rgb;
+}
+static void sphere(v3 o, v3 d, v3 c, float r, v3 rgb, surf* s) {
+  v3 oc = vsub(o, c);
+  float b = vdot(oc, d), cc = vdot(oc, oc) - r * r;
+  float disc = b * b - cc;
+  if (disc < 0.0f) return;
+  float t = -b - sqrtf(disc);
+  if (!(t > 0.0f) || !(t < s->t)) return;
+  s->t = t;
+  s->n = vnorm(vsub(vadd(o, vmul(t, d)), c));
+  s->rgb = rgb;
+}
+static void cube(v3 o, v3 d, v3 c, float h, v3 rgb, surf* s) {
+  float tmin = 0.0f, tmax = s->t, sg = 0.0f;
+  int ax = -1;
+  float oo[3] = {o.x - c.x, o.y - c.y, o.z - c.z}, dd[3] = {d.x, d.y, d.z};
+  for (int k = 0; k < 3; k++) {
+    if (dd[k] == 0.0f) { if (oo[k] < -h || oo[k] > h) return; continue; }
+    float t1 = (-h - oo[k]) / dd[k], t2 = (h - oo[k]) / dd[k], sgn = -1.0f;
+    if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; sgn = 1.0f; }
+    if (t1 > tmin) { tmin = t1; ax = k; sg = sgn; }
+    if (t2 < tmax) tmax = t2;
+    if (tmin > tmax) return;
+  }
+  if (ax < 0 || !(tmin > 0.0f) || !(tmin < s->t)) return;
+  s->t = tmin;
+  s->n = ax == 0 ? V(sg, 0, 0) : ax == 1 ? V(0, sg, 0) : V(0, 0, sg);
+  s->rgb = rgb;
+}
+static v3 shade(v3 p, v3 n, v3 eye, v3 rgb, const float (*lights)[3], int nlight) {
+  v3 v = vnorm(vsub(eye, p));
+  if (vdot(n, v) < 0.0f) n = vmul(-1.0f, n);
+  float diff = 0.0f, spec = 0.0f;
+  float ndl = vdot(n, v);
+  if (ndl > 0.0f) {
+    diff = diff + MJS_HEADLIGHT_DIFFUSE * ndl;
+    spec = spec + MJS_HEADLIGHT_SPECULAR * pow2k(ndl, MJS_MATERIAL_SHININESS_POW2);
+  }
+  for (int k = 0; k < nlight; k++) {
+    v3 l = vnorm(vsub(V(lights[k][0], lights[k][1], lights[k][2]), p));
+    float spotcos = l.z;
+    if (spotcos < MJS_LIGHT_CUTOFF_COS) continue;
+    float spot = pow2k(spotcos, 3) * pow2k(spotcos, 1);
+    float nl = vdot(n, l);
+    if (nl > 0.0f) {
+      diff = diff + MJS_LIGHT_DIFFUSE * nl * spot;
+      float ndh = vdot(n, vnorm(vadd(l, v)));
+      if (ndh > 0.0f) spec = spec + MJS_LIGHT_SPECULAR * pow2k(ndh, MJS_MATERIAL_SHININESS_POW2) * spot;
+    }
+  }
+  float k = MJS_HEADLIGHT_AMBIENT + diff, sp = MJS_MATERIAL_SPECULAR * spec;
+  return V(rgb.x * k + sp, rgb.y * k + sp, rgb.z * k + sp);
+}
+static uint8_t to_u8(float c) {
+  c = c < 0.0f ? 0.0f : (c > 1.0f ? 1.0f : c);
+  return (uint8_t)(int)(c * 255.0f + 0.5f);
+}
+
+/* scene camera image of a Pointmass env: out uint8 [H, W, 3] */
+void om_render_pointmass(const om_env* e, int H, int W, uint8_t* out) {
+  const double* q = MJS_PM_CAM_QUAT;
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  float right[3], up[3], back[3];
+  for (int k = 0; k < 3; k++) { right[k] = (float)R[3 * k]; up[k] = (float)R[3 * k + 1]; back[k] = (float)R[3 * k + 2]; }
+  float tan_half = (float)tan(MJS_PM_CAM_FOVY * 3.14159265358979323846 / 360.0);
+  v3 eye = V((float)MJS_PM_CAM_POS[0], (float)MJS_PM_CAM_POS[1], (float)MJS_PM_CAM_POS[2]);
+  float qx = (float)e->d.qpos[0], qy = (float)e->d.qpos[1], tx = (float)e->target_pos[0], ty = (float)e->target_pos[1];
+  float mx = (float)e->d.mocap_pos[0][0], my = (float)e->d.mocap_pos[0][1];
+  v3 wallrgb = V(MJS_PM_WALL_RGB[0], MJS_PM_WALL_RGB[1], MJS_PM_WALL_RGB[2]);
+  float hi = (float)MJS_PM_ARENA_HI, wz = (float)MJS_PM_WALL_Z;
+  float aspect = (float)W / (float)H;
+  for (int row = 0; row < H; row++)
+    for (int col = 0; col < W; col++) {
+      float px = (2.0f * ((float)col + 0.5f) / (float)W - 1.0f) * tan_half * aspect;
+      float py = (1.0f - 2.0f * ((float)row + 0.5f) / (float)H) * tan_half;
+      v3 d = vnorm(V(px * right[0] + py * up[0] - back[0], px * right[1] + py * up[1] - back[1], px * right[2] + py * up[2] - back[2]));
+      surf s;
+      s.t = INFINITY; s.n = V(0, 0, 1); s.rgb = V(0, 0, 0);
+      rect_z(eye, d, 0.0f, hi, hi, V(0, 0, 0), 1, &s);
+      wall(eye, d, 0, -hi, 1.0f, hi, 0.0f, 2.0f * wz, wallrgb, &s);
+      wall(eye, d, 1, -hi, 1.0f, hi, 0.0f, 2.0f * wz, wallrgb, &s);
+      wall(eye, d, 0, hi, -1.0f, hi, 0.0f, 2.0f * wz, wallrgb, &s);
+      wall(eye, d, 1, hi, -1.0f, hi, 0.0f, 2.0f * wz, wallrgb, &s);
+      cube(eye, d, V(tx, ty, (float)(MJS_PM_RADIUS / 2)), MJS_PM_TARGET_HALF, V(MJS_PM_TARGET_RGB[0], MJS_PM_TARGET_RGB[1], MJS_PM_TARGET_RGB[2]), &s);
+      sphere(eye, d, V(mx, my, 0.0f), MJS_PM_MOCAP_SITE_RADIUS, V(MJS_SITE_DEFAULT_RGB[0], MJS_SITE_DEFAULT_RGB[1], MJS_SITE_DEFAULT_RGB[2]), &s);
+      v3 c = V(0, 0, 0);
+      if (s.t < INFINITY) c = shade(vadd(eye, vmul(s.t, d)), s.n, eye, s.rgb, MJS_PM_LIGHT_POS, 2);
+      surf b;
+      b.t = s.t; b.n = V(0, 0, 1); b.rgb = V(0, 0, 0);
+      sphere(eye, d, V(qx, qy, (float)MJS_PM_RADIUS), (float)MJS_PM_RADIUS, V(MJS_PM_SPHERE_RGBA[0], MJS_PM_SPHERE_RGBA[1], MJS_PM_SPHERE_RGBA[2]), &b);
+      if (b.t < s.t) {
+        v3 sc = shade(vadd(eye, vmul(b.t, d)), b.n, eye, b.rgb, MJS_PM_LIGHT_POS, 2);
+        float a = MJS_PM_SPHERE_RGBA[3];
+        c = V(a * sc.x + (1.0f - a) * c.x, a * sc.y + (1.0f - a) * c.y, a * sc.z + (1.0f - a) * c.z);
+      }
+      uint8_t* o = out + ((size_t)row * W + col) * 3;
+      o[0] = to_u8(c.x); o[1] = to_u8(c.y); o[2] = to_u8(c.z);
+    }
+}

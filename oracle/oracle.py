@@ -87,6 +87,7 @@ def lib() -> C.CDLL:
         L.om_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
         L.om_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.om_env_seed.argtypes = [C.c_void_p, C.c_uint32]
+        L.om_render_pointmass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.om_rng_seed.argtypes = [C.POINTER(_Rng), C.c_uint32]
         L.om_rng_uniform.argtypes = [C.POINTER(_Rng), C.c_double, C.c_double]
         L.om_rng_uniform.restype = C.c_double
@@ -195,6 +196,14 @@ class OracleBatch:
         a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, self.action_dim)
         lib().om_batch_step(self._h, a.ctypes.data, self._out.ctypes.data, self.nthreads)
         return self._result()
+
+    def render(self, height: int, width: int) -> np.ndarray:
+        """scene-camera images of all envs: uint8 [N, H, W, 3] (Pointmass scene only so far)"""
+        assert self.task == TASK_POINTMASS
+        img = np.zeros((self.n, height, width, 3), dtype=np.uint8)
+        for i in range(self.n):
+            lib().om_render_pointmass(lib().om_batch_env(self._h, i), height, width, img[i].ctypes.data)
+        return img
 
     def close(self):
         if self._h:

@@ -174,8 +174,6 @@ def test_single_env_adapter_matches_reference_semantics(oracle_mod):
     assert r is None and info["discount"] is None and not term and not trunc
     with pytest.raises(AssertionError):
         env.step(np.zeros(3, dtype=np.float32))
-    with pytest.raises(NotImplementedError):
-        m.make("mujoco_sim/point_mass_reach-v0")  # registered VISUAL variant: render kernel not built yet
     env.close()
 
 
@@ -231,4 +229,56 @@ def test_sb3_vec_env_surface(oracle_mod):
                 assert "terminal_observation" not in infos[i]
     assert n_done == 2 * N
     assert env.env_is_wrapped(object) == [False] * N and len(env.get_attr("num_envs")) == N
+    env.close()
+
+
+def test_render_bit_exact_with_oracle(oracle_mod):
+    """Scene-camera images (row a15): uint8 output of the HIP ray caster == the CPU restatement
+    bit for bit (float32, + - * / sqrt only, no FMA contraction), at the reference's 64x64
+    observation size and at the adapter's 256x256 render size, after some motion."""
+    import mujoco_sim_amd as m
+
+    N = 24
+    venv = m.HipVectorEnv("point_mass_reach", N, seed=2025)
+    ob = oracle_mod.OracleBatch(0, N, 2025)
+    venv.reset()
+    ob.reset()
+    acts = _actions("point_mass_reach", 7, N)
+    for t in range(7):
+        venv.step(torch.from_numpy(acts[t]))
+        ob.step(acts[t])
+    for res in (64, 256):
+        gpu = venv.render(res, res).cpu().numpy()
+        cpu = ob.render(res, res)
+        assert gpu.shape == (N, res, res, 3) and gpu.dtype == np.uint8
+        assert np.array_equal(gpu, cpu), f"{(gpu != cpu).sum()} differing bytes at {res}x{res}"
+    # the red translucent sphere is where the state says it is (pinhole model, top-down camera)
+    img = gpu[0]
+    x, y = venv.flat_obs[0, 0].item(), venv.flat_obs[0, 1].item()
+    f = 0.5 * 256 / np.tan(np.radians(15.0))
+    col, row = int(128 + f * x / (2.4 - 0.05)), int(128 - f * y / (2.4 - 0.05))
+    assert img[row, col, 0] > 150 and img[row, col, 0] > 1.5 * img[row, col, 2]
+    venv.close()
+
+
+def test_registered_visual_env_id():
+    """mujoco_sim/__init__.py:26-30: the registered point_mass_reach-v0 is the VISUAL variant
+    (64x64 image + position); test_gym_envs.py:21-36 determinism includes the image."""
+    import mujoco_sim_amd as m
+
+    env = m.make("mujoco_sim/point_mass_reach-v0")
+    assert list(env.observation_space.spaces) == ["pointmass/position", "Camera/rgb_image"]
+    assert env.observation_space["Camera/rgb_image"].shape == (64, 64, 3) and env.observation_space["Camera/rgb_image"].dtype == np.uint8
+    env.seed(2025)
+    obs, _ = env.reset()
+    env.seed(2025)
+    obs2, _ = env.reset()
+    env.seed(2024)
+    obs3, _ = env.reset()
+    for k, v in obs.items():
+        assert np.allclose(v, obs2[k], atol=1e-6)
+        assert not np.allclose(v, obs3[k], atol=1e-6)
+    o, r, term, trunc, info = env.step(env.action_space.sample())
+    assert o["Camera/rgb_image"].shape == (64, 64, 3) and o["Camera/rgb_image"].dtype == np.uint8
+    assert env.render().shape == (256, 256, 3)
     env.close()

@@ -216,3 +216,25 @@ def test_oracle_matches_golden(oracle_mod, name, task):
         for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
             assert np.array_equal(r[k], g[k][t]), (k, t)
     assert (g["step_type"] == 2).any() and (g["step_type"] == 0).any()  # fixtures cover episode ends + auto-resets
+
+
+def test_oracle_render_camera_model(oracle_mod):
+    """Own image definition: pinhole camera in MuJoCo's convention, top-down at
+    z = 2.4 with fovy 30 deg (point_reach.py:22). The red sphere and the green target box project
+    where the state says; outside the 1 m arena the background is black."""
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_POINTMASS, 1, 2025)
+    obs = b.reset()["obs"][0]
+    img = b.render(128, 128)[0]
+    assert img.shape == (128, 128, 3) and img.dtype == np.uint8
+    f = 0.5 * 128 / np.tan(np.radians(15.0))
+
+    def pix(x, y, z):
+        return int(64 - f * y / (2.4 - z)), int(64 + f * x / (2.4 - z))  # row, col
+
+    r, c = pix(obs[0], obs[1], 0.05)
+    assert img[r, c, 0] > 150 and img[r, c, 0] > 1.5 * img[r, c, 1]  # pointmass: red, blended over the floor
+    r, c = pix(obs[2], obs[3], 0.065)
+    assert img[r, c, 1] > 100 and img[r, c, 0] < 40 and img[r, c, 2] < 40  # target: green box top
+    assert (img[0, 0] == 0).all() and (img[127, 127] == 0).all()  # beyond the arena: nothing
+    centre = img[60:68, 60:68].reshape(-1, 3).astype(int)
+    assert (centre[:, 2] > centre[:, 0]).all()  # bluish checker floor
