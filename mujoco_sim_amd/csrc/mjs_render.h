@@ -40,8 +40,8 @@ MJS_DEV F3 sub(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 MJS_DEV F3 mul(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
 MJS_DEV float dotf(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 MJS_DEV F3 normalize(F3 a) {
-  float n = sqrtf(dotf(a, a));
-  return F3{a.x / n, a.y / n, a.z / n};
+  float inv = 1.0f / sqrtf(dotf(a, a));  // one IEEE division, then multiplies (same on the CPU side)
+  return F3{a.x * inv, a.y * inv, a.z * inv};
 }
 MJS_DEV float pow_pow2(float x, int k) {  // x^(2^k)
   for (int i = 0; i < k; i++) x = x * x;

@@ -22,7 +22,7 @@ static v3 vadd(v3 a, v3 b) { return V(a.x + b.x, a.y + b.y, a.z + b.z); }
 static v3 vsub(v3 a, v3 b) { return V(a.x - b.x, a.y - b.y, a.z - b.z); }
 static v3 vmul(float s, v3 a) { return V(s * a.x, s * a.y, s * a.z); }
 static float vdot(v3 a, v3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-static v3 vnorm(v3 a) { float n = sqrtf(vdot(a, a)); return V(a.x / n, a.y / n, a.z / n); }
+static v3 vnorm(v3 a) { float inv = 1.0f / sqrtf(vdot(a, a)); return V(a.x * inv, a.y * inv, a.z * inv); }
 static float pow2k(float x, int k) { for (int i = 0; i < k; i++) x = x * x; return x; }
 
 typedef struct { float t; v3 n, rgb; } surf;
