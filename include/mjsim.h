@@ -125,6 +125,11 @@ int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_o
 enum { MJS_CAMERA_SCENE = 0 };
 int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uint8_t* rgb_dev, void* stream);
 
+/* Test hook: the device implementation of ur5e.inverse_kinematics_closest (entities/robots/robot.py:33-37)
+ * on n independent inputs: flange poses T_dev [n, 12] (row-major 3x3 rotation then translation),
+ * guesses [n, 6] -> q_dev [n, 6], ok_dev [n]. No handle needed; device = current HIP device. */
+int mjs_debug_ur5e_ik(const double* T_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream);
+
 /* checkpoint / resume of the physics+task state: float64 [state_dim, N] ... */
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream);

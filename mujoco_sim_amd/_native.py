@@ -25,7 +25,7 @@ FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
 EXPORTED_SYMBOLS = [
     "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
     "mjs_create", "mjs_destroy", "mjs_last_error", "mjs_seed", "mjs_reset", "mjs_step", "mjs_rollout",
-    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render",
+    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik",
 ]
 
 
@@ -96,6 +96,7 @@ def lib() -> C.CDLL:
     L.mjs_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(MjsOutputs), C.c_void_p]
     L.mjs_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.mjs_debug_ur5e_ik.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mjs_render.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.mjs_get_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_set_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

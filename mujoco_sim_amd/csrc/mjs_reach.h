@@ -329,22 +329,215 @@ MJS_DEV void actuate_and_solve(const double* q, const double* v, const double* c
   udu_solve(A, Dinv, rhs);
 }
 
+// ------------------------------------------------------------------ joint-limit rows
+// mj_instantiateLimit / mj_makeImpedance / mj_referenceConstraint + the primal Newton solver
+// (mj_solPrimal) for the only constraint rows the Robot-Reach scene can activate: joint limits
+// (MJS_UR_JNT_RANGE; J = +-e_j). 12 static slots: 2j = lower side of joint j, 2j+1 = upper side, the
+// oracle's row order. The solver is cold-started at qacc_smooth (the kernel does not carry
+// qacc_warmstart; the strictly convex problem has one minimiser, so this agrees with the oracle to
+// the solver tolerance; fault bit MJS_FAULT_LIMIT_COLDSTART reports that rows were active).
+constexpr int NLIM = 2 * NJ;
+struct LimitRows {
+  double D[NLIM], aref[NLIM];
+  bool on[NLIM];
+};
+MJS_DEV bool build_limit_rows(const double* q, const double* v, LimitRows& r) {
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  bool any = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+#pragma unroll
+    for (int side = 0; side < 2; side++) {
+      const int k = 2 * j + side;
+      const double sgn = side == 0 ? 1.0 : -1.0;  // row Jacobian entry on dof j
+      double dist = side == 0 ? q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - q[j];
+      bool on = dist < 0.0;  // jnt_margin = 0
+      double imp = impedance_default(dist);
+      double R = fmax(MJS_MINVAL, (1 - imp) * UR5E_DOF_INVWEIGHT0[j] / imp);
+      r.on[k] = on;
+      r.D[k] = 1 / R;
+      r.aref[k] = -B * (sgn * v[j]) - K * imp * dist;
+      any = any || on;
+    }
+  }
+  return any;
+}
+// in-place Cholesky of a symmetric positive definite 6x6 (lower triangle used) and solve
+MJS_DEV bool chol6(double H[NJ][NJ]) {
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double s = H[i][j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k];
+      if (i == j) {
+        if (s < MJS_MINVAL) return false;
+        H[i][i] = sqrt(s);
+      } else
+        H[i][j] = s / H[j][j];
+    }
+  }
+  return true;
+}
+MJS_DEV void chol6_solve(const double L[NJ][NJ], double* x) {
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+    double s = x[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s / L[i][i];
+  }
+#pragma unroll
+  for (int i = NJ - 1; i >= 0; i--) {
+    double s = x[i];
+#pragma unroll
+    for (int k = i + 1; k < NJ; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+// constraint force in joint space for the active limit rows; Mf = full symmetric M incl. armature
+__device__ __noinline__ void solve_limits(const double Mf[NJ][NJ], const double* qfrc_smooth, const LimitRows& r, double* qfrc_constraint) {
+  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], jar[NLIM], force[NLIM];
+  bool active[NLIM];
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) L[i][j] = Mf[i][j];
+    a_s[i] = qfrc_smooth[i];
+  }
+  chol6(L);
+  chol6_solve(L, a_s);  // qacc_smooth
+#pragma unroll
+  for (int i = 0; i < NJ; i++) a[i] = a_s[i];
+  auto update = [&](double& cost_out) {
+    double cost = 0;
+#pragma unroll
+    for (int k = 0; k < NLIM; k++) {
+      bool act = r.on[k] && jar[k] < 0;
+      active[k] = act;
+      force[k] = act ? -r.D[k] * jar[k] : 0.0;
+      if (act) cost += 0.5 * r.D[k] * jar[k] * jar[k];
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) gauss += (Ma[i] - qfrc_smooth[i]) * (a[i] - a_s[i]);
+    cost_out = cost + 0.5 * gauss;
+  };
+  auto refresh = [&]() {
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * a[k];
+      Ma[i] = m;
+    }
+#pragma unroll
+    for (int k = 0; k < NLIM; k++) jar[k] = -r.aref[k] + ((k & 1) ? -a[k >> 1] : a[k >> 1]);
+  };
+  refresh();
+  double cost;
+  update(cost);
+  const double scale = 1 / (UR5E_MEANINERTIA * NJ);
+#pragma unroll 1
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[NJ], search[NJ], Mv[NJ], H[NJ][NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      grad[i] = Ma[i] - qfrc_smooth[i] - (force[2 * i] - force[2 * i + 1]);
+#pragma unroll
+      for (int j = 0; j <= i; j++) H[i][j] = Mf[i][j];
+      if (active[2 * i]) H[i][i] += r.D[2 * i];
+      if (active[2 * i + 1]) H[i][i] += r.D[2 * i + 1];
+      search[i] = -grad[i];
+    }
+    if (!chol6(H)) break;
+    chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * search[k];
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    // 1-D Newton with bracketing, MuJoCo's gradient tolerance (same routine as the pointmass kernel)
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+#pragma unroll
+      for (int k = 0; k < NLIM; k++) {
+        double jv = (k & 1) ? -search[k >> 1] : search[k >> 1];
+        double x = jar[k] + alpha * jv;
+        if (r.on[k] && x < 0) { d1 += r.D[k] * x * jv; d2 += r.D[k] * jv * jv; }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+#pragma unroll
+    for (int k = 0; k < NLIM; k++) jar[k] += alpha * ((k & 1) ? -search[k >> 1] : search[k >> 1]);
+    double oldcost = cost;
+    update(cost);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double g = Ma[i] - qfrc_smooth[i] - (force[2 * i] - force[2 * i + 1]);
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+#pragma unroll
+  for (int i = 0; i < NJ; i++) qfrc_constraint[i] = force[2 * i] - force[2 * i + 1];
+}
+
 // One forward-dynamics evaluation + implicitfast solve: (M - dt*dF/dv)^-1 qfrc_smooth, no
 // constraint rows active. M(q) and the bias forces come from the generated straight-line code
 // (tools/gen_ur5e_dynamics.py: link-local CRBA + RNE with every structural zero folded).
-MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, double* qacc_int) {
+MJS_DEV void dynamics(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, double* qacc_int, bool& limit_rows_active) {
 #if MJS_REACH_GENERIC_DYNAMICS
   dynamics_generic(q, v, ctrl, qacc_int);
 #else
-  double M[21], bias[NJ], A[NJ][NJ], rhs[NJ];
+  double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
   ur5e_dynamics_gen(cs, sn, v, M, bias);
 #pragma unroll
   for (int i = 0; i < NJ; i++) {
 #pragma unroll
     for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
-    rhs[i] = -bias[i];
   }
-  actuate_and_solve(q, v, ctrl, A, rhs);
+  const int clamped = actuator_forces(q, v, ctrl, fact);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];  // qfrc_smooth = passive - bias + actuator
+  LimitRows rows;
+  if (build_limit_rows(q, v, rows)) {  // rare: some joint is beyond its range
+    double Mf[NJ][NJ], fc[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? A[i][j] : A[j][i];
+      Mf[i][i] += MJS_UR_ARMATURE;
+    }
+    solve_limits(Mf, rhs, rows, fc);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) rhs[j] += fc[j];  // + qfrc_constraint
+    limit_rows_active = true;
+  }
+  factor_system(A, clamped, Dinv);
+  udu_solve(A, Dinv, rhs);
 #pragma unroll
   for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
 #endif
@@ -631,6 +824,59 @@ MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
   for (int k = 0; k < 3; k++) obs[9 + k] = st.target[k];
 }
 
+// The 20 substeps of one control step on ONE wavefront, joint-limit rows included (robust path: used
+// by kernel_variant = single wave, and by the default kernel for workgroups in which some joint is
+// within reach of its range). noinline + by value: keeps this rarely-taken code (and the limit
+// solver's call frame) out of the role-specialised hot loop.
+struct SoloIn {
+  double q[NJ], v[NJ], q0[NJ], q1[NJ], cs[NJ], sn[NJ], time, t0, t1;
+};
+struct SoloOut {
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], time;
+  bool bad, limit_rows_active;
+};
+__device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
+  // work on register copies; the in/out structs live in the call frame
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { q[j] = in.q[j]; v[j] = in.v[j]; cs[j] = in.cs[j]; sn[j] = in.sn[j]; q0[j] = in.q0[j]; q1[j] = in.q1[j]; }
+  double time = in.time;
+  const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
+  bool bad = false, limit_rows_active = false;
+#pragma unroll 1
+  for (int s = 0; s < MJS_RR_NSUB; s++) {
+    // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
+    double t = fmin(fmax(time, t0), t1);
+    double ctrl[NJ], qacc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    dynamics(q, v, ctrl, cs, sn, qacc, limit_rows_active);
+    double acc2 = 0, dq2 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      acc2 = fma(qacc[j], qacc[j], acc2);
+      v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+      double dq = MJS_RR_PHYSICS_DT * v[j];
+      q[j] += dq;
+      dq2 = fma(dq, dq, dq2);
+      rotate_small(cs[j], sn[j], dq);
+    }
+    bad = bad || !(acc2 <= 1e20);
+    if (!(dq2 <= 0.01)) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(q[j], &sn[j], &cs[j]);
+    }
+    time += MJS_RR_PHYSICS_DT;
+  }
+  SoloOut o;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; }
+  o.time = time;
+  o.bad = bad;
+  o.limit_rows_active = limit_rows_active;
+  return o;
+}
+
 // ROLES == 1: one wavefront steps 64 envs. ROLES == 2 (default for stepping): two wavefronts of
 // one workgroup, placed on different SIMDs of the CU, step the same 64 envs: role 0 builds M(q),
 // factorises the implicitfast matrix (U D U^T) and inverts U while role 1 evaluates the servo
@@ -678,87 +924,102 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 1);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
-  bool bad = false;
+  bool bad = false, limit_rows_active = false;
   double cs[NJ], sn[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+  // Joint-limit rows can only become active if a joint gets within reach of its range during this
+  // control step (0.6 rad of travel is far beyond what the clamped servos produce in 0.1 s). Then the
+  // whole workgroup takes the robust single-wavefront path, which checks the limits every substep;
+  // both roles evaluate the same predicate on the same data, so the decision is consistent.
+  bool near_limit = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) near_limit = near_limit || (st.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - st.q[j] < 0.6);
+  const bool solo = (ROLES == 1) || __any(near_limit);
+  if (solo) {
+    if (role != 0) return;
+    SoloIn in;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
+    in.time = st.time; in.t0 = t0; in.t1 = t1;
+    SoloOut o = solo_control_step(in);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
+    st.time = o.time;
+    bad = o.bad;
+    limit_rows_active = o.limit_rows_active;
+  } else if constexpr (ROLES == 2) {
 #pragma unroll 1
-  for (int s = 0; s < MJS_RR_NSUB; s++) {
-    double qacc[NJ];
-    if (ROLES == 1) {
-      // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
-      double t = fmin(fmax(st.time, t0), t1);
-      double ctrl[NJ];
+    for (int s = 0; s < MJS_RR_NSUB; s++) {
+      double qacc[NJ];
+      if (role == 1) {
+        // role 1: servo set-point, actuator forces and bias forces -> qfrc_smooth
+        double t = fmin(fmax(st.time, t0), t1);
+        double ctrl[NJ], bias[NJ], fact[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-      dynamics(st.q, st.v, ctrl, cs, sn, qacc);
-    } else if (role == 1) {
-      // role 1: servo set-point, actuator forces and bias forces -> qfrc_smooth
-      double t = fmin(fmax(st.time, t0), t1);
-      double ctrl[NJ], bias[NJ], fact[NJ];
+        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+        actuator_forces(st.q, st.v, ctrl, fact);
+        ur5e_bias_gen(cs, sn, st.v, bias);
 #pragma unroll
-      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-      actuator_forces(st.q, st.v, ctrl, fact);
-      ur5e_bias_gen(cs, sn, st.v, bias);
+        for (int j = 0; j < NJ; j++) xch[0][j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+        __syncthreads();  // qfrc_smooth published
+        __syncthreads();  // qacc published
 #pragma unroll
-      for (int j = 0; j < NJ; j++) xch[0][j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
-      __syncthreads();  // qfrc_smooth published
-      __syncthreads();  // qacc published
+        for (int j = 0; j < NJ; j++) qacc[j] = xch[0][6 + j][lane];
+      } else {
+        // role 0: joint-space inertia, implicitfast matrix, U D U^T and U^-1, all before the barrier
+        // (overlapping role 1); the clamp mask is recomputed here (cheap)
+        if (s == 10) MJS_STAMP(p, 8);
+        double t = fmin(fmax(st.time, t0), t1);
+        double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
 #pragma unroll
-      for (int j = 0; j < NJ; j++) qacc[j] = xch[0][6 + j][lane];
-    } else {
-      // role 0: joint-space inertia, implicitfast matrix, U D U^T and U^-1, all before the barrier
-      // (overlapping role 1); the clamp mask is recomputed here (cheap)
-      if (s == 10) MJS_STAMP(p, 8);
-      double t = fmin(fmax(st.time, t0), t1);
-      double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+        int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
+        ur5e_M_gen(cs, sn, M);
 #pragma unroll
-      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-      int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
-      ur5e_M_gen(cs, sn, M);
+        for (int r = 0; r < NJ; r++) {
 #pragma unroll
-      for (int r = 0; r < NJ; r++) {
+          for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+        }
+        factor_system(A, clamped, Dinv);
+        invert_unit_upper(A, W);
+        // opaque register uses pin the whole factorisation before the barrier
 #pragma unroll
-        for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+        for (int r = 0; r < NJ; r++) {
+          asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+          for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+        }
+        if (s == 10) MJS_STAMP(p, 9);
+        __syncthreads();  // qfrc_smooth published
+        if (s == 10) MJS_STAMP(p, 10);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) rhs[j] = xch[0][j][lane];
+        apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) xch[0][6 + j][lane] = qacc[j];
+        __syncthreads();  // qacc published
+        if (s == 10) MJS_STAMP(p, 11);
       }
-      factor_system(A, clamped, Dinv);
-      invert_unit_upper(A, W);
-      // opaque register uses pin the whole factorisation before the barrier
+      // mj_checkAcc: NaN / inf / |qacc| > 1e10 all make the sum of squares fail this one test
+      double acc2 = 0, dq2 = 0;
 #pragma unroll
-      for (int r = 0; r < NJ; r++) {
-        asm volatile("" : "+v"(Dinv[r]));
-#pragma unroll
-        for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+      for (int j = 0; j < NJ; j++) {
+        acc2 = fma(qacc[j], qacc[j], acc2);
+        st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+        double dq = MJS_RR_PHYSICS_DT * st.v[j];
+        st.q[j] += dq;
+        dq2 = fma(dq, dq, dq2);
+        rotate_small(cs[j], sn[j], dq);
       }
-      if (s == 10) MJS_STAMP(p, 9);
-      __syncthreads();  // qfrc_smooth published
-      if (s == 10) MJS_STAMP(p, 10);
+      bad = bad || !(acc2 <= 1e20);
+      if (!(dq2 <= 0.01)) {  // some |dq| may exceed 0.1 rad (runaway state): fall back to the exact functions
 #pragma unroll
-      for (int j = 0; j < NJ; j++) rhs[j] = xch[0][j][lane];
-      apply_inverse(W, Dinv, rhs, qacc);
-#pragma unroll
-      for (int j = 0; j < NJ; j++) xch[0][6 + j][lane] = qacc[j];
-      __syncthreads();  // qacc published
-      if (s == 10) MJS_STAMP(p, 11);
+        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+      }
+      st.time += MJS_RR_PHYSICS_DT;
+      if (role == 0 && s == 10) MJS_STAMP(p, 12);
     }
-    // mj_checkAcc: NaN / inf / |qacc| > 1e10 all make the sum of squares fail this one test
-    double acc2 = 0, dq2 = 0;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      acc2 = fma(qacc[j], qacc[j], acc2);
-      st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
-      double dq = MJS_RR_PHYSICS_DT * st.v[j];
-      st.q[j] += dq;
-      dq2 = fma(dq, dq, dq2);
-      rotate_small(cs[j], sn[j], dq);
-    }
-    bad = bad || !(acc2 <= 1e20);
-    if (!(dq2 <= 0.01)) {  // some |dq| may exceed 0.1 rad (runaway state): fall back to the exact functions
-#pragma unroll
-      for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-    }
-    st.time += MJS_RR_PHYSICS_DT;
-    if (ROLES == 2 && role == 0 && s == 10) MJS_STAMP(p, 12);
   }
   if (role != 0) return;
 #pragma unroll
@@ -779,7 +1040,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 3);
   int ncon = count_floor_contacts(c);
   MJS_STAMP(p, 4);
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0);
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
   // everything is written out BEFORE the (rare, real function call) same-step reset so that no value

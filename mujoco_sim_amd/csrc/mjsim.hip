@@ -78,6 +78,19 @@ __global__ void set_state_kernel(double* state, uint8_t* flags, const double* in
   flags[i] = (uint8_t)in[(size_t)S * N + i];
 }
 
+__global__ void debug_ik_kernel(const double* T, const double* guess, double* q, uint8_t* ok, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  rr::Aff A;
+  for (int k = 0; k < 9; k++) A.r[k] = T[(size_t)i * 12 + k];
+  for (int k = 0; k < 3; k++) A.t[k] = T[(size_t)i * 12 + 9 + k];
+  double g[6], out[6] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 6; k++) g[k] = guess[(size_t)i * 6 + k];
+  bool found = rr::ik_closest(A, g, out);
+  for (int k = 0; k < 6; k++) q[(size_t)i * 6 + k] = out[k];
+  ok[i] = found;
+}
+
 KernelParams make_params(const mjs_handle* h, const double* actions, const uint8_t* mask, const mjs_outputs* out) {
   KernelParams p;
   p.N = h->cfg.num_envs;
@@ -277,6 +290,13 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
   rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
   HIP_TRY(h, hipGetLastError());
+  return MJS_OK;
+}
+
+int mjs_debug_ur5e_ik(const double* T_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream) {
+  if (!T_dev || !guess_dev || !q_dev || !ok_dev || n < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_debug_ur5e_ik: bad argument");
+  debug_ik_kernel<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(T_dev, guess_dev, q_dev, ok_dev, n);
+  HIP_TRY(nullptr, hipGetLastError());
   return MJS_OK;
 }
 

@@ -390,6 +390,15 @@ void om_debug_reach_dynamics(const double* q, const double* v, double* M_out /*3
   }
 }
 
+/* debug hook for tests: overwrite joint positions / velocities of a robot env (then mj_forward) */
+void om_debug_set_robot_state(om_env* e, const double* q, const double* v) {
+  memcpy(e->d.qpos, q, sizeof(double) * 6);
+  memcpy(e->d.qvel, v, sizeof(double) * 6);
+  memset(e->d.qacc_warmstart, 0, sizeof e->d.qacc_warmstart);
+  e->reset_pending = 0;
+  om_forward(&e->m, &e->d);
+}
+
 /* ---------------------------------------------------------------- batch */
 struct om_batch { int n; om_env* envs; };
 

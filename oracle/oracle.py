@@ -197,6 +197,14 @@ class OracleBatch:
         lib().om_batch_step(self._h, a.ctypes.data, self._out.ctypes.data, self.nthreads)
         return self._result()
 
+    def set_robot_state(self, q, v):
+        """debug: overwrite joint positions/velocities of every robot env ([N,6] each)"""
+        q = np.ascontiguousarray(q, dtype=np.float64); v = np.ascontiguousarray(v, dtype=np.float64)
+        L = lib()
+        L.om_debug_set_robot_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        for i in range(self.n):
+            L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
+
     def render(self, height: int, width: int) -> np.ndarray:
         """scene-camera images of all envs: uint8 [N, H, W, 3] (Pointmass scene only so far)"""
         assert self.task == TASK_POINTMASS

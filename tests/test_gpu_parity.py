@@ -282,3 +282,73 @@ def test_registered_visual_env_id():
     assert o["Camera/rgb_image"].shape == (64, 64, 3) and o["Camera/rgb_image"].dtype == np.uint8
     assert env.render().shape == (256, 256, 3)
     env.close()
+
+
+def test_joint_limit_rows_parity(oracle_mod):
+    """Joint-limit constraint rows (mj_instantiateLimit + Newton). From q_elbow = -3.10 the closest IK
+    solution is the 2*pi-wrapped one (-5.06), so the (ctrl-clamped) servo holds the elbow against its
+    lower limit (-3.1415) for the whole run: sustained active rows. The kernel's limit solver is
+    cold-started, the oracle warm-started: agreement to the solver tolerance (1e-6), flags exact."""
+    import mujoco_sim_amd as m
+
+    N = 64
+    venv = m.HipVectorEnv("robot_reach", N, seed=5, time_limit=1e9)
+    ob = oracle_mod.OracleBatch(1, N, 5, time_limit=1e9)
+    venv.reset()
+    ob.reset()
+    rs = np.random.RandomState(3)
+    q = np.tile([0.3, -1.2, -3.10, -0.5, 1.2, 0.2], (N, 1)) + rs.uniform(-0.02, 0.02, (N, 6))
+    v = np.tile([0.0, 0.0, -1.0, 0.0, 0.0, 0.0], (N, 1)) + rs.uniform(-0.2, 0.2, (N, 6))
+    st = venv.get_state().cpu().numpy()
+    st[0:6], st[6:12], st[16] = q.T, v.T, 0.0
+    venv.set_state(torch.from_numpy(st))
+    ob.set_robot_state(q, v)
+    act = np.tile([0.0, -0.45, 0.3], (N, 1))
+    rows_steps = 0
+    for t in range(16):
+        venv.step(torch.from_numpy(act))
+        o = ob.step(act)
+        g = _gpu_result(venv)
+        np.testing.assert_allclose(g["obs"], o["obs"], rtol=0, atol=1e-6, err_msg=f"step {t}")
+        np.testing.assert_allclose(g["reward"], o["reward"], rtol=0, atol=1e-6)
+        assert np.array_equal(g["step_type"], o["step_type"]) and not (g["fault"] & 1).any()
+        rows_steps += int((g["fault"] & 4).all())
+    assert rows_steps >= 6, "the limit rows were not persistently active"
+    elbow = g["obs"][:, 5]
+    assert (elbow < -3.13).all() and (elbow > -3.16).all()  # held at the (soft) lower limit of -3.1415
+    venv.close()
+
+
+def test_device_ik_matches_oracle_on_random_inputs(oracle_mod):
+    """ur5e.inverse_kinematics_closest (robot.py:33-37): the device implementation (guess-branch
+    first, pruned, shared intermediates) picks the same solution as the oracle's exhaustive loop on
+    20k random reachable poses, with guesses near the generating configuration and unrelated guesses
+    in +-2*pi (2*pi-wrapping of candidates exercised); unreachable poses report failure on both sides."""
+    import ctypes as C
+
+    from mujoco_sim_amd import _native as nat
+
+    L = nat.lib()
+    rs = np.random.RandomState(0)
+    n = 20000
+    qgen = rs.uniform(-3.1, 3.1, (n, 6))
+    guess = qgen + rs.normal(0, 0.3, (n, 6))
+    guess[n // 2:] = rs.uniform(-6.2, 6.2, (n - n // 2, 6))
+    T = np.stack([oracle_mod.ur5e_fk_dh(q) for q in qgen])
+    T[-50:, :3, 3] *= 3.0  # out of reach
+    T12 = np.concatenate([T[:, :3, :3].reshape(n, 9), T[:, :3, 3]], axis=1)
+    Td, gd = torch.from_numpy(T12).cuda(), torch.from_numpy(guess).cuda()
+    qd = torch.zeros(n, 6, dtype=torch.float64, device="cuda")
+    ok = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    assert L.mjs_debug_ur5e_ik(C.c_void_p(Td.data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(qd.data_ptr()), C.c_void_p(ok.data_ptr()), n, None) == 0
+    torch.cuda.synchronize()
+    qg, okh = qd.cpu().numpy(), ok.cpu().numpy()
+    n_fail = 0
+    for i in range(n):
+        qo = oracle_mod.ur5e_ik_closest(T[i], guess[i])
+        if qo is None:
+            assert okh[i] == 0
+            n_fail += 1
+        else:
+            assert okh[i] == 1 and np.abs(qg[i] - qo).max() < 1e-7, (i, qg[i], qo)
+    assert n_fail >= 40

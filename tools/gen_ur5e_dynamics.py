@@ -380,6 +380,50 @@ def emit(outputs):
     return lines, counts
 
 
+def evaluate(vals, env):
+    """numeric evaluation of graph values with symbol bindings env (name -> float)"""
+    memo = {}
+
+    def ev(k):
+        if k in memo:
+            return memo[k]
+        op, a, b = G.nodes[k]
+        if op == "sym":
+            r = env[a]
+        elif op == "add":
+            r = ev(a) + ev(b)
+        elif op == "sub":
+            r = ev(a) - ev(b)
+        elif op == "mul":
+            r = ev(a) * ev(b)
+        elif op == "mulc":
+            r = ev(a) * b
+        else:
+            r = ev(a) + b
+        memo[k] = r
+        return r
+
+    return [v.c if v.is_const else v.sign * ev(v.id) for v in vals]
+
+
+def model_constants(M):
+    """mj_setConst quantities at qpos0 = 0: dof_invweight0 = diag(M^-1), meaninertia = mean(diag M)"""
+    import numpy as np
+
+    env = {f"c[{j}]": 1.0 for j in range(NJ)}
+    env.update({f"s[{j}]": 0.0 for j in range(NJ)})
+    env.update({f"qd[{j}]": 0.0 for j in range(NJ)})
+    flat = evaluate([M[i][j] for i in range(NJ) for j in range(i + 1)], env)
+    A = np.zeros((NJ, NJ))
+    k = 0
+    for i in range(NJ):
+        for j in range(i + 1):
+            A[i, j] = A[j, i] = flat[k]
+            k += 1
+    A += np.eye(NJ) * spec_scalar("MJS_UR_ARMATURE")
+    return np.diag(np.linalg.inv(A)), float(np.trace(A) / NJ)
+
+
 def main():
     tau, M = build()
     out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
@@ -387,6 +431,8 @@ def main():
     lb, cb = emit(out_bias)
     lm, cm = emit(out_M)
     nb, nm = sum(cb.values()), sum(cm.values())
+    invw_arr, meaninertia = model_constants(M)
+    invw = ", ".join(repr(float(x)) for x in invw_arr)
     header = f"""// mjs_ur5e_dyn_gen.h — GENERATED by tools/gen_ur5e_dynamics.py from include/mjs_scene_spec.h.
 // DO NOT EDIT. Straight-line float64 code for the UR5e (+ lumped gripper payload, D-1):
 //   ur5e_M_gen:    M[21], lower triangle (row-major, M[i*(i+1)/2+j], j<=i) of the joint-space inertia
@@ -402,6 +448,10 @@ def main():
 #ifndef MJS_DEV
 #define MJS_DEV __device__ __forceinline__
 #endif
+
+// mj_setConst quantities of this model at qpos0 = 0 (armature included): used by the joint-limit rows
+constexpr double UR5E_DOF_INVWEIGHT0[6] = {{{invw}}};
+constexpr double UR5E_MEANINERTIA = {meaninertia!r};
 
 MJS_DEV void ur5e_M_gen(const double* c, const double* s, double* M) {{
 """
