@@ -19,7 +19,7 @@ def native():
 
 def test_library_exports_every_declared_symbol(native):
     header = (ROOT / "include" / "mjsim.h").read_text()
-    declared = set(re.findall(r"\b(mjs_[a-z_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(mjs_[a-z0-9_]+)\s*\(", header))
     assert declared == set(native.EXPORTED_SYMBOLS), declared ^ set(native.EXPORTED_SYMBOLS)
     L = C.CDLL(str(native.LIB_PATH))
     for name in sorted(declared):
