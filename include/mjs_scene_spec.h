@@ -218,4 +218,21 @@ MJS_K float MJS_HEADLIGHT_SPECULAR = 0.5f;
 MJS_K float MJS_MATERIAL_SPECULAR = 0.5f;
 MJS_K int   MJS_MATERIAL_SHININESS_POW2 = 6;     /* shininess 0.5 -> GL exponent 64 = 2^6 */
 
+/* Robot scenes appearance. The reference shows the menagerie visual MESHES (absent); the arm is
+ * drawn with its collision proxies (MJS_UR_COL_*) plus two stand-ins (deviation D-6). Colours follow
+ * the menagerie material names (linkgray / urblue / jointgray / black) [MEN]. */
+MJS_K float MJS_RR_FLOOR_RGB[3] = {0.3f, 0.3f, 0.3f};          /* [REF] empty_robot_arena.py:19 */
+MJS_K float MJS_RR_TARGET_RGB[3] = {1.0f, 1.0f, 1.0f};         /* [REF] robot_reach.py:98-105 */
+MJS_K float MJS_RR_TARGET_RADIUS = 0.03f;
+MJS_K float MJS_UR_LINKGRAY[3] = {0.82f, 0.82f, 0.82f};
+MJS_K float MJS_UR_URBLUE[3] = {0.49f, 0.678f, 0.8f};
+MJS_K float MJS_UR_JOINTGRAY[3] = {0.278f, 0.278f, 0.278f};
+MJS_K float MJS_UR_BLACK[3] = {0.033f, 0.033f, 0.033f};
+MJS_K int   MJS_UR_COL_IS_JOINT[MJS_UR_NCOLGEOM] = {1, 1, 0, 1, 0, 1, 1, 1, 0, 0};  /* urblue vs linkgray */
+MJS_K float MJS_UR_BASE_STANDIN[2] = {0.075f, 0.05f};           /* cylinder radius, half-height at z = 0.05 */
+MJS_K float MJS_G2F85_STANDIN_HALF[3] = {0.04f, 0.02f, 0.07f};   /* box in the flange frame, centred at z = 0.07 */
+/* [REF] empty_robot_arena.py:24-26: six positional lights at (x, +-x, 3), x in {-3, 3, 0.5} */
+MJS_K float MJS_RR_LIGHT_POS[6][3] = {{-3.0f, -3.0f, 3.0f}, {-3.0f, 3.0f, 3.0f}, {3.0f, 3.0f, 3.0f},
+                                      {3.0f, -3.0f, 3.0f},  {0.5f, 0.5f, 3.0f},  {0.5f, -0.5f, 3.0f}};
+
 #endif /* MJS_SCENE_SPEC_H */

@@ -13,6 +13,7 @@
 #pragma once
 #include "mjs_kernel_common.h"
 #include "mjs_pointmass.h"
+#include "mjs_reach.h"
 
 namespace rend {
 
@@ -205,6 +206,187 @@ __global__ __launch_bounds__(256) void pointmass_kernel(RenderParams p) {
     const float a = MJS_PM_SPHERE_RGBA[3];
     c = F3{a * sc.x + (1.0f - a) * c.x, a * sc.y + (1.0f - a) * c.y, a * sc.z + (1.0f - a) * c.z};
   }
+  uint8_t* o = p.out + ((size_t)env * p.H * p.W + pix) * 3;
+  o[0] = to_u8(c.x);
+  o[1] = to_u8(c.y);
+  o[2] = to_u8(c.z);
+}
+
+// ------------------------------------------------------------------------ robot scenes
+// Two stages: (1) one thread per env turns the joint state into a world-space primitive list
+// (float32 records, the arm's collision proxies + stand-ins); (2) one thread per pixel
+// ray-casts that list. Same arithmetic restrictions as above; the only CPU/GPU difference left is
+// the float64 forward kinematics feeding stage 1 (1e-16 before the float32 rounding).
+constexpr int PRIM_FLOATS = 20;
+enum { PRIM_SPHERE = 1, PRIM_CAPSULE = 2, PRIM_CYLINDER = 3, PRIM_BOX = 4 };
+constexpr int RR_NPRIM = MJS_UR_NCOLGEOM + 3;  // proxies + base stand-in + gripper stand-in + target site
+
+MJS_DEV void put3(float* dst, V3 v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; }
+MJS_DEV void put_rgb(float* dst, const float* rgb) { dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2]; }
+
+__global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, float* prims, int N) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  double q[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) q[j] = state[(size_t)(rr::S_Q + j) * N + i];
+  rr::Chain c;
+  rr::fk(q, c);
+  float* out = prims + (size_t)i * RR_NPRIM * PRIM_FLOATS;
+#pragma unroll
+  for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
+    float* pr = out + g * PRIM_FLOATS;
+    const int b = MJS_UR_COL_BODY[g];
+    const M3 R = c.R[b];
+    V3 gp = madd(madd(madd(c.p[b], MJS_UR_COL_POS[g][0], R.cx), MJS_UR_COL_POS[g][1], R.cy), MJS_UR_COL_POS[g][2], R.cz);
+    V3 axis = (MJS_UR_COL_QUAT[g][1] != 0.0) ? -R.cy : R.cz;
+    const double half = MJS_UR_COL_SIZE[g][1];
+    pr[0] = MJS_UR_COL_TYPE[g] == 3 ? (float)PRIM_CAPSULE : (float)PRIM_CYLINDER;
+    put3(pr + 1, madd(gp, -half, axis));
+    put3(pr + 4, madd(gp, half, axis));
+    pr[13] = (float)MJS_UR_COL_SIZE[g][0];
+    put_rgb(pr + 14, MJS_UR_COL_IS_JOINT[g] ? MJS_UR_URBLUE : MJS_UR_LINKGRAY);
+  }
+  {  // base stand-in: vertical cylinder on the floor
+    float* pr = out + MJS_UR_NCOLGEOM * PRIM_FLOATS;
+    pr[0] = (float)PRIM_CYLINDER;
+    put3(pr + 1, v3(0, 0, 0));
+    put3(pr + 4, v3(0, 0, 2.0 * MJS_UR_BASE_STANDIN[1]));
+    pr[13] = MJS_UR_BASE_STANDIN[0];
+    put_rgb(pr + 14, MJS_UR_JOINTGRAY);
+  }
+  {  // gripper stand-in: box in the flange frame (x = wrist_3 x, y = -wrist_3 z, z = wrist_3 y)
+    float* pr = out + (MJS_UR_NCOLGEOM + 1) * PRIM_FLOATS;
+    const M3 R = c.R[6];
+    V3 centre = madd(c.p[6], MJS_UR_FLANGE_POS[1] + (double)MJS_G2F85_STANDIN_HALF[2], R.cy);
+    pr[0] = (float)PRIM_BOX;
+    put3(pr + 1, centre);
+    put3(pr + 4, R.cx);   // box axis u (half[0])
+    put3(pr + 7, -R.cz);  // box axis v (half[1]); w = u x v = flange z (half[2])
+    pr[10] = MJS_G2F85_STANDIN_HALF[0]; pr[11] = MJS_G2F85_STANDIN_HALF[1]; pr[12] = MJS_G2F85_STANDIN_HALF[2];
+    put_rgb(pr + 14, MJS_UR_BLACK);
+  }
+  {  // target site
+    float* pr = out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS;
+    pr[0] = (float)PRIM_SPHERE;
+    pr[1] = (float)state[(size_t)(rr::S_TARGET + 0) * N + i];
+    pr[2] = (float)state[(size_t)(rr::S_TARGET + 1) * N + i];
+    pr[3] = (float)state[(size_t)(rr::S_TARGET + 2) * N + i];
+    pr[13] = MJS_RR_TARGET_RADIUS;
+    put_rgb(pr + 14, MJS_RR_TARGET_RGB);
+  }
+}
+
+// capsule / capped cylinder between pa and pb (closed-form ray tests)
+MJS_DEV void hit_capsule(F3 o, F3 d, F3 pa, F3 pb, float r, F3 rgb, Surf& s) {
+  F3 ba = sub(pb, pa), oa = sub(o, pa);
+  float baba = dotf(ba, ba), bard = dotf(ba, d), baoa = dotf(ba, oa), rdoa = dotf(d, oa), oaoa = dotf(oa, oa);
+  float a = baba - bard * bard, b = baba * rdoa - baoa * bard, c = baba * oaoa - baoa * baoa - r * r * baba;
+  float h = b * b - a * c;
+  if (h < 0.0f) return;
+  if (a > 0.0f) {
+    float t = (-b - sqrtf(h)) / a;
+    float y = baoa + t * bard;
+    if (y > 0.0f && y < baba) {
+      if (!(t > 0.0f) || !(t < s.t)) return;
+      s.t = t;
+      F3 pn = sub(add(oa, mul(t, d)), mul(y / baba, ba));
+      s.n = mul(1.0f / r, pn);
+      s.rgb = rgb;
+      return;
+    }
+    // end caps
+    F3 oc = y <= 0.0f ? oa : sub(o, pb);
+    float bb = dotf(d, oc), cc = dotf(oc, oc) - r * r;
+    float hh = bb * bb - cc;
+    if (hh > 0.0f) {
+      float tc = -bb - sqrtf(hh);
+      if (!(tc > 0.0f) || !(tc < s.t)) return;
+      s.t = tc;
+      s.n = mul(1.0f / r, add(oc, mul(tc, d)));
+      s.rgb = rgb;
+    }
+  }
+}
+MJS_DEV void hit_cylinder(F3 o, F3 d, F3 pa, F3 pb, float r, F3 rgb, Surf& s) {
+  F3 ba = sub(pb, pa), oa = sub(o, pa);
+  float baba = dotf(ba, ba), bard = dotf(ba, d), baoa = dotf(ba, oa);
+  float k2 = baba - bard * bard, k1 = baba * dotf(oa, d) - baoa * bard, k0 = baba * dotf(oa, oa) - baoa * baoa - r * r * baba;
+  float h = k1 * k1 - k2 * k0;
+  if (h < 0.0f) return;
+  if (k2 > 0.0f) {
+    float t = (-k1 - sqrtf(h)) / k2;
+    float y = baoa + t * bard;
+    if (y > 0.0f && y < baba) {
+      if (!(t > 0.0f) || !(t < s.t)) return;
+      s.t = t;
+      s.n = mul(1.0f / r, sub(add(oa, mul(t, d)), mul(y / baba, ba)));
+      s.rgb = rgb;
+      return;
+    }
+  }
+  // caps
+  if (bard == 0.0f) return;
+  float tc = ((bard < 0.0f ? baba : 0.0f) - baoa) / bard;  // the cap facing the ray
+  if (!(tc > 0.0f) || !(tc < s.t)) return;
+  F3 q = add(oa, mul(tc, d));
+  float yc = bard < 0.0f ? baba : 0.0f;
+  F3 radial = sub(q, mul(yc / baba, ba));
+  if (dotf(radial, radial) > r * r) return;
+  s.t = tc;
+  float inv = 1.0f / sqrtf(baba);
+  s.n = mul(bard < 0.0f ? inv : -inv, ba);
+  s.rgb = rgb;
+}
+MJS_DEV void hit_obb(F3 o, F3 d, F3 c, F3 u, F3 v, F3 half, F3 rgb, Surf& s) {
+  F3 w = F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+  F3 oc = sub(o, c);
+  const float oo[3] = {dotf(oc, u), dotf(oc, v), dotf(oc, w)}, dd[3] = {dotf(d, u), dotf(d, v), dotf(d, w)}, hh[3] = {half.x, half.y, half.z};
+  float tmin = 0.0f, tmax = s.t, sg = 0.0f;
+  int ax = -1;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    if (dd[k] == 0.0f) {
+      if (oo[k] < -hh[k] || oo[k] > hh[k]) return;
+      continue;
+    }
+    float t1 = (-hh[k] - oo[k]) / dd[k], t2 = (hh[k] - oo[k]) / dd[k], sgn = -1.0f;
+    if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; sgn = 1.0f; }
+    if (t1 > tmin) { tmin = t1; ax = k; sg = sgn; }
+    if (t2 < tmax) tmax = t2;
+    if (tmin > tmax) return;
+  }
+  if (ax < 0 || !(tmin > 0.0f) || !(tmin < s.t)) return;
+  s.t = tmin;
+  s.n = mul(sg, ax == 0 ? u : ax == 1 ? v : w);
+  s.rgb = rgb;
+}
+
+__global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const float* prims) {
+  const int env = blockIdx.y;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= p.H * p.W) return;
+  const int row = pix / p.W, col = pix - row * p.W;
+  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+  const F3 d = pixel_ray(p, row, col);
+  Surf s;
+  s.t = INFINITY;
+  s.n = f3(0, 0, 1);
+  s.rgb = f3(0, 0, 0);
+  hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+  const float* pe = prims + (size_t)env * RR_NPRIM * PRIM_FLOATS;
+#pragma unroll 1
+  for (int k = 0; k < RR_NPRIM; k++) {
+    const float* pr = pe + k * PRIM_FLOATS;
+    const int type = (int)pr[0];
+    const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]), rgb = f3(pr[14], pr[15], pr[16]);
+    if (type == PRIM_SPHERE) hit_sphere(eye, d, p0, pr[13], rgb, s);
+    else if (type == PRIM_CAPSULE) hit_capsule(eye, d, p0, p1, pr[13], rgb, s);
+    else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
+    else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
+  }
+  F3 c = f3(0, 0, 0);
+  if (s.t < INFINITY) c = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
   uint8_t* o = p.out + ((size_t)env * p.H * p.W + pix) * 3;
   o[0] = to_u8(c.x);
   o[1] = to_u8(c.y);

@@ -58,6 +58,7 @@ class RobotReachTask:
         self.control_timestep = self.config.control_timestep
         self.reward_type = self.config.reward_type
         self.observation_type = self.config.observation_type
+        self.image_resolution = self.config.image_resolution
         if self.config.action_type != RobotReachConfig.ABS_EEF_ACTION:
             # the reference's before_step only implements the absolute-EEF path (robot_reach.py:159-169)
             raise NotImplementedError("only ABS_EEF_ACTION is implemented (as in the reference)")

@@ -130,14 +130,13 @@ class HipVectorEnv:
         self.image_resolution = int(image_resolution)
         self._img = None
         if observation_type == VISUAL_OBS:
-            if task != "point_mass_reach":
-                raise NotImplementedError("visual observations are built for the Pointmass scene only so far")
             r = self.image_resolution
             self._img = torch.zeros(N, r, r, 3, dtype=torch.uint8, device=dev)
-            self._visual_keys = ("pointmass/position",)
-            self.single_observation_space = Dict(OrderedDict(
-                [("pointmass/position", Box(-np.inf, np.inf, shape=(2,), dtype=np.float64)),
-                 ("Camera/rgb_image", Box(0, 255, shape=(r, r, 3), dtype=np.uint8))]))
+            # point_reach.py:119-121 / robot_reach.py:139-141: proprioception + scene camera image
+            self._visual_keys = ("pointmass/position",) if task == "point_mass_reach" else ("ur5e/tcp_position",)
+            spaces = [(k, Box(-np.inf, np.inf, shape=(n,), dtype=np.float64)) for k, _, n in self.spec.obs_layout if k in self._visual_keys]
+            spaces.append(("Camera/rgb_image", Box(0, 255, shape=(r, r, 3), dtype=np.uint8)))
+            self.single_observation_space = Dict(OrderedDict(spaces))
             self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
         if seed is not None:
             self.seed(seed)

@@ -150,3 +150,135 @@ void om_render_pointmass(const om_env* e, int H, int W, uint8_t* out) {
       o[0] = to_u8(c.x); o[1] = to_u8(c.y); o[2] = to_u8(c.z);
     }
 }
+
+/* ------------------------------------------------------------------ robot scenes */
+static void capsule(v3 o, v3 d, v3 pa, v3 pb, float r, v3 rgb, surf* s) {
+  v3 ba = vsub(pb, pa), oa = vsub(o, pa);
+  float baba = vdot(ba, ba), bard = vdot(ba, d), baoa = vdot(ba, oa), rdoa = vdot(d, oa), oaoa = vdot(oa, oa);
+  float a = baba - bard * bard, b = baba * rdoa - baoa * bard, c = baba * oaoa - baoa * baoa - r * r * baba;
+  float h = b * b - a * c;
+  if (h < 0.0f) return;
+  if (a > 0.0f) {
+    float t = (-b - sqrtf(h)) / a;
+    float y = baoa + t * bard;
+    if (y > 0.0f && y < baba) {
+      if (!(t > 0.0f) || !(t < s->t)) return;
+      s->t = t;
+      s->n = vmul(1.0f / r, vsub(vadd(oa, vmul(t, d)), vmul(y / baba, ba)));
+      s->rgb = rgb;
+      return;
+    }
+    v3 oc = y <= 0.0f ? oa : vsub(o, pb);
+    float bb = vdot(d, oc), cc = vdot(oc, oc) - r * r;
+    float hh = bb * bb - cc;
+    if (hh > 0.0f) {
+      float tc = -bb - sqrtf(hh);
+      if (!(tc > 0.0f) || !(tc < s->t)) return;
+      s->t = tc;
+      s->n = vmul(1.0f / r, vadd(oc, vmul(tc, d)));
+      s->rgb = rgb;
+    }
+  }
+}
+static void cylinder(v3 o, v3 d, v3 pa, v3 pb, float r, v3 rgb, surf* s) {
+  v3 ba = vsub(pb, pa), oa = vsub(o, pa);
+  float baba = vdot(ba, ba), bard = vdot(ba, d), baoa = vdot(ba, oa);
+  float k2 = baba - bard * bard, k1 = baba * vdot(oa, d) - baoa * bard, k0 = baba * vdot(oa, oa) - baoa * baoa - r * r * baba;
+  float h = k1 * k1 - k2 * k0;
+  if (h < 0.0f) return;
+  if (k2 > 0.0f) {
+    float t = (-k1 - sqrtf(h)) / k2;
+    float y = baoa + t * bard;
+    if (y > 0.0f && y < baba) {
+      if (!(t > 0.0f) || !(t < s->t)) return;
+      s->t = t;
+      s->n = vmul(1.0f / r, vsub(vadd(oa, vmul(t, d)), vmul(y / baba, ba)));
+      s->rgb = rgb;
+      return;
+    }
+  }
+  if (bard == 0.0f) return;
+  float tc = ((bard < 0.0f ? baba : 0.0f) - baoa) / bard;
+  if (!(tc > 0.0f) || !(tc < s->t)) return;
+  v3 q = vadd(oa, vmul(tc, d));
+  float yc = bard < 0.0f ? baba : 0.0f;
+  v3 radial = vsub(q, vmul(yc / baba, ba));
+  if (vdot(radial, radial) > r * r) return;
+  s->t = tc;
+  float inv = 1.0f / sqrtf(baba);
+  s->n = vmul(bard < 0.0f ? inv : -inv, ba);
+  s->rgb = rgb;
+}
+static void obb(v3 o, v3 d, v3 c, v3 u, v3 v, v3 half, v3 rgb, surf* s) {
+  v3 w = V(u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x);
+  v3 oc = vsub(o, c);
+  float oo[3] = {vdot(oc, u), vdot(oc, v), vdot(oc, w)}, dd[3] = {vdot(d, u), vdot(d, v), vdot(d, w)}, hh[3] = {half.x, half.y, half.z};
+  float tmin = 0.0f, tmax = s->t, sg = 0.0f;
+  int ax = -1;
+  for (int k = 0; k < 3; k++) {
+    if (dd[k] == 0.0f) { if (oo[k] < -hh[k] || oo[k] > hh[k]) return; continue; }
+    float t1 = (-hh[k] - oo[k]) / dd[k], t2 = (hh[k] - oo[k]) / dd[k], sgn = -1.0f;
+    if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; sgn = 1.0f; }
+    if (t1 > tmin) { tmin = t1; ax = k; sg = sgn; }
+    if (t2 < tmax) tmax = t2;
+    if (tmin > tmax) return;
+  }
+  if (ax < 0 || !(tmin > 0.0f) || !(tmin < s->t)) return;
+  s->t = tmin;
+  s->n = vmul(sg, ax == 0 ? u : ax == 1 ? v : w);
+  s->rgb = rgb;
+}
+static v3 Vd(const double* p) { return V((float)p[0], (float)p[1], (float)p[2]); }
+
+/* scene camera image of a Robot-Reach env (robot_reach.py:52 camera; arm drawn by its collision
+ * proxies + stand-ins): out uint8 [H, W, 3] */
+void om_render_robot(const om_env* e, int H, int W, uint8_t* out) {
+  const om_model* m = &e->m;
+  const om_data* dd = &e->d;
+  const double* q = MJS_RR_CAM_QUAT;
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
+                 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  float right[3], up[3], back[3];
+  for (int k = 0; k < 3; k++) { right[k] = (float)R[3 * k]; up[k] = (float)R[3 * k + 1]; back[k] = (float)R[3 * k + 2]; }
+  float tan_half = (float)tan(MJS_RR_CAM_FOVY * 3.14159265358979323846 / 360.0);
+  v3 eye = Vd(MJS_RR_CAM_POS);
+  /* primitive list, float32 */
+  v3 cap_a[MJS_UR_NCOLGEOM], cap_b[MJS_UR_NCOLGEOM];
+  for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
+    const double* gp = dd->geom_xpos[1 + g];
+    const double* gm = dd->geom_xmat[1 + g];
+    double half = m->geom_size[1 + g][1], a[3], b[3];
+    for (int k = 0; k < 3; k++) { a[k] = gp[k] + -half * gm[3 * k + 2]; b[k] = gp[k] + half * gm[3 * k + 2]; }
+    cap_a[g] = Vd(a); cap_b[g] = Vd(b);
+  }
+  const double* sp = dd->site_xpos[0];
+  const double* sm = dd->site_xmat[0];
+  double bc[3], bu[3], bv[3];
+  for (int k = 0; k < 3; k++) { bc[k] = sp[k] + (double)MJS_G2F85_STANDIN_HALF[2] * sm[3 * k + 2]; bu[k] = sm[3 * k]; bv[k] = sm[3 * k + 1]; }
+  v3 box_c = Vd(bc), box_u = Vd(bu), box_v = Vd(bv);
+  v3 tgt = Vd(e->target_pos);
+  float aspect = (float)W / (float)H;
+  for (int row = 0; row < H; row++)
+    for (int col = 0; col < W; col++) {
+      float px = (2.0f * ((float)col + 0.5f) / (float)W - 1.0f) * tan_half * aspect;
+      float py = (1.0f - 2.0f * ((float)row + 0.5f) / (float)H) * tan_half;
+      v3 d = vnorm(V(px * right[0] + py * up[0] - back[0], px * right[1] + py * up[1] - back[1], px * right[2] + py * up[2] - back[2]));
+      surf s;
+      s.t = INFINITY; s.n = V(0, 0, 1); s.rgb = V(0, 0, 0);
+      rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, V(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), 0, &s);
+      for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
+        const float* c = MJS_UR_COL_IS_JOINT[g] ? MJS_UR_URBLUE : MJS_UR_LINKGRAY;
+        if (MJS_UR_COL_TYPE[g] == 3) capsule(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
+        else cylinder(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
+      }
+      cylinder(eye, d, V(0, 0, 0), V(0, 0, (float)(2.0 * MJS_UR_BASE_STANDIN[1])), MJS_UR_BASE_STANDIN[0], V(MJS_UR_JOINTGRAY[0], MJS_UR_JOINTGRAY[1], MJS_UR_JOINTGRAY[2]), &s);
+      obb(eye, d, box_c, box_u, box_v, V(MJS_G2F85_STANDIN_HALF[0], MJS_G2F85_STANDIN_HALF[1], MJS_G2F85_STANDIN_HALF[2]), V(MJS_UR_BLACK[0], MJS_UR_BLACK[1], MJS_UR_BLACK[2]), &s);
+      sphere(eye, d, tgt, MJS_RR_TARGET_RADIUS, V(MJS_RR_TARGET_RGB[0], MJS_RR_TARGET_RGB[1], MJS_RR_TARGET_RGB[2]), &s);
+      v3 c = V(0, 0, 0);
+      if (s.t < INFINITY) c = shade(vadd(eye, vmul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS, 6);
+      uint8_t* o = out + ((size_t)row * W + col) * 3;
+      o[0] = to_u8(c.x); o[1] = to_u8(c.y); o[2] = to_u8(c.z);
+    }
+}

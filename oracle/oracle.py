@@ -88,6 +88,7 @@ def lib() -> C.CDLL:
         L.om_batch_step.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.om_env_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.om_render_pointmass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.om_render_robot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.om_rng_seed.argtypes = [C.POINTER(_Rng), C.c_uint32]
         L.om_rng_uniform.argtypes = [C.POINTER(_Rng), C.c_double, C.c_double]
         L.om_rng_uniform.restype = C.c_double
@@ -206,11 +207,11 @@ class OracleBatch:
             L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
 
     def render(self, height: int, width: int) -> np.ndarray:
-        """scene-camera images of all envs: uint8 [N, H, W, 3] (Pointmass scene only so far)"""
-        assert self.task == TASK_POINTMASS
+        """scene-camera images of all envs: uint8 [N, H, W, 3]"""
+        fn = lib().om_render_pointmass if self.task == TASK_POINTMASS else lib().om_render_robot
         img = np.zeros((self.n, height, width, 3), dtype=np.uint8)
         for i in range(self.n):
-            lib().om_render_pointmass(lib().om_batch_env(self._h, i), height, width, img[i].ctypes.data)
+            fn(lib().om_batch_env(self._h, i), height, width, img[i].ctypes.data)
         return img
 
     def close(self):

@@ -238,3 +238,29 @@ def test_oracle_render_camera_model(oracle_mod):
     assert (img[0, 0] == 0).all() and (img[127, 127] == 0).all()  # beyond the arena: nothing
     centre = img[60:68, 60:68].reshape(-1, 3).astype(int)
     assert (centre[:, 2] > centre[:, 0]).all()  # bluish checker floor
+
+
+def test_oracle_render_robot_scene(oracle_mod):
+    """Robot-Reach scene camera (robot_reach.py:52: pos (0,-1.1,0.5), quat (-0.7,-0.35,0,0), fovy 70):
+    the white target site and the black gripper stand-in project where the state says."""
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, 1, 2025)
+    obs = b.reset()["obs"][0]
+    H = 160
+    img = b.render(H, H)[0]
+    q = np.array([-0.7, -0.35, 0.0, 0.0]); q /= np.linalg.norm(q)
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    f = 0.5 * H / np.tan(np.radians(35.0))
+
+    def pix(p):
+        pc = R.T @ (np.asarray(p) - np.array([0.0, -1.1, 0.5]))  # camera frame: looks along -z
+        return int(H / 2 - f * pc[1] / -pc[2]), int(H / 2 + f * pc[0] / -pc[2])
+
+    r, c = pix(obs[9:12])
+    assert (img[r, c] > 150).all(), img[r, c]  # white target sphere
+    tcp = obs[0:3]
+    r, c = pix(tcp + np.array([0.0, 0.0, 0.08]))  # inside the gripper stand-in, above the TCP (tool points down)
+    assert (img[r, c] < 40).all(), img[r, c]
+    assert (img[H - 1, 0] > 30).all() and abs(int(img[H - 1, 0, 0]) - int(img[H - 1, 0, 2])) < 3  # grey floor
