@@ -186,6 +186,38 @@ MJS_K double MJS_RR_TARGET_DEFAULT_POS[3] = {0.0, -0.5, 0.001};
 MJS_K double MJS_TOP_DOWN_QUAT_XYZW[4] = {1.0, 0.0, 0.0, 0.0};
 MJS_K double MJS_ROBOT_ARENA_HALF = 1.5;       /* EmptyRobotArena(3), empty_robot_arena.py:18-20 */
 
+/* ------------------------------------------------ Robot Button-Push [REF] */
+/* environments/tasks/robot_push_button.py:35-43,76-79,108 */
+MJS_K double MJS_BP_GOAL_THRESHOLD = 0.05;
+MJS_K int    MJS_BP_MAX_CONTROL_STEPS = 100;
+MJS_K double MJS_BP_ROBOT_SPACE_LO[3] = {-0.2, -0.6, 0.02};
+MJS_K double MJS_BP_ROBOT_SPACE_HI[3] = {0.2, -0.3, 0.3};
+MJS_K double MJS_BP_SWITCH_SPACE_LO[3] = {-0.2, -0.6, 0.0};
+MJS_K double MJS_BP_SWITCH_SPACE_HI[3] = {0.2, -0.3, 0.1};
+MJS_K double MJS_BP_ROBOT_END_POS[3] = {-0.3, -0.2, 0.3};
+/* entities/props/switch.py:10-41,51-60,86-87 */
+MJS_K double MJS_SW_BOX_HALF = 0.025;          /* box 0.05^3 centred at z = 0.025 */
+MJS_K double MJS_SW_BUTTON_RADIUS = 0.02;      /* cylinder size [0.02, 0.02, 0.01]: radius, half-height */
+MJS_K double MJS_SW_BUTTON_HALF = 0.02;
+MJS_K double MJS_SW_BUTTON_Z = 0.05;
+MJS_K double MJS_SW_SITE_SCALE = 1.01;
+MJS_K double MJS_SW_MIN_FORCE = 5.0;
+MJS_K double MJS_SW_MAX_FORCE = 200.0;
+MJS_K double MJS_SW_POSITION_OFFSET = 0.01;    /* get_position: xpos + 0.5*size[1], added to all 3 coordinates */
+/* wrist camera entity attached at the flange (robot_push_button.py:53-54,90-96; entities/camera.py:78-88):
+ * a box (half 0.045,0.0125,0.0125) and a sphere (r 0.0125) at `pos` in the flange frame, default density */
+MJS_K double MJS_WCAM_POS[3] = {0.0, 0.05, 0.0};
+MJS_K double MJS_WCAM_QUAT[4] = {0.0, 0.0, 0.999, 0.04};
+MJS_K double MJS_WCAM_FOVY = 42.0;
+MJS_K double MJS_CAM_BOX_HALF[3] = {0.045, 0.0125, 0.0125};
+MJS_K double MJS_CAM_SPHERE_RADIUS = 0.0125;
+MJS_K double MJS_BP_CAM_POS[3] = {0.0, -1.7, 0.7};             /* scene camera, robot_push_button.py:51-52 */
+MJS_K double MJS_BP_CAM_QUAT[4] = {-0.7, -0.35, 0.0, 0.0};
+MJS_K double MJS_BP_CAM_FOVY = 70.0;
+/* collision stand-in for the CLOSED 2F-85 finger tips (deviation D-1): a sphere whose lowest point is
+ * the TCP, on the lumped gripper body. Own choice, not in the reference. */
+MJS_K double MJS_G2F85_PROXY_RADIUS = 0.012;
+
 /* --------------------------------------------------- rendering (a15) */
 /* Fixed cameras [REF]: MuJoCo camera convention = looks along its local -z, +x right, +y up;
  * quaternions (w,x,y,z) as written in the task code; fovy in degrees. */

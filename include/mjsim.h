@@ -25,7 +25,15 @@ extern "C" {
 #define MJS_ABI_VERSION 1
 
 /* tasks (environments/tasks/*.py) */
-enum { MJS_TASK_POINTMASS_REACH = 0, MJS_TASK_ROBOT_REACH = 1 };
+enum {
+  MJS_TASK_POINTMASS_REACH = 0, /* tasks/point_reach.py */
+  MJS_TASK_ROBOT_REACH = 1,     /* tasks/robot_reach.py */
+  MJS_TASK_PLANAR_PUSH = 2,     /* tasks/robot_planar_push.py: id reserved, mjs_create returns MJS_ERR_UNSUPPORTED */
+  MJS_TASK_BUTTON_PUSH = 3      /* tasks/robot_push_button.py */
+};
+/* Button-Push action spaces (robot_push_button.py:35-36,143-157): absolute joints + gripper (7-D, the
+ * registered default) or absolute TCP position + gripper (4-D). Other tasks ignore the field. */
+enum { MJS_ACTION_ABS_JOINT = 0, MJS_ACTION_ABS_EEF = 1 };
 /* reward types: point_reach.py:11-14, robot_reach.py:37-38 */
 enum { MJS_REW_SPARSE = 0, MJS_REW_DENSE_POTENTIAL = 1, MJS_REW_DENSE_NEG_DISTANCE = 2, MJS_REW_DENSE_BIASED_NEG_DISTANCE = 3 };
 /* dm_env StepType as produced by composer.Environment (dmc2gym.py:144-145 reads .last()) */
@@ -60,6 +68,8 @@ typedef struct {
   int32_t env_index_offset;     /* global index of local env 0 (multi-GPU shards keep global seeds) */
   int32_t kernel_variant;       /* MJS_VARIANT_*: 0 = default (tuned); others for A/B profiling */
   double time_limit;            /* composer.Environment(time_limit=...) (__init__.py:21); <=0 = task default */
+  int32_t action_type;          /* MJS_ACTION_* (Button-Push only) */
+  int32_t reserved0;            /* must be 0 */
 } mjs_config;
 
 /* Per-step outputs. Device pointers, caller-owned, any may be NULL.
@@ -83,10 +93,14 @@ typedef struct {
 const char* mjs_version(void);
 /* flat observation width: Pointmass {pointmass/position(2), goal_position(2)} (point_reach.py:115-118);
  * Robot-Reach {ur5e/tcp_position(3), ur5e/joint_configuration(6), target_position(3)}
- * (robot_reach.py:134-137, robot.py:292-298) */
+ * (robot_reach.py:134-137, robot.py:292-298); Button-Push {ur5e/joint_configuration(6),
+ * ur5e/tcp_position(3), switch/position(3), switch/active(1)} (robot_push_button.py:113-119, switch.py:99-108) */
 int mjs_obs_dim(int task);
-/* action width: 2 (point_reach.py:204-209) / 3 (robot_reach.py:187-201) */
+/* action width: 2 (point_reach.py:204-209) / 3 (robot_reach.py:187-201) / Button-Push default 7
+ * (robot_push_button.py:181-203) */
 int mjs_action_dim(int task);
+/* action width for a task + MJS_ACTION_* pair (Button-Push: 7 or 4); equals mjs_action_dim otherwise */
+int mjs_action_dim_for(int task, int action_type);
 /* number of float64 per env in mjs_get_state / mjs_set_state */
 int mjs_state_dim(int task);
 /* algorithmic HBM bytes one env-step moves (state R+W, action, outputs), from the real layout */

@@ -16,14 +16,15 @@ _ROOT = _PKG.parent
 LIB_PATH = Path(os.environ["MJS_LIB"]) if os.environ.get("MJS_LIB") else _PKG / "lib" / "libmjsim.so"  # MJS_LIB: diagnostic builds
 _SOURCES = [*sorted((_PKG / "csrc").glob("*")), _ROOT / "include" / "mjsim.h", _ROOT / "include" / "mjs_scene_spec.h"]
 
-TASK_POINTMASS_REACH, TASK_ROBOT_REACH = 0, 1
+TASK_POINTMASS_REACH, TASK_ROBOT_REACH, TASK_PLANAR_PUSH, TASK_BUTTON_PUSH = 0, 1, 2, 3
+ACTION_ABS_JOINT, ACTION_ABS_EEF = 0, 1
 REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DISTANCE = 0, 1, 2, 3
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
 
 EXPORTED_SYMBOLS = [
-    "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
+    "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_action_dim_for", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
     "mjs_create", "mjs_destroy", "mjs_last_error", "mjs_seed", "mjs_reset", "mjs_step", "mjs_rollout",
     "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik",
 ]
@@ -33,7 +34,7 @@ class MjsConfig(C.Structure):
     _fields_ = [
         ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
-        ("kernel_variant", C.c_int32), ("time_limit", C.c_double),
+        ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -85,6 +86,8 @@ def lib() -> C.CDLL:
     for name in ("mjs_obs_dim", "mjs_action_dim", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps"):
         getattr(L, name).argtypes = [C.c_int]
         getattr(L, name).restype = C.c_int
+    L.mjs_action_dim_for.argtypes = [C.c_int, C.c_int]
+    L.mjs_action_dim_for.restype = C.c_int
     L.mjs_create.argtypes = [C.POINTER(MjsConfig), C.POINTER(C.c_void_p)]
     L.mjs_destroy.argtypes = [C.c_void_p]
     L.mjs_destroy.restype = None

@@ -1,0 +1,494 @@
+// mjs_button.h — Robot Button-Push fused control-step kernel (BASELINE config 5, physics + task
+// logic; the cameras are in mjs_render.h).
+//
+// Path replaced (reference, paths under /root/reference/mujoco_sim/):
+//   environments/tasks/robot_push_button.py:143-157 before_step: gripper.move + servoJ (7-D absolute
+//       joint action, the registered default) or servoL (4-D absolute EEF action)
+//   per substep: entities/robots/robot.py:261-263 servo interpolation, Physics.step() on the scene of
+//       robot_push_button.py:66-108 (UR5e + gripper + wrist camera + static switch), then
+//       entities/props/switch.py:51-60,71-72 Switch._update_activation on the touch sensor
+//   robot_push_button.py:167-170,205-219 reward / goal / termination / discount,
+//   robot_push_button.py:126-134 + switch.py:62-65 initialize_episode (6 uniforms + IK + switch pose)
+// Deviation D-1 applies: the 2F-85 is a rigid lump; its CLOSED finger tips are represented by one
+// collision sphere whose lowest point is the TCP (include/mjs_scene_spec.h MJS_G2F85_PROXY_RADIUS), so
+// the contacts that exist are sphere-floor, sphere-switch box and sphere-button cylinder, pyramidal
+// condim 3. One wavefront per 64 envs (lane per env); the contact / joint-limit rows go through a
+// generic in-lane primal Newton solver that is only entered by lanes that have active rows.
+#pragma once
+#include "mjs_kernel_common.h"
+#include "mjs_reach.h"
+
+namespace bp {
+
+using rr::NJ;
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, STATE_DIM = 16;
+constexpr int OBS_DIM = 13, ACT_DIM_JOINT = 7, ACT_DIM_EEF = 4;
+enum { FLAG_SWITCH_ACTIVE = 4, FLAG_SWITCH_PRESSED = 8 };
+constexpr int MAXROW = 24;  // 12 joint-limit slots + 3 contacts x 4 pyramid edges
+
+// ---------------------------------------------------------------- generic small Newton (nv = 6)
+// rows: J [nrow][6], D, aref; all rows are inequality rows (limits, contacts). Cold start at
+// qacc_smooth. Mirrors oracle/om_engine.c om_solve_constraint (MuJoCo mj_solPrimal, Newton).
+__device__ __noinline__ void solve_rows(const double (*Mf)[NJ], const double* qfrc_smooth, int nrow, const double (*J)[NJ], const double* D,
+                                        const double* aref, double* force, double* qfrc_constraint) {
+  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], jar[MAXROW], jv[MAXROW];
+  bool active[MAXROW];
+  for (int i = 0; i < NJ; i++) {
+    for (int j = 0; j < NJ; j++) L[i][j] = Mf[i][j];
+    a_s[i] = qfrc_smooth[i];
+  }
+  rr::chol6(L);
+  rr::chol6_solve(L, a_s);
+  for (int i = 0; i < NJ; i++) a[i] = a_s[i];
+  auto refresh = [&]() {
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * a[k];
+      Ma[i] = m;
+    }
+    for (int r = 0; r < nrow; r++) {
+      double x = -aref[r];
+      for (int k = 0; k < NJ; k++) x += J[r][k] * a[k];
+      jar[r] = x;
+    }
+  };
+  auto update = [&]() {
+    double cost = 0;
+    for (int r = 0; r < nrow; r++) {
+      bool act = jar[r] < 0;
+      active[r] = act;
+      force[r] = act ? -D[r] * jar[r] : 0.0;
+      if (act) cost += 0.5 * D[r] * jar[r] * jar[r];
+    }
+    double gauss = 0;
+    for (int i = 0; i < NJ; i++) gauss += (Ma[i] - qfrc_smooth[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+  refresh();
+  double cost = update();
+  const double scale = 1 / (UR5E_BP_MEANINERTIA * NJ);
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[NJ], search[NJ], Mv[NJ], H[NJ][NJ];
+    for (int i = 0; i < NJ; i++) {
+      double g = Ma[i] - qfrc_smooth[i];
+      for (int r = 0; r < nrow; r++) g -= J[r][i] * force[r];
+      grad[i] = g;
+      for (int j = 0; j <= i; j++) {
+        double h = Mf[i][j];
+        for (int r = 0; r < nrow; r++)
+          if (active[r]) h += J[r][i] * D[r] * J[r][j];
+        H[i][j] = h;
+      }
+      search[i] = -g;
+    }
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * search[k];
+      Mv[i] = m;
+    }
+    for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    for (int r = 0; r < nrow; r++) {
+      double x = 0;
+      for (int k = 0; k < NJ; k++) x += J[r][k] * search[k];
+      jv[r] = x;
+    }
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+      for (int r = 0; r < nrow; r++) {
+        double x = jar[r] + alpha * jv[r];
+        if (x < 0) { d1 += D[r] * x * jv[r]; d2 += D[r] * jv[r] * jv[r]; }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+    for (int i = 0; i < NJ; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+    for (int r = 0; r < nrow; r++) jar[r] += alpha * jv[r];
+    double oldcost = cost;
+    cost = update();
+    double gn = 0;
+    for (int i = 0; i < NJ; i++) {
+      double g = Ma[i] - qfrc_smooth[i];
+      for (int r = 0; r < nrow; r++) g -= J[r][i] * force[r];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  for (int i = 0; i < NJ; i++) {
+    double f = 0;
+    for (int r = 0; r < nrow; r++) f += J[r][i] * force[r];
+    qfrc_constraint[i] = f;
+  }
+}
+
+// mju_makeFrame: two tangents for a unit normal
+MJS_DEV void make_frame(V3 n, V3& t1, V3& t2) {
+  V3 y = (n.y > -0.5 && n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
+  double dp = dot(n, y);
+  y = madd(y, -dp, n);
+  double len = sqrt(dot(y, y));
+  t1 = (1.0 / len) * y;
+  t2 = cross(n, t1);
+}
+
+struct ContactSet {
+  int n;             // detected contacts (dist <= 0) of the proxy sphere: floor, switch box, button cylinder
+  double dist[3];
+  V3 pos[3], nrm[3];
+  double sgn[3];     // +1: the sphere is geom2 (plane-sphere), -1: the sphere is geom1
+  bool on_switch[3];
+};
+
+// collision of the gripper stand-in sphere (centre c) with floor, switch box, button cylinder, in the
+// oracle's pair order (mjc_PlaneSphere, mjc_SphereBox, mjc_SphereCylinder; normals geom1 -> geom2)
+MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
+  const double rp = MJS_G2F85_PROXY_RADIUS;
+  cs.n = 0;
+  auto add = [&](double dist, V3 n, double sgn, bool on_switch) {
+    int k = cs.n++;
+    cs.dist[k] = dist; cs.nrm[k] = n; cs.sgn[k] = sgn; cs.on_switch[k] = on_switch;
+    cs.pos[k] = sgn > 0 ? madd(c, -(rp + 0.5 * dist), n) : madd(c, rp + 0.5 * dist, n);
+  };
+  if (!(c.z > rp)) add(c.z - rp, v3(0, 0, 1), 1.0, false);
+  {  // box: clamp the centre into the box
+    const double h = MJS_SW_BOX_HALF;
+    V3 bc = v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF);
+    V3 loc = c - bc;
+    V3 cl = v3(clampd(loc.x, -h, h), clampd(loc.y, -h, h), clampd(loc.z, -h, h));
+    bool inside = cl.x == loc.x && cl.y == loc.y && cl.z == loc.z;
+    if (!inside) {
+      V3 v = (bc + cl) - c;
+      double len = sqrt(dot(v, v)), dist = len - rp;
+      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+    } else {
+      double best = INFINITY, sg = 1;
+      int ax = 0;
+      const double l[3] = {loc.x, loc.y, loc.z};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        if (h - l[k] < best) { best = h - l[k]; ax = k; sg = 1; }
+        if (h + l[k] < best) { best = h + l[k]; ax = k; sg = -1; }
+      }
+      V3 n = ax == 0 ? v3(-sg, 0, 0) : ax == 1 ? v3(0, -sg, 0) : v3(0, 0, -sg);
+      add(-(best + rp), n, -1.0, true);
+    }
+  }
+  {  // button cylinder (axis z): side / cap / rim
+    const double r2 = MJS_SW_BUTTON_RADIUS, h2 = MJS_SW_BUTTON_HALF;
+    V3 cc = v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z);
+    V3 vec = c - cc;
+    double x = vec.z;
+    V3 a = v3(vec.x, vec.y, vec.z - x);
+    double a2 = dot(a, a);
+    if (fabs(x) <= h2) {
+      V3 p = v3(cc.x, cc.y, cc.z + x);
+      V3 v = p - c;
+      double len = sqrt(dot(v, v)), dist = len - rp - r2;
+      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+    } else if (a2 <= r2 * r2) {
+      double sg = x > 0 ? 1.0 : -1.0, dist = fabs(x) - h2 - rp;
+      if (!(dist > 0.0)) add(dist, v3(0, 0, -sg), -1.0, true);
+    } else {
+      double sg = x > 0 ? 1.0 : -1.0, la = sqrt(a2);
+      V3 p = v3(cc.x + a.x / la * r2, cc.y + a.y / la * r2, cc.z + h2 * sg + a.z / la * r2);
+      V3 v = p - c;
+      double len = sqrt(dot(v, v)), dist = len - rp;
+      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+    }
+  }
+}
+
+MJS_DEV V3 proxy_centre(const rr::Chain& c) {
+  return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS, c.R[6].cy);
+}
+
+// Constraint stage of one physics step for a lane that may have rows: joint limits + proxy contacts.
+// In: q, v, cos/sin, M (lower, no armature), qfrc_smooth. Out: qfrc_constraint added into rhs,
+// touch sensor value, number of detected proxy contacts, whether any row was active.
+__device__ __noinline__ void constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, const double A[NJ][NJ],
+                                              double* rhs, double& touch, int& ncon_proxy, bool& rows_active) {
+  double J[MAXROW][NJ], D[MAXROW], aref[MAXROW], force[MAXROW];
+  int nrow = 0;
+  touch = 0;
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  // joint limits (mj_instantiateLimit), lower side first
+  for (int j = 0; j < NJ; j++)
+    for (int side = 0; side < 2; side++) {
+      double sgn = side == 0 ? 1.0 : -1.0;
+      double dist = side == 0 ? q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - q[j];
+      if (dist < 0.0) {
+        for (int k = 0; k < NJ; k++) J[nrow][k] = 0;
+        J[nrow][j] = sgn;
+        double imp = impedance_default(dist);
+        D[nrow] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_BP_DOF_INVWEIGHT0[j] / imp);
+        aref[nrow] = -B * (sgn * v[j]) - K * imp * dist;
+        nrow++;
+      }
+    }
+  // contacts of the gripper stand-in sphere
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  ContactSet con;
+  detect_contacts(proxy_centre(ch), sw, con);
+  ncon_proxy = con.n;
+  int first_row[3] = {-1, -1, -1};
+  const double mu = MJS_GEOM_FRICTION_SLIDE;
+  for (int c = 0; c < con.n; c++) {
+    if (!(con.dist[c] < 0.0)) continue;  // detected but not active (dist == margin)
+    V3 t1, t2;
+    make_frame(con.nrm[c], t1, t2);
+    double Jc[3][NJ];
+    for (int j = 0; j < NJ; j++) {
+      V3 col = con.sgn[c] * cross(rr::joint_axis(ch, j), con.pos[c] - ch.p[j + 1]);  // (jac2 - jac1) column
+      Jc[0][j] = dot(con.nrm[c], col); Jc[1][j] = dot(t1, col); Jc[2][j] = dot(t2, col);
+    }
+    double imp = impedance_default(con.dist[c]);
+    double dA = UR5E_BP_EEF_BODY_INVWEIGHT0[0] + mu * mu * UR5E_BP_EEF_BODY_INVWEIGHT0[0];
+    double R0 = fmax(MJS_MINVAL, (1 - imp) * dA / imp);
+    double Dc = 1 / (2 * mu * mu * R0);
+    first_row[c] = nrow;
+    for (int k = 1; k < 3; k++)
+      for (int s = 1; s >= -1; s -= 2) {
+        double vel = 0;
+        for (int j = 0; j < NJ; j++) { J[nrow][j] = Jc[0][j] + s * mu * Jc[k][j]; vel += J[nrow][j] * v[j]; }
+        D[nrow] = Dc;
+        aref[nrow] = -B * vel - K * imp * con.dist[c];
+        nrow++;
+      }
+  }
+  if (nrow == 0) return;
+  rows_active = true;
+  double Mf[NJ][NJ], fc[NJ];
+  for (int i = 0; i < NJ; i++) {
+    for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? A[i][j] : A[j][i];
+    Mf[i][i] += MJS_UR_ARMATURE;
+  }
+  solve_rows(Mf, rhs, nrow, J, D, aref, force, fc);
+  for (int j = 0; j < NJ; j++) rhs[j] += fc[j];
+  // touch sensor (mj_sensorAcc): normal forces of contacts with the switch whose point is inside the site
+  const double sr = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE, sh = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
+  for (int c = 0; c < con.n; c++) {
+    if (first_row[c] < 0 || !con.on_switch[c]) continue;
+    V3 loc = con.pos[c] - v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z);
+    if (loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh) continue;
+    touch += force[first_row[c]] + force[first_row[c] + 1] + force[first_row[c] + 2] + force[first_row[c] + 3];
+  }
+}
+
+// One Physics.step() of a lane: smooth dynamics (generated, Button-Push payload variant), constraint
+// stage when `maybe_rows`, implicitfast solve. Returns the integrator's acceleration.
+MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, bool maybe_rows,
+                            double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active) {
+  double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
+  ur5e_bp_M_gen(cs, sn, M);
+  ur5e_bp_bias_gen(cs, sn, v, bias);
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
+  }
+  const int clamped = rr::actuator_forces(q, v, ctrl, fact);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
+  touch = 0;
+  ncon_proxy = 0;
+  if (maybe_rows) constraint_stage(q, v, cs, sn, sw, A, rhs, touch, ncon_proxy, rows_active);
+  rr::factor_system(A, clamped, Dinv);
+  rr::udu_solve(A, Dinv, rhs);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
+}
+
+// can this lane get constraint rows during the next control step? (joint near its range, or the
+// gripper stand-in within reach of the floor / the switch; 0.12 m covers one control step of travel)
+MJS_DEV bool rows_possible(const double* q, const rr::Chain& ch, V3 sw) {
+  bool near = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) near = near || (q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - q[j] < 0.6);
+  V3 c = proxy_centre(ch);
+  V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
+  return near || c.z < 0.15 || dot(d, d) < 0.2 * 0.2;
+}
+
+// Switch._update_activation (switch.py:51-60)
+MJS_DEV void switch_update(double touch, uint8_t& flags) {
+  bool was = flags & FLAG_SWITCH_PRESSED;
+  bool pressed = touch >= MJS_SW_MIN_FORCE && touch <= MJS_SW_MAX_FORCE;
+  if (pressed && !was) flags ^= FLAG_SWITCH_ACTIVE;  // flip on the rising edge
+  flags = pressed ? (flags | FLAG_SWITCH_PRESSED) : (flags & ~FLAG_SWITCH_PRESSED);
+}
+
+MJS_DEV void make_obs(const rr::State& st, const rr::Chain& c, uint8_t flags, double* obs) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++) obs[j] = st.q[j];  // ur5e/joint_configuration
+  V3 tcp = rr::tcp_position(c);
+  obs[6] = tcp.x; obs[7] = tcp.y; obs[8] = tcp.z;  // ur5e/tcp_position
+  // Switch.get_position: button xpos + 0.5*size[1] added to ALL coordinates (switch.py:86-87)
+  obs[9] = st.target[0] + MJS_SW_POSITION_OFFSET;
+  obs[10] = st.target[1] + MJS_SW_POSITION_OFFSET;
+  obs[11] = st.target[2] + MJS_SW_BUTTON_Z + MJS_SW_POSITION_OFFSET;
+  obs[12] = (flags & FLAG_SWITCH_ACTIVE) ? 1.0 : 0.0;
+}
+
+// initialize_episode (robot_push_button.py:126-134, switch.py:62-65). st.target holds the switch position.
+struct ResetOut {
+  rr::State st;
+  uint8_t flags;
+  int ncon;
+};
+__device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_flags) {
+  ResetOut o;
+  RngCursor c = rng_open(rng, i);
+  double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_BP_ROBOT_SPACE_LO[k], MJS_BP_ROBOT_SPACE_HI[k]);
+  bool ok = rr::tcp_pose_to_joints(rp, zeros, q);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { o.st.q[j] = ok ? q[j] : 0.0; o.st.v[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 3; k++) o.st.target[k] = rng_uniform(rng, i, c, MJS_BP_SWITCH_SPACE_LO[k], MJS_BP_SWITCH_SPACE_HI[k]);
+  rng_close(rng, i, c);
+  o.st.time = 0;
+  // mj_forward at the reset state (ctrl = q) gives the touch force the switch sees in initialize_episode
+  double cs[NJ], sn[NJ], qacc[NJ], touch;
+  int ncp;
+  bool rows = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) sincos(o.st.q[j], &sn[j], &cs[j]);
+  V3 sw = v3(o.st.target[0], o.st.target[1], o.st.target[2]);
+  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, true, qacc, touch, ncp, rows);
+  uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
+  switch_update(touch, f);                      // with _is_active = False
+  o.flags = f;
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  o.ncon = rr::count_floor_contacts(ch) + ncp;
+  return o;
+}
+
+template <bool IS_RESET>
+__global__ __launch_bounds__(64) void kernel(KernelParams p) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= p.N) return;
+  uint8_t flags = p.flags[i];
+  double obs[OBS_DIM];
+  rr::Chain c;
+  if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
+    ResetOut r = episode_init(p.rng, i, flags);
+    rr::store_state(p, i, r.st);
+    p.flags[i] = r.flags;
+    rr::fk(r.st.q, c);
+    make_obs(r.st, c, r.flags, obs);
+    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, r.ncon);
+    return;
+  }
+  rr::State st = rr::load_state(p, i);
+  const V3 sw = v3(st.target[0], st.target[1], st.target[2]);
+  // before_step (robot_push_button.py:143-157)
+  const int adim = p.action_type == MJS_ACTION_ABS_EEF ? ACT_DIM_EEF : ACT_DIM_JOINT;
+  double q0[NJ], q1[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) q0[j] = st.q[j];
+  if (p.action_type == MJS_ACTION_ABS_EEF) {
+    double act[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * adim + k];
+    if (!rr::tcp_pose_to_joints(act, q0, q1)) {
+      flags |= FLAG_IK_FAILED;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) q1[j] = q0[j];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) q1[j] = p.actions[(size_t)i * adim + j];  // servoJ(a[:6]); a[6] drives the (lumped) fingers only
+  }
+  const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
+  bool bad = false, rows_active = false;
+  double cs[NJ], sn[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+  rr::fk_cs(cs, sn, c);
+  const bool maybe_rows = rows_possible(st.q, c, sw);
+  int ncon_proxy = 0;
+#pragma unroll 1
+  for (int s = 0; s < MJS_RR_NSUB; s++) {
+    double t = fmin(fmax(st.time, t0), t1);
+    double ctrl[NJ], qacc[NJ], touch;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    physics_forces(st.q, st.v, ctrl, cs, sn, sw, maybe_rows, qacc, touch, ncon_proxy, rows_active);
+    double acc2 = 0, dq2 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      acc2 = fma(qacc[j], qacc[j], acc2);
+      st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+      double dq = MJS_RR_PHYSICS_DT * st.v[j];
+      st.q[j] += dq;
+      dq2 = fma(dq, dq, dq2);
+      rr::rotate_small(cs[j], sn[j], dq);
+    }
+    bad = bad || !(acc2 <= 1e20);
+    if (!(dq2 <= 0.01)) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    }
+    st.time += MJS_RR_PHYSICS_DT;
+    switch_update(touch, flags);  // Switch.after_substep (switch.py:71-72)
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);
+  rr::fk_cs(cs, sn, c);
+  make_obs(st, c, flags, obs);
+  // goal: switch active and TCP within 0.05 of the end position (robot_push_button.py:205-219)
+  double dx = obs[6] - MJS_BP_ROBOT_END_POS[0], dy = obs[7] - MJS_BP_ROBOT_END_POS[1], dz = obs[8] - MJS_BP_ROBOT_END_POS[2];
+  bool success = (flags & FLAG_SWITCH_ACTIVE) && sqrt(dx * dx + dy * dy + dz * dz) < MJS_BP_GOAL_THRESHOLD;
+  double reward = success ? 1.0 : 0.0, discount = success ? 0.0 : 1.0;
+  bool terminate = success;
+  if (bad) { reward = 0; discount = 0; terminate = true; }
+  if (st.time >= p.time_limit) terminate = true;
+  // ncon after the step (mj_step1 of the last substep): arm-vs-floor + stand-in sphere contacts
+  int ncon = rr::count_floor_contacts(c);
+  if (maybe_rows) {
+    ContactSet con;
+    detect_contacts(proxy_centre(c), sw, con);
+    ncon += con.n;
+  }
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
+  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+  uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0));
+  rr::store_state(p, i, st);
+  p.flags[i] = newflags;
+  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
+    if (p.out.terminal_obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    ResetOut r = episode_init(p.rng, i, newflags);
+    rr::store_state(p, i, r.st);
+    p.flags[i] = r.flags;
+    rr::fk(r.st.q, c);
+    make_obs(r.st, c, r.flags, obs);
+    if (p.out.obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    if (p.out.ncon) p.out.ncon[i] = r.ncon;
+  }
+}
+
+}  // namespace bp

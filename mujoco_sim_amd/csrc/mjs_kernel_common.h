@@ -16,6 +16,7 @@ struct KernelParams {
   int reward_type;
   int autoreset;
   int terminate_on_success;
+  int action_type;
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]

@@ -42,13 +42,13 @@ class HipSB3VecEnv(_Base):
             self.num_envs, self.observation_space, self.action_space = num_envs, obs_space, act_space
         self.render_mode = None
         self._actions = None
-        self._lo = torch.as_tensor(np.asarray(self.venv.spec.action_low), dtype=torch.float64, device=self.venv.device)
-        self._hi = torch.as_tensor(np.asarray(self.venv.spec.action_high), dtype=torch.float64, device=self.venv.device)
+        self._lo = torch.as_tensor(np.asarray(self.venv.action_low), dtype=torch.float64, device=self.venv.device)
+        self._hi = torch.as_tensor(np.asarray(self.venv.action_high), dtype=torch.float64, device=self.venv.device)
 
     # ------------------------------------------------------------------ helpers
     def _obs_numpy(self, flat: torch.Tensor):
         host = flat.cpu().numpy()
-        return OrderedDict((k, host[:, s:s + n].copy()) for k, s, n in self.venv.spec.obs_layout)
+        return OrderedDict((k, host[:, s:s + n].copy()) for k, s, n in self.venv._state_layout)
 
     # ---------------------------------------------------------------- VecEnv API
     def seed(self, seed: int | None = None):
@@ -76,7 +76,7 @@ class HipSB3VecEnv(_Base):
         if dones.any():
             term_obs = b["terminal_obs"].cpu().numpy()
             for i in np.nonzero(dones)[0]:
-                infos[i]["terminal_observation"] = OrderedDict((k, term_obs[i, s:s + n].copy()) for k, s, n in self.venv.spec.obs_layout)
+                infos[i]["terminal_observation"] = OrderedDict((k, term_obs[i, s:s + n].copy()) for k, s, n in self.venv._state_layout)
                 infos[i]["TimeLimit.truncated"] = bool(truncated[i] and not terminated[i])
         return obs, reward, dones, infos
 

@@ -25,6 +25,10 @@ DENSE_NEG_DISTANCE_REWARD = "dense_negative_distance_reward"
 DENSE_BIASED_NEG_DISTANCE_REWARD = "dense_biased_negative_distance_reward"
 STATE_OBS = "state_observations"
 VISUAL_OBS = "visual_observations"
+# Button-Push action types (robot_push_button.py:28-29)
+ABS_EEF_ACTION = "absolute_eef_action"
+ABS_JOINT_ACTION = "absolute_joint_action"
+_ACTION_IDS = {ABS_JOINT_ACTION: nat.ACTION_ABS_JOINT, ABS_EEF_ACTION: nat.ACTION_ABS_EEF}
 
 _REWARD_IDS = {
     SPARSE_REWARD: nat.REW_SPARSE,
@@ -64,7 +68,17 @@ TASKS = {
         (-0.1, -0.6, 0.02), (0.1, -0.4, 0.2), np.float64,
         (SPARSE_REWARD, DENSE_NEG_DISTANCE_REWARD),
         0.1, 0.005, 100),
+    # robot_push_button.py:113-119 observables (which robot observable is enabled follows the action type, the
+    # kernel always writes both), switch.py:86-108 (the Switch model is an unnamed mjcf root -> "unnamed_model/");
+    # :176-203 action spec (ABS_JOINT default; ABS_EEF bounds are substituted in HipVectorEnv), :38-40 timing
+    "robot_push_button": TaskSpec(
+        "robot_push_button", nat.TASK_BUTTON_PUSH,
+        (("ur5e/joint_configuration", 0, 6), ("ur5e/tcp_position", 6, 3), ("unnamed_model/position", 9, 3), ("unnamed_model/active", 12, 1)),
+        (-3.14,) * 6 + (0.0,), (3.14,) * 6 + (0.085,), np.float64,
+        (SPARSE_REWARD,),
+        0.1, 0.005, 100),
 }
+_BUTTON_EEF_ACTION_BOUNDS = ((-0.2, -0.6, 0.02, 0.0), (0.2, -0.3, 0.3, 0.085))  # robot_push_button.py:79,177-192
 
 
 def _as_uint8_ptr(t):
@@ -77,10 +91,17 @@ class HipVectorEnv:
     def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
-                 observation_type: str = STATE_OBS, image_resolution: int = 64):
+                 observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
+        if task == "robot_push_button":
+            action_type = action_type or ABS_JOINT_ACTION
+            if action_type not in _ACTION_IDS:
+                raise AssertionError(f"action_type must be one of {tuple(_ACTION_IDS)}")  # robot_push_button.py:33
+        elif action_type is not None:
+            raise ValueError(f"task {task!r} has no action_type option")
+        self.action_type = action_type
         if reward_type is not None and reward_type not in self.spec.reward_types:
             raise AssertionError(f"reward_type {reward_type!r} not in {self.spec.reward_types}")  # reference asserts (point_reach.py:68)
         if autoreset not in _AUTORESET_IDS:
@@ -95,12 +116,13 @@ class HipVectorEnv:
         cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self.device.index or 0,
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
-                            time_limit=float(time_limit) if time_limit is not None else -1.0)
+                            time_limit=float(time_limit) if time_limit is not None else -1.0,
+                            action_type=_ACTION_IDS.get(action_type, 0), reserved0=0)
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h
         self.obs_dim = self._lib.mjs_obs_dim(self.spec.task_id)
-        self.action_dim = self._lib.mjs_action_dim(self.spec.task_id)
+        self.action_dim = self._lib.mjs_action_dim_for(self.spec.task_id, _ACTION_IDS.get(action_type, 0))
         self.state_dim = self._lib.mjs_state_dim(self.spec.task_id)
         self.algorithmic_bytes_per_env_step = self._lib.mjs_algorithmic_bytes_per_env_step(self.spec.task_id)
         N, dev = self.num_envs, self.device
@@ -117,10 +139,19 @@ class HipVectorEnv:
             "ncon": torch.zeros(N, dtype=torch.int32, device=dev),
         }
         self._out = self._make_outputs(self._buf)
+        # enabled observables: everything the kernel writes, except that Button-Push enables only the robot
+        # observable matching its action type (robot_push_button.py:113-117)
+        self.action_low, self.action_high = self.spec.action_low, self.spec.action_high
+        self._state_layout = self.spec.obs_layout
+        if task == "robot_push_button":
+            drop = "ur5e/tcp_position" if action_type == ABS_JOINT_ACTION else "ur5e/joint_configuration"
+            self._state_layout = tuple(e for e in self.spec.obs_layout if e[0] != drop)
+            if action_type == ABS_EEF_ACTION:
+                self.action_low, self.action_high = _BUTTON_EEF_ACTION_BOUNDS
         # spaces (dmc2gym.py:55-63,90,99-101)
         self.single_observation_space = Dict(OrderedDict(
-            (k, Box(-np.inf, np.inf, shape=(n,), dtype=np.float64)) for k, _, n in self.spec.obs_layout))
-        self.single_action_space = Box(np.asarray(self.spec.action_low, dtype=np.float32), np.asarray(self.spec.action_high, dtype=np.float32), dtype=np.float32)
+            (k, Box(-np.inf, np.inf, shape=(n,), dtype=np.float64)) for k, _, n in self._state_layout))
+        self.single_action_space = Box(np.asarray(self.action_low, dtype=np.float32), np.asarray(self.action_high, dtype=np.float32), dtype=np.float32)
         self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
         self.action_space = batch_box(self.single_action_space, N)
         # visual observations (point_reach.py:119-121: camera image + pointmass position)
@@ -156,7 +187,7 @@ class HipVectorEnv:
             d = OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout if k in self._visual_keys)
             d["Camera/rgb_image"] = self._img
             return d
-        return OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout)
+        return OrderedDict((k, flat[..., s:s + n]) for k, s, n in self._state_layout)
 
     def _info(self, b):
         return {"is_success": b["is_success"], "discount": b["discount"], "step_type": b["step_type"], "fault": b["fault"],

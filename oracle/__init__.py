@@ -11,6 +11,9 @@ from .oracle import (  # noqa: F401
     AUTORESET_SAME_STEP,
     TASK_POINTMASS,
     TASK_ROBOT_REACH,
+    TASK_BUTTON_PUSH,
+    ACTION_ABS_JOINT,
+    ACTION_ABS_EEF,
     OracleBatch,
     OracleRng,
     build,

@@ -69,6 +69,9 @@ typedef struct {
   /* equality: weld only */
   int eq_body1[OM_MAXEQ], eq_body2[OM_MAXEQ];
   double eq_data[OM_MAXEQ][11], eq_solref[OM_MAXEQ][2], eq_solimp[OM_MAXEQ][5];
+  /* touch sensor: site index (-1 none) and its cylinder size (radius, half-height) */
+  int touch_site;
+  double touch_size[2];
   /* options + statistics */
   double dt, gravity[3], tolerance, impratio, meaninertia;
   double solref[2], solimp[5]; /* global default contact/limit parameters */
@@ -101,6 +104,7 @@ typedef struct {
   double qfrc_bias[OM_MAXV], qfrc_passive[OM_MAXV], qfrc_actuator[OM_MAXV], actuator_force[OM_MAXU];
   double qfrc_smooth[OM_MAXV], qacc_smooth[OM_MAXV], qacc[OM_MAXV], qfrc_constraint[OM_MAXV];
   int solver_niter, warning_bad;
+  double touch_force; /* touch sensordata (mj_sensorAcc) */
 } om_data;
 
 /* numpy-compatible MT19937 (legacy RandomState(int seed)) */
@@ -130,10 +134,12 @@ enum { OM_STEP_FIRST = 0, OM_STEP_MID = 1, OM_STEP_LAST = 2 };
 enum { OM_REW_SPARSE = 0, OM_REW_DENSE_POTENTIAL = 1, OM_REW_DENSE_NEG_DISTANCE = 2, OM_REW_DENSE_BIASED_NEG_DISTANCE = 3 };
 enum { OM_AUTORESET_NEXT_STEP = 0, OM_AUTORESET_SAME_STEP = 1, OM_AUTORESET_DISABLED = 2 };
 
+enum { OM_ACTION_ABS_JOINT = 0, OM_ACTION_ABS_EEF = 1 }; /* robot_push_button.py:28-29 */
 typedef struct {
   int task, reward_type, autoreset;
   double time_limit;         /* composer.Environment(time_limit=...) */
   int terminate_on_success;  /* Robot-Reach only: opt-in (deviation D-2) */
+  int action_type;           /* Button-Push only */
 } om_task_config;
 
 #define OM_MAXOBS 16
@@ -157,6 +163,9 @@ typedef struct {
   int traj_active;
   double traj_q0[6], traj_q1[6], traj_t0, traj_t1;
   int ik_failed;
+  /* Switch entity state (entities/props/switch.py:10-16,51-60) */
+  int switch_active, switch_pressed, switch_num_pressed;
+  double switch_pos[3];
 } om_env;
 
 void om_default_config(int task, om_task_config* cfg);
@@ -170,6 +179,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out);
 /* scene-camera image (own ray caster, om_render.c): out uint8 [H, W, 3] */
 void om_render_pointmass(const om_env* e, int H, int W, uint8_t* out);
 void om_render_robot(const om_env* e, int H, int W, uint8_t* out);
+void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out);
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
 void om_debug_reach_dynamics(const double* q, const double* v, double* M_out, double* bias_out);
 

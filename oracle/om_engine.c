@@ -391,6 +391,80 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
   }
 }
 
+/* sphere (g1) vs sphere-like point set of g2: shared tail of the sphere tests. Normal points from
+ * geom1 to geom2 (MuJoCo convention). */
+static void sphere_point(const om_model* m, om_data* d, int g1, int g2, const double* c1, double r1, const double* p2, double r2) {
+  double v[3] = {p2[0] - c1[0], p2[1] - c1[1], p2[2] - c1[2]};
+  double len = norm3(v), nrm[3], pos[3];
+  double dist = len - r1 - r2;
+  if (dist > 0.0) return; /* margin 0 */
+  if (len < MJS_MINVAL) { nrm[0] = 1; nrm[1] = 0; nrm[2] = 0; } else for (int k = 0; k < 3; k++) nrm[k] = v[k] / len;
+  for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+  add_contact(m, d, g1, g2, dist, pos, nrm);
+}
+
+/* mjc_SphereCylinder: side / cap / rim cases */
+static void collide_sphere_cylinder(const om_model* m, om_data* d, int g1, int g2) {
+  const double* c1 = d->geom_xpos[g1];
+  const double* c2 = d->geom_xpos[g2];
+  const double* m2 = d->geom_xmat[g2];
+  double r1 = m->geom_size[g1][0], r2 = m->geom_size[g2][0], h2 = m->geom_size[g2][1];
+  double axis[3] = {m2[2], m2[5], m2[8]}, vec[3], a[3];
+  for (int k = 0; k < 3; k++) vec[k] = c1[k] - c2[k];
+  double x = dot3(vec, axis);
+  for (int k = 0; k < 3; k++) a[k] = vec[k] - axis[k] * x;
+  double a2 = dot3(a, a);
+  if (fabs(x) <= h2) { /* side: sphere vs the point of the axis at the same height, radius r2 */
+    double p[3];
+    for (int k = 0; k < 3; k++) p[k] = c2[k] + axis[k] * x;
+    sphere_point(m, d, g1, g2, c1, r1, p, r2);
+  } else if (a2 <= r2 * r2) { /* cap: plane through the cap, normal along the axis */
+    double sgn = x > 0 ? 1.0 : -1.0, nrm[3], pos[3];
+    double dist = fabs(x) - h2 - r1;
+    if (dist > 0.0) return;
+    for (int k = 0; k < 3; k++) nrm[k] = -sgn * axis[k]; /* from the sphere towards the cylinder */
+    for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+    add_contact(m, d, g1, g2, dist, pos, nrm);
+  } else { /* rim: closest point of the cap circle */
+    double sgn = x > 0 ? 1.0 : -1.0, p[3], la = sqrt(a2);
+    for (int k = 0; k < 3; k++) p[k] = c2[k] + axis[k] * h2 * sgn + a[k] / la * r2;
+    sphere_point(m, d, g1, g2, c1, r1, p, 0.0);
+  }
+}
+
+/* mjc_SphereBox: clamp the centre into the box */
+static void collide_sphere_box(const om_model* m, om_data* d, int g1, int g2) {
+  const double* c1 = d->geom_xpos[g1];
+  const double* c2 = d->geom_xpos[g2];
+  const double* m2 = d->geom_xmat[g2];
+  const double* sz = m->geom_size[g2];
+  double r1 = m->geom_size[g1][0], rel[3], loc[3], cl[3];
+  for (int k = 0; k < 3; k++) rel[k] = c1[k] - c2[k];
+  for (int k = 0; k < 3; k++) loc[k] = m2[k] * rel[0] + m2[3 + k] * rel[1] + m2[6 + k] * rel[2]; /* R^T rel */
+  int inside = 1;
+  for (int k = 0; k < 3; k++) {
+    cl[k] = fmin(fmax(loc[k], -sz[k]), sz[k]);
+    if (cl[k] != loc[k]) inside = 0;
+  }
+  if (!inside) {
+    double pw[3];
+    for (int k = 0; k < 3; k++) pw[k] = c2[k] + m2[3 * k] * cl[0] + m2[3 * k + 1] * cl[1] + m2[3 * k + 2] * cl[2];
+    sphere_point(m, d, g1, g2, c1, r1, pw, 0.0);
+  } else { /* centre inside the box: push out through the nearest face */
+    int ax = 0;
+    double best = INFINITY, sgn = 1;
+    for (int k = 0; k < 3; k++) {
+      double dpos = sz[k] - loc[k], dneg = sz[k] + loc[k];
+      if (dpos < best) { best = dpos; ax = k; sgn = 1; }
+      if (dneg < best) { best = dneg; ax = k; sgn = -1; }
+    }
+    double nrm[3], pos[3], dist = -(best + r1);
+    for (int k = 0; k < 3; k++) nrm[k] = -sgn * m2[3 * k + ax]; /* from the sphere towards the box interior */
+    for (int k = 0; k < 3; k++) pos[k] = c1[k] + nrm[k] * (r1 + 0.5 * dist);
+    add_contact(m, d, g1, g2, dist, pos, nrm);
+  }
+}
+
 static int body_weld(const om_model* m, int b) { return m->body_weldid[b]; }
 
 static void om_collision(const om_model* m, om_data* d) {
@@ -406,9 +480,12 @@ static void om_collision(const om_model* m, om_data* d) {
         if (w1 == p2 || w2 == p1) continue; /* parent-child filter */
       }
       int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-      if (t1 == OM_GEOM_PLANE && t2 != OM_GEOM_PLANE) collide_plane(m, d, g1, g2);
-      else if (t2 == OM_GEOM_PLANE && t1 != OM_GEOM_PLANE) collide_plane(m, d, g2, g1);
-      /* other pairs: not needed by the Pointmass / Robot-Reach scenes */
+      int ga = g1, gb = g2; /* MuJoCo orders a pair by geom type */
+      if (t1 > t2) { ga = g2; gb = g1; int tt = t1; t1 = t2; t2 = tt; }
+      if (t1 == OM_GEOM_PLANE && t2 != OM_GEOM_PLANE) collide_plane(m, d, ga, gb);
+      else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_CYLINDER) collide_sphere_cylinder(m, d, ga, gb);
+      else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_BOX) collide_sphere_box(m, d, ga, gb);
+      /* other pairs (capsule-capsule, capsule-box, ...): not evaluated */
     }
 }
 
@@ -869,11 +946,33 @@ void om_step1(const om_model* m, om_data* d) {
   om_fwd_velocity(m, d);
 }
 
+/* mj_sensorAcc, touch sensor: sum of the normal forces of the contacts that involve a geom of the
+ * site's body and whose contact point lies inside the (cylinder) site volume */
+static void om_sensor_touch(const om_model* m, om_data* d) {
+  d->touch_force = 0;
+  if (m->touch_site < 0) return;
+  int s = m->touch_site, sb = m->site_body[s];
+  for (int c = 0; c < d->ncon; c++) {
+    const om_contact* con = &d->contact[c];
+    if (con->efc_address < 0) continue;
+    if (m->geom_body[con->geom1] != sb && m->geom_body[con->geom2] != sb) continue;
+    double rel[3], loc[3];
+    for (int k = 0; k < 3; k++) rel[k] = con->pos[k] - d->site_xpos[s][k];
+    for (int k = 0; k < 3; k++) loc[k] = d->site_xmat[s][k] * rel[0] + d->site_xmat[s][3 + k] * rel[1] + d->site_xmat[s][6 + k] * rel[2];
+    if (loc[0] * loc[0] + loc[1] * loc[1] > m->touch_size[0] * m->touch_size[0] || fabs(loc[2]) > m->touch_size[1]) continue;
+    int nrow = con->dim == 1 ? 1 : 2 * (con->dim - 1);
+    double fn = 0;
+    for (int r = 0; r < nrow; r++) fn += d->efc_force[con->efc_address + r]; /* pyramid: normal = sum of edges */
+    d->touch_force += fn;
+  }
+}
+
 void om_step2(const om_model* m, om_data* d) {
   int nv = m->nv;
   om_actuation(m, d);
   om_fwd_acceleration(m, d);
   om_solve_constraint(m, d);
+  om_sensor_touch(m, d);
   om_check_state(m, d);
   memcpy(d->qacc_warmstart, d->qacc, sizeof(double) * nv);
   double qacc[OM_MAXV];
@@ -919,6 +1018,7 @@ void om_forward(const om_model* m, om_data* d) {
   om_actuation(m, d);
   om_fwd_acceleration(m, d);
   om_solve_constraint(m, d);
+  om_sensor_touch(m, d);
 }
 
 /* dm_control Physics.step() legacy mode (non-RK4): mj_step2 then mj_step1, so that

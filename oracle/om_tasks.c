@@ -48,6 +48,7 @@ static void model_defaults(om_model* m) {
   m->solimp[0] = MJS_SOLIMP_D0; m->solimp[1] = MJS_SOLIMP_DWIDTH; m->solimp[2] = MJS_SOLIMP_WIDTH;
   m->solimp[3] = MJS_SOLIMP_MIDPOINT; m->solimp[4] = MJS_SOLIMP_POWER;
   m->nbody = 1; /* world */
+  m->touch_site = -1;
   m->body_mocapid[0] = -1;
   m->body_quat[0][0] = m->body_iquat[0][0] = 1;
 }
@@ -184,6 +185,37 @@ static void build_robot(om_model* m, int eef_gripper) {
   om_set_const(m);
 }
 
+/* Button-Push scene (robot_push_button.py:66-108): UR5e + lumped gripper (+ collision stand-in sphere
+ * for the closed finger tips) + wrist-camera geoms' mass + static switch (box, button cylinder, touch
+ * site). The switch body position is a MODEL field rewritten at every reset (Entity.set_pose). */
+static void build_button(om_model* m) {
+  build_robot(m, 1);
+  const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
+  int payload = m->nbody - 1, wrist3 = m->body_parent[payload];
+  /* proxy sphere on the gripper body: tip at the TCP */
+  const double ppos[3] = {0, 0, MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS};
+  add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
+  /* wrist camera body: box + sphere of default density, concentric at MJS_WCAM_POS (mass only) */
+  double bx = MJS_CAM_BOX_HALF[0], by = MJS_CAM_BOX_HALF[1], bz = MJS_CAM_BOX_HALF[2], rs = MJS_CAM_SPHERE_RADIUS;
+  double mb = MJS_GEOM_DENSITY * 8 * bx * by * bz, ms = MJS_GEOM_DENSITY * 4.0 / 3.0 * 3.14159265358979323846 * rs * rs * rs;
+  double Is = 0.4 * ms * rs * rs;
+  double inertia[3] = {mb * (by * by + bz * bz) / 3 + Is, mb * (bx * bx + bz * bz) / 3 + Is, mb * (bx * bx + by * by) / 3 + Is};
+  add_body(m, wrist3, MJS_UR_FLANGE_POS, MJS_UR_FLANGE_QUAT, mb + ms, MJS_WCAM_POS, MJS_WCAM_QUAT, inertia, 0.0);
+  /* switch: static body */
+  int sw = add_body(m, 0, zero3, ident, 0, NULL, NULL, NULL, 0);
+  const double boxpos[3] = {0, 0, MJS_SW_BOX_HALF}, butpos[3] = {0, 0, MJS_SW_BUTTON_Z};
+  add_geom(m, sw, OM_GEOM_BOX, boxpos, ident, MJS_SW_BOX_HALF, MJS_SW_BOX_HALF, MJS_SW_BOX_HALF);
+  add_geom(m, sw, OM_GEOM_CYLINDER, butpos, ident, MJS_SW_BUTTON_RADIUS, MJS_SW_BUTTON_HALF, 0);
+  int s = m->nsite++;
+  m->site_body[s] = sw;
+  memcpy(m->site_pos[s], butpos, sizeof butpos);
+  m->site_quat[s][0] = 1;
+  m->touch_site = s;
+  m->touch_size[0] = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE;
+  m->touch_size[1] = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
+  om_set_const(m);
+}
+
 /* ------------------------------------------------------------ task API */
 void om_default_config(int task, om_task_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
@@ -192,13 +224,18 @@ void om_default_config(int task, om_task_config* cfg) {
   if (task == OM_TASK_POINTMASS) {
     cfg->reward_type = OM_REW_DENSE_BIASED_NEG_DISTANCE;                  /* point_reach.py:63 */
     cfg->time_limit = MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT;      /* __init__.py:21,28 */
+  } else if (task == OM_TASK_BUTTON_PUSH) {
+    cfg->reward_type = OM_REW_SPARSE;                                     /* robot_push_button.py:47 */
+    cfg->time_limit = MJS_BP_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      /* __init__.py:32-34 */
+    cfg->action_type = OM_ACTION_ABS_JOINT;                               /* robot_push_button.py:49 */
   } else {
     cfg->reward_type = OM_REW_DENSE_NEG_DISTANCE;                         /* robot_reach.py:75 */
     cfg->time_limit = MJS_RR_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      /* BASELINE cfg 3 */
   }
 }
-int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : 12; }
-int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : 3; }
+/* Button-Push flat obs: ur5e/joint_configuration(6), ur5e/tcp_position(3), switch position(3), active(1) */
+int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : task == OM_TASK_BUTTON_PUSH ? 13 : 12; }
+int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : task == OM_TASK_BUTTON_PUSH ? 7 : 3; }
 int om_sizeof_step_out(void) { return (int)sizeof(om_step_out); }
 
 void om_env_seed(om_env* e, uint32_t seed) { om_rng_seed(&e->rng, seed); }
@@ -207,6 +244,7 @@ void om_env_init(om_env* e, const om_task_config* cfg, uint32_t seed) {
   memset(e, 0, sizeof *e);
   e->cfg = *cfg;
   if (cfg->task == OM_TASK_POINTMASS) { build_pointmass(&e->m); e->n_sub = (int)round(MJS_PM_CONTROL_DT / MJS_PM_PHYSICS_DT); }
+  else if (cfg->task == OM_TASK_BUTTON_PUSH) { build_button(&e->m); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   else { build_robot(&e->m, 1); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   e->distance_to_target = 1.0;          /* point_reach.py:112-113 */
   e->previous_distance_to_target = 1.0;
@@ -239,11 +277,26 @@ static void write_obs(const om_env* e, double* obs) {
   if (e->cfg.task == OM_TASK_POINTMASS) {
     obs[0] = e->d.xpos[2][0]; obs[1] = e->d.xpos[2][1];     /* pointmass/position (pointmass.py:87-98) */
     obs[2] = e->target_pos[0]; obs[3] = e->target_pos[1];   /* goal_position (point_reach.py:211-212) */
+  } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
+    for (int j = 0; j < 6; j++) obs[j] = e->d.qpos[j];       /* ur5e/joint_configuration (robot.py:296-298) */
+    get_tcp_position(e, obs + 6);                            /* ur5e/tcp_position */
+    /* Switch.get_position: button geom xpos + 0.5*size[1] on ALL coordinates (switch.py:86-87) */
+    for (int k = 0; k < 3; k++) obs[9 + k] = e->switch_pos[k] + (k == 2 ? MJS_SW_BUTTON_Z : 0.0) + MJS_SW_POSITION_OFFSET;
+    obs[12] = e->switch_active;                              /* SwitchObservables.active (intended, App. D-6) */
   } else {
     get_tcp_position(e, obs);                                /* ur5e/tcp_position */
     for (int j = 0; j < 6; j++) obs[3 + j] = e->d.qpos[j];   /* ur5e/joint_configuration */
     for (int k = 0; k < 3; k++) obs[9 + k] = e->target_pos[k]; /* target_position */
   }
+}
+
+/* Switch._update_activation (switch.py:51-60), called from initialize_episode and after every substep */
+static void switch_update(om_env* e) {
+  double f = e->d.touch_force;
+  int was = e->switch_pressed;
+  e->switch_pressed = (f >= MJS_SW_MIN_FORCE && f <= MJS_SW_MAX_FORCE);
+  if (e->switch_pressed && !was) e->switch_active = !e->switch_active; /* flip on the rising edge */
+  e->switch_num_pressed += e->switch_pressed;
 }
 
 static void episode_init(om_env* e) {
@@ -260,6 +313,20 @@ static void episode_init(om_env* e) {
     double px = om_rng_uniform(&e->rng, lo, hi), py = om_rng_uniform(&e->rng, lo, hi);
     d->qpos[0] = px; d->qpos[1] = py; d->qvel[0] = d->qvel[1] = 0;
     d->mocap_pos[0][0] = px; d->mocap_pos[0][1] = py;
+  } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
+    /* robot_push_button.py:126-134: robot xyz -> IK -> joints; switch xyz -> switch.set_pose (model edit) */
+    double rp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
+    for (int k = 0; k < 3; k++) rp[k] = om_rng_uniform(&e->rng, MJS_BP_ROBOT_SPACE_LO[k], MJS_BP_ROBOT_SPACE_HI[k]);
+    if (tcp_pose_to_joints(rp, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, zeros, q))
+      for (int j = 0; j < 6; j++) { d->qpos[j] = q[j]; d->qvel[j] = 0; d->ctrl[j] = q[j]; }
+    for (int k = 0; k < 3; k++) e->switch_pos[k] = om_rng_uniform(&e->rng, MJS_BP_SWITCH_SPACE_LO[k], MJS_BP_SWITCH_SPACE_HI[k]);
+    memcpy(m->body_pos[m->site_body[m->touch_site]], e->switch_pos, sizeof e->switch_pos);
+    om_forward(m, d);
+    /* Switch.initialize_episode (switch.py:62-65) */
+    e->switch_num_pressed = 0;
+    e->switch_active = 0;
+    switch_update(e);
+    return;
   } else {
     /* robot_reach.py:143-150 with spaces.py:24-31 */
     double rp[3], tp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
@@ -308,8 +375,16 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       t = fmin(fmax(t, MJS_PM_ARENA_LO), MJS_PM_ARENA_HI);
       d->mocap_pos[0][k] = t;
     }
+  } else if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.action_type == OM_ACTION_ABS_JOINT) {
+    /* robot_push_button.py:151-157: gripper.move(a[6]) only sets the finger actuator's ctrl (no finger
+     * DoF under D-1); servoJ(a[:6]) -> robot.py:227-259 */
+    memcpy(e->traj_q0, d->qpos, sizeof e->traj_q0);
+    memcpy(e->traj_q1, action, sizeof e->traj_q1);
+    e->traj_t0 = d->time;
+    e->traj_t1 = d->time + MJS_RR_CONTROL_DT;
+    e->traj_active = 1;
   } else {
-    /* robot_reach.py:159-169 -> robot.py:218-259 */
+    /* robot_reach.py:159-169 / robot_push_button.py:143-149 -> robot.py:218-259 */
     double q_now[6], q_ik[6];
     memcpy(q_now, d->qpos, sizeof q_now);
     if (!tcp_pose_to_joints(action, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, q_now, q_ik)) {
@@ -330,6 +405,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       for (int j = 0; j < 6; j++) d->ctrl[j] = e->traj_q0[j] + (e->traj_q1[j] - e->traj_q0[j]) * (t - e->traj_t0) / (e->traj_t1 - e->traj_t0);
     }
     om_physics_step(m, d);
+    if (e->cfg.task == OM_TASK_BUTTON_PUSH) switch_update(e); /* Switch.after_substep (switch.py:71-72) */
   }
   /* after_step + reward/discount/termination */
   int terminate = 0, success = 0;
@@ -346,6 +422,15 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       case OM_REW_DENSE_POTENTIAL: reward = e->previous_distance_to_target - e->distance_to_target; break;
       default: reward = -e->distance_to_target + 0.5; break;
     }
+    terminate = success;
+    discount = success ? 0.0 : 1.0;
+  } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
+    /* robot_push_button.py:167-170,205-219: goal = switch active AND tcp within 0.05 of the end position */
+    double tcp[3], dd = 0;
+    get_tcp_position(e, tcp);
+    for (int k = 0; k < 3; k++) dd += (tcp[k] - MJS_BP_ROBOT_END_POS[k]) * (tcp[k] - MJS_BP_ROBOT_END_POS[k]);
+    success = e->switch_active && sqrt(dd) < MJS_BP_GOAL_THRESHOLD;
+    reward = success ? 1.0 : 0.0;
     terminate = success;
     discount = success ? 0.0 : 1.0;
   } else {
@@ -388,6 +473,27 @@ void om_debug_reach_dynamics(const double* q, const double* v, double* M_out /*3
     for (int j = 0; j < 6; j++) M_out[6 * i + j] = d.M[i][j];
     bias_out[i] = d.qfrc_bias[i] - d.qfrc_passive[i];
   }
+}
+
+/* debug hook for tests: same as om_debug_reach_dynamics for the Button-Push model, plus the
+ * body_invweight0 (translation, rotation) of the gripper body (the contact rows' diagApprox) */
+void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out) {
+  static __thread om_model m;
+  static __thread om_data d;
+  static __thread int built = 0;
+  if (!built) { build_button(&m); built = 1; }
+  om_reset_data(&m, &d);
+  memcpy(d.qpos, q, sizeof(double) * 6);
+  memcpy(d.qvel, v, sizeof(double) * 6);
+  om_step1(&m, &d);
+  for (int i = 0; i < 6; i++) {
+    for (int j = 0; j < 6; j++) M_out[6 * i + j] = d.M[i][j];
+    bias_out[i] = d.qfrc_bias[i] - d.qfrc_passive[i];
+  }
+  invw_out[0] = m.body_invweight0[8][0];
+  invw_out[1] = m.body_invweight0[8][1];
+  invw_out[2] = m.meaninertia;
+  for (int i = 0; i < 6; i++) invw_out[3 + i] = m.dof_invweight0[i];
 }
 
 /* debug hook for tests: overwrite joint positions / velocities of a robot env (then mj_forward) */

@@ -11,7 +11,8 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "_build" / "liboracle.so"
 
-TASK_POINTMASS, TASK_ROBOT_REACH = 0, 1
+TASK_POINTMASS, TASK_ROBOT_REACH, TASK_BUTTON_PUSH = 0, 1, 3
+ACTION_ABS_JOINT, ACTION_ABS_EEF = 0, 1
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DISTANCE = 0, 1, 2, 3
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
@@ -25,6 +26,7 @@ class TaskConfig(C.Structure):
         ("autoreset", C.c_int),
         ("time_limit", C.c_double),
         ("terminate_on_success", C.c_int),
+        ("action_type", C.c_int),
     ]
 
 
@@ -154,7 +156,7 @@ class OracleBatch:
 
     def __init__(self, task: int, n: int, base_seed: int = 0, *, reward_type: int | None = None,
                  autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
-                 terminate_on_success: bool = False, nthreads: int = 1):
+                 terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None):
         L = lib()
         cfg = TaskConfig()
         L.om_default_config(task, C.byref(cfg))
@@ -164,8 +166,12 @@ class OracleBatch:
             cfg.time_limit = time_limit
         cfg.autoreset = autoreset
         cfg.terminate_on_success = int(terminate_on_success)
+        if action_type is not None:
+            cfg.action_type = action_type
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
         self.obs_dim, self.action_dim = L.om_obs_dim(task), L.om_action_dim(task)
+        if task == TASK_BUTTON_PUSH and cfg.action_type == ACTION_ABS_EEF:
+            self.action_dim = 4
         self._h = L.om_batch_create(C.byref(cfg), n, base_seed & 0xFFFFFFFF)
         self._out = np.zeros(n, dtype=_STEP_DTYPE)
 

@@ -384,3 +384,96 @@ def test_render_robot_scene_matches_oracle(oracle_mod):
     obs, *_ = vis.step(torch.from_numpy(_actions("robot_reach", 1, 4)[0]))
     assert obs["Camera/rgb_image"].dtype == torch.uint8 and obs["Camera/rgb_image"].float().std() > 10
     vis.close()
+
+
+# ------------------------------------------------------------------------------------------ Button-Push
+def _button_actions(action_type, T, N, seed=4242):
+    rs = np.random.RandomState(seed)
+    if action_type == "absolute_eef_action":  # robot_push_button.py:177-192 bounds
+        return rs.uniform([-0.2, -0.6, 0.02, 0.0], [0.2, -0.3, 0.3, 0.085], (T, N, 4))
+    nominal = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04])
+    return nominal + rs.uniform(-1, 1, (T, N, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04])
+
+
+@pytest.mark.parametrize("action_type", ["absolute_eef_action", "absolute_joint_action"])
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_button_push_parity_with_oracle(oracle_mod, action_type, autoreset):
+    import mujoco_sim_amd as m
+
+    N, T = 128, 112
+    venv = m.HipVectorEnv("robot_push_button", N, seed=2025, autoreset=autoreset, action_type=action_type)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 2025, autoreset={"next_step": 0, "same_step": 1}[autoreset], nthreads=8,
+                                action_type={"absolute_joint_action": 0, "absolute_eef_action": 1}[action_type])
+    assert venv.action_dim == ob.action_dim == (4 if action_type == "absolute_eef_action" else 7)
+    acts = _button_actions(action_type, T, N)
+    venv.reset()
+    o = ob.reset()
+    g = _gpu_result(venv)
+    np.testing.assert_allclose(g["obs"], o["obs"], rtol=0, atol=ATOL)
+    assert np.array_equal(g["ncon"], o["ncon"])
+    n_last = n_contact = n_active = 0
+    for t in range(T):
+        venv.step(torch.from_numpy(acts[t]))
+        o = ob.step(acts[t])
+        g = _gpu_result(venv)
+        _compare(t, g, o)
+        assert np.array_equal((g["fault"] & 1).astype(bool), o["fault"])
+        assert np.array_equal((g["fault"] & 2).astype(bool), o["ik_failed"])
+        if autoreset == "same_step":
+            ended = o["step_type"] == 2
+            np.testing.assert_allclose(g["terminal_obs"][ended], o["terminal_obs"][ended], rtol=0, atol=ATOL)
+        n_last += int((o["step_type"] == 2).sum())
+        n_contact += int((o["ncon"] > 0).sum())
+        n_active += int((o["obs"][:, 12] > 0.5).sum())
+    assert n_last >= N       # every env crossed its time limit and was re-drawn on the device
+    assert n_contact > 50    # the gripper stand-in really touched the floor / the switch
+    if action_type == "absolute_eef_action":
+        assert n_active > 0  # and some presses toggled the switch
+
+
+def _demo_actions(obs):
+    """create_demonstration_policy of the reference (robot_push_button.py:231-300), ABS_EEF variant, vectorised."""
+    tcp, sw, active = obs[:, 6:9], obs[:, 9:12], obs[:, 12] > 0.5
+    above = (tcp[:, 2] > sw[:, 2]) & (np.linalg.norm(tcp[:, :2] - sw[:, :2], axis=1) < 0.01)
+    a = sw.copy()
+    a[:, 2] += 0.05
+    low = tcp[:, 2] < sw[:, 2] + 0.02
+    a[low, :2] = tcp[low, :2]
+    a[above] = sw[above]
+    end = np.tile(np.array([-0.3, -0.2, 0.3]), (len(obs), 1))
+    near = np.linalg.norm(sw[:, :2] - tcp[:, :2], axis=1) < 0.05
+    end[near, 2] = sw[near, 2] + 0.1
+    a[active] = end[active]
+    diff = a - tcp
+    big = np.max(np.abs(diff), axis=1)
+    s = np.where(big > 0.05, 0.05 / np.maximum(big, 1e-12), 1.0)
+    return np.concatenate([tcp + diff * s[:, None], np.zeros((len(obs), 1))], axis=1)
+
+
+def test_button_push_demonstration_policy(oracle_mod):
+    # closed loop: the reference's scripted policy computed from the GPU observations drives both sides
+    import mujoco_sim_amd as m
+
+    N = 64
+    venv = m.HipVectorEnv("robot_push_button", N, seed=77, autoreset="disabled", action_type="absolute_eef_action")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 77, autoreset=2, nthreads=8, action_type=1)
+    venv.reset()
+    ob.reset()
+    obs = venv.flat_obs.cpu().numpy().copy()
+    done = np.zeros(N, bool)
+    success = np.zeros(N, bool)
+    for t in range(100):
+        a = _demo_actions(obs)
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        live = ~done
+        np.testing.assert_allclose(g["obs"][live], o["obs"][live], rtol=0, atol=1e-8, err_msg=f"step {t}")
+        for k in ("step_type", "terminated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[live].astype(int), np.asarray(o[k])[live].astype(int)), (k, t)
+        success |= live & g["is_success"].astype(bool)
+        done |= g["step_type"] == 2
+        obs = g["obs"]
+        if done.all():
+            break
+    assert success.sum() >= N // 2, success.sum()  # the scripted policy solves most episodes

@@ -232,20 +232,59 @@ def merge(parts):
     return m, com, I
 
 
-links = []  # per joint j: dict(E_const, r, axis, m, c, I)
+def quat_to_mat(q):
+    w, x, y, z = q
+    n = (w * w + x * x + y * y + z * z) ** 0.5
+    w, x, y, z = w / n, x / n, y / n, z / n
+    return [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+            [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+            [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+
+
+def transpose_num(A):
+    return [[A[j][i] for j in range(3)] for i in range(3)]
+
+
 Rf = quat_to_mat_exact(flange_quat)
-for j in range(NJ):
-    b = j + 1
-    m, c, I = link_inertial(b)
-    if j == NJ - 1:
-        # lumped gripper payload rigidly attached at the flange site (deviation D-1)
-        pc = [flange_pos[k] + num_matvec(Rf, pl_ipos)[k] for k in range(3)]
-        pD = [[pl_diag[0], 0, 0], [0, pl_diag[1], 0], [0, 0, pl_diag[2]]]
-        pI = num_matmul(num_matmul(Rf, pD), [[Rf[jj][i] for jj in range(3)] for i in range(3)])
-        payload = (pl_mass, pc, pI)
-        m, c, I = merge([(m, c, I), payload])
-    links.append(dict(C=quat_to_mat_exact(body_quat[b]), r=body_pos[b], axis=jnt_axis[j], m=m, c=c, I=I))
-payload_com = payload[1]
+
+
+def flange_part(mass, ipos, iquat, diag):
+    """rigid part given in the flange frame -> (m, com, Icom) in the wrist_3 frame"""
+    R = num_matmul(Rf, quat_to_mat(iquat) if iquat is not None else [[1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    com = [flange_pos[k] + num_matvec(Rf, ipos)[k] for k in range(3)]
+    D = [[diag[0], 0, 0], [0, diag[1], 0], [0, 0, diag[2]]]
+    return (mass, com, num_matmul(num_matmul(R, D), transpose_num(R)))
+
+
+GRIPPER = flange_part(pl_mass, pl_ipos, None, pl_diag)  # lumped 2F-85 (deviation D-1)
+
+
+def wrist_camera_part():
+    """box + sphere of default density, concentric (entities/camera.py:78-88), robot_push_button.py:90-96"""
+    import math
+
+    bx, by, bz = spec_array("MJS_CAM_BOX_HALF")
+    rs = spec_scalar("MJS_CAM_SPHERE_RADIUS")
+    rho = spec_scalar("MJS_GEOM_DENSITY")
+    mb, ms = rho * 8 * bx * by * bz, rho * 4.0 / 3.0 * math.pi * rs ** 3
+    Is = 0.4 * ms * rs * rs
+    diag = [mb * (by * by + bz * bz) / 3 + Is, mb * (bx * bx + bz * bz) / 3 + Is, mb * (bx * bx + by * by) / 3 + Is]
+    return flange_part(mb + ms, spec_array("MJS_WCAM_POS"), spec_array("MJS_WCAM_QUAT"), diag)
+
+
+def make_links(extra_parts):
+    """per joint j: dict(C, r, axis, m, c, I); extra_parts = un-gravity-compensated rigid parts on link 6.
+    Returns (links, (mass, com) of the un-compensated parts together)"""
+    links = []
+    for j in range(NJ):
+        b = j + 1
+        m, c, I = link_inertial(b)
+        if j == NJ - 1:
+            m, c, I = merge([(m, c, I)] + list(extra_parts))
+        links.append(dict(C=quat_to_mat_exact(body_quat[b]), r=body_pos[b], axis=jnt_axis[j], m=m, c=c, I=I))
+    um = sum(p[0] for p in extra_parts)
+    ucom = [sum(p[0] * p[1][k] for p in extra_parts) / um for k in range(3)]
+    return links, (um, ucom)
 
 
 def clean(x):
@@ -260,7 +299,8 @@ def joint_rot(axis, c, s):
     raise ValueError(axis)
 
 
-def build():
+def build(links, uncomp):
+    pl_mass, payload_com = uncomp
     cs = [sym(f"c[{j}]") for j in range(NJ)]
     sn = [sym(f"s[{j}]") for j in range(NJ)]
     qd = [sym(f"qd[{j}]") for j in range(NJ)]
@@ -406,8 +446,9 @@ def evaluate(vals, env):
     return [v.c if v.is_const else v.sign * ev(v.id) for v in vals]
 
 
-def model_constants(M):
-    """mj_setConst quantities at qpos0 = 0: dof_invweight0 = diag(M^-1), meaninertia = mean(diag M)"""
+def model_constants(M, links, body_com_local):
+    """mj_setConst quantities at qpos0 = 0: dof_invweight0 = diag(M^-1), meaninertia = mean(diag M),
+    body_invweight0 (translation, rotation) of a body rigidly attached to link 6 with COM body_com_local"""
     import numpy as np
 
     env = {f"c[{j}]": 1.0 for j in range(NJ)}
@@ -421,55 +462,81 @@ def model_constants(M):
             A[i, j] = A[j, i] = flat[k]
             k += 1
     A += np.eye(NJ) * spec_scalar("MJS_UR_ARMATURE")
-    return np.diag(np.linalg.inv(A)), float(np.trace(A) / NJ)
+    Ainv = np.linalg.inv(A)
+    # forward kinematics at q = 0 (base frame; the base's own Rz(180deg) does not change the traces)
+    R, p = np.eye(3), np.zeros(3)
+    axes, anchors = [], []
+    for L in links:
+        p = p + R @ np.array(L["r"])
+        R = R @ np.array(L["C"], dtype=float)
+        axes.append(R @ np.array(L["axis"]))
+        anchors.append(p.copy())
+    P = p + R @ np.array(body_com_local)
+    Jt = np.stack([np.cross(axes[j], P - anchors[j]) for j in range(NJ)], axis=1)
+    Jr = np.stack(axes, axis=1)
+    tran = float(np.trace(Jt @ Ainv @ Jt.T) / 3)
+    rot = float(np.trace(Jr @ Ainv @ Jr.T) / 3)
+    return np.diag(Ainv), float(np.trace(A) / NJ), tran, rot
 
 
-def main():
-    tau, M = build()
+def emit_variant(prefix, links, uncomp, body_com_local, what):
+    tau, M = build(links, uncomp)
     out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
     out_M = [(f"M[{i * (i + 1) // 2 + j}]", M[i][j]) for i in range(NJ) for j in range(i + 1)]
     lb, cb = emit(out_bias)
     lm, cm = emit(out_M)
     nb, nm = sum(cb.values()), sum(cm.values())
-    invw_arr, meaninertia = model_constants(M)
-    invw = ", ".join(repr(float(x)) for x in invw_arr)
-    header = f"""// mjs_ur5e_dyn_gen.h — GENERATED by tools/gen_ur5e_dynamics.py from include/mjs_scene_spec.h.
-// DO NOT EDIT. Straight-line float64 code for the UR5e (+ lumped gripper payload, D-1):
-//   ur5e_M_gen:    M[21], lower triangle (row-major, M[i*(i+1)/2+j], j<=i) of the joint-space inertia
-//                  matrix WITHOUT joint armature (role of mj_crb; reference path: Physics.step,
-//                  SURVEY App. B).                                  {nm} ops before FMA fusion
-//   ur5e_bias_gen: bias[6], Coriolis/centrifugal forces of the whole arm minus the joint torque of
-//                  the payload's weight, i.e. qfrc_bias - qfrc_gravcomp of MuJoCo (gravcomp=1 on the
-//                  arm bodies only, entities/robots/robot.py:80-82), so that
-//                  qfrc_smooth = -bias + actuator force.             {nb} ops before FMA fusion
-// inputs: c[j] = cos(q_j), s[j] = sin(q_j), qd[j] = joint velocity. The two functions share no
-// sub-expression, which is what lets the kernel run them on two different wavefronts.
+    invw, meaninertia, tran, rot = model_constants(M, links, body_com_local)
+    up = prefix.upper()
+    text = f"""
+// ---- variant "{prefix}": {what}
+// mj_setConst quantities of this model at qpos0 = 0 (armature included)
+constexpr double {up}_DOF_INVWEIGHT0[6] = {{{", ".join(repr(float(x)) for x in invw)}}};
+constexpr double {up}_MEANINERTIA = {meaninertia!r};
+constexpr double {up}_EEF_BODY_INVWEIGHT0[2] = {{{tran!r}, {rot!r}}};  // translation, rotation: contact rows of the EEF body
+
+MJS_DEV void {prefix}_M_gen(const double* c, const double* s, double* M) {{  // {nm} ops before FMA fusion
+""" + "\n".join(lm) + f"""
+}}
+
+MJS_DEV void {prefix}_bias_gen(const double* c, const double* s, const double* qd, double* bias) {{  // {nb} ops before FMA fusion
+""" + "\n".join(lb) + """
+}
+"""
+    print(f"variant {prefix}: M {nm} ops, bias {nb} ops, eef invweight0 = ({tran:.6g}, {rot:.6g})")
+    return text
+
+
+def main():
+    header = """// mjs_ur5e_dyn_gen.h — GENERATED by tools/gen_ur5e_dynamics.py from include/mjs_scene_spec.h.
+// DO NOT EDIT. Straight-line float64 code for the UR5e with a rigid end-effector lump (D-1), per scene:
+//   <v>_M_gen:    M[21], lower triangle (row-major, M[i*(i+1)/2+j], j<=i) of the joint-space inertia
+//                 matrix WITHOUT joint armature (role of mj_crb; reference path: Physics.step, SURVEY App. B)
+//   <v>_bias_gen: bias[6], Coriolis/centrifugal forces of the whole arm minus the joint torque of the
+//                 weight of the un-gravity-compensated end-effector parts, i.e. qfrc_bias - qfrc_gravcomp
+//                 of MuJoCo (gravcomp=1 on the arm bodies only, entities/robots/robot.py:80-82), so that
+//                 qfrc_smooth = -bias + actuator force
+// inputs: c[j] = cos(q_j), s[j] = sin(q_j), qd[j] = joint velocity. M and bias share no sub-expression,
+// which is what lets the kernel run them on two different wavefronts.
 #pragma once
 #ifndef MJS_DEV
 #define MJS_DEV __device__ __forceinline__
 #endif
-
-// mj_setConst quantities of this model at qpos0 = 0 (armature included): used by the joint-limit rows
-constexpr double UR5E_DOF_INVWEIGHT0[6] = {{{invw}}};
-constexpr double UR5E_MEANINERTIA = {meaninertia!r};
-
-MJS_DEV void ur5e_M_gen(const double* c, const double* s, double* M) {{
 """
-    mid = """
-}
-
-MJS_DEV void ur5e_bias_gen(const double* c, const double* s, const double* qd, double* bias) {
-"""
-    tail = """
-}
-
+    text = header
+    links, uncomp = make_links([GRIPPER])
+    text += emit_variant("ur5e", links, uncomp, GRIPPER[1], "Robot-Reach: UR5e + lumped 2F-85 gripper (robot_reach.py:90-95)")
+    cam = wrist_camera_part()
+    links2, uncomp2 = make_links([GRIPPER, cam])
+    text += emit_variant("ur5e_bp", links2, uncomp2, GRIPPER[1], "Button-Push: + wrist-camera geoms' mass at the flange (robot_push_button.py:90-96)")
+    text += """
 MJS_DEV void ur5e_dynamics_gen(const double* c, const double* s, const double* qd, double* M, double* bias) {
   ur5e_M_gen(c, s, M);
   ur5e_bias_gen(c, s, qd, bias);
 }
 """
-    OUT.write_text(header + "\n".join(lm) + mid + "\n".join(lb) + tail)
-    print(f"wrote {OUT} : M {nm} ops {cm} | bias {nb} ops {cb}")
+    OUT.write_text(text)
+    print(f"wrote {OUT}")
 
 
 if __name__ == "__main__":
