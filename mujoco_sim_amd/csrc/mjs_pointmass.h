@@ -295,6 +295,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
     episode_init(p, i, st);
     newflags = 0;
     obs[0] = st.qx; obs[1] = st.qy; obs[2] = st.tx; obs[3] = st.ty;
+    ncon = count_contacts(st);  // d->ncon as read after the reset's mj_forward
   }
   store_state(p, i, st);
   p.flags[i] = newflags;

@@ -455,6 +455,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     episode_init(e);
     e->reset_pending = 0;
     write_obs(e, out->obs);
+    out->ncon = count_contacts(d); /* d->ncon as the caller would read it after the reset's mj_forward */
   }
 }
 
@@ -522,6 +523,7 @@ void om_batch_reset(om_batch* b, om_step_out* outs) {
 }
 void om_batch_step(om_batch* b, const double* actions, om_step_out* outs, int nthreads) {
   int A = om_action_dim(b->envs[0].cfg.task);
+  if (b->envs[0].cfg.task == OM_TASK_BUTTON_PUSH && b->envs[0].cfg.action_type == OM_ACTION_ABS_EEF) A = 4; /* robot_push_button.py:177 */
 #pragma omp parallel for num_threads(nthreads) schedule(static)
   for (int i = 0; i < b->n; i++) om_env_step(&b->envs[i], actions + (size_t)i * A, &outs[i]);
 }
