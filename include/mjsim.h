@@ -69,7 +69,8 @@ typedef struct {
   int32_t kernel_variant;       /* MJS_VARIANT_*: 0 = default (tuned); others for A/B profiling */
   double time_limit;            /* composer.Environment(time_limit=...) (__init__.py:21); <=0 = task default */
   int32_t action_type;          /* MJS_ACTION_* (Button-Push only) */
-  int32_t reserved0;            /* must be 0 */
+  int32_t button_disturbances;  /* Button-Push only: after each control step an active, released switch is
+                                 * deactivated with probability 0.01 from the env's stream (robot_push_button.py:159-165) */
 } mjs_config;
 
 /* Per-step outputs. Device pointers, caller-owned, any may be NULL.
@@ -143,6 +144,12 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
  * on n independent inputs: flange poses T_dev [n, 12] (row-major 3x3 rotation then translation),
  * guesses [n, 6] -> q_dev [n, 6], ok_dev [n]. No handle needed; device = current HIP device. */
 int mjs_debug_ur5e_ik(const double* T_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream);
+
+/* Replaces Robot.get_joint_positions_from_tcp_pose (entities/robots/robot.py:33-37,140-151) for the top-down
+ * TCP orientation every task uses: n TCP positions [n, 3] + current joints [n, 6] -> closest IK solution
+ * q_dev [n, 6] (the guess itself where none exists), ok_dev [n]. What a host policy needs to turn a
+ * Cartesian target into a Button-Push joint action (robot_push_button.py:287-291). */
+int mjs_ur5e_tcp_to_joints(const double* tcp_pos_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream);
 
 /* checkpoint / resume of the physics+task state: float64 [state_dim, N] ... */
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);

@@ -15,6 +15,7 @@ from ._native import MjsError, build  # noqa: F401
 from .environments.dmc2gym import DMCEnvironmentAdapter, HipEnvironment, TimeStep  # noqa: F401
 from .environments.tasks.point_reach import PointMassReachTask
 from .environments.tasks.robot_reach import RobotReachConfig, RobotReachTask
+from .environments.tasks.robot_push_button import RobotPushButtonTask
 from .vector_env import TASKS, HipVectorEnv  # noqa: F401
 
 __version__ = "0.1.0"
@@ -42,6 +43,8 @@ registry = {
     "mujoco_sim/point_mass_reach_state-v0": (partial(make_point_mass_reach_env, PointMassReachTask, max_steps=50),
                                              {"observation_type": "state_observations"}),
     "mujoco_sim/robot_reach_state-v0": (_make_robot_reach_env, {}),
+    "mujoco_sim/robot_push_button_state-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
+                                              {"observation_type": RobotPushButtonTask.STATE_OBS, "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
 }
 
 

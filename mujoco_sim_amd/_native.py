@@ -26,7 +26,7 @@ FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
 EXPORTED_SYMBOLS = [
     "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_action_dim_for", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
     "mjs_create", "mjs_destroy", "mjs_last_error", "mjs_seed", "mjs_reset", "mjs_step", "mjs_rollout",
-    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik",
+    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik", "mjs_ur5e_tcp_to_joints",
 ]
 
 
@@ -34,7 +34,7 @@ class MjsConfig(C.Structure):
     _fields_ = [
         ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
-        ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("reserved0", C.c_int32),
+        ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("button_disturbances", C.c_int32),
     ]
 
 
@@ -100,6 +100,7 @@ def lib() -> C.CDLL:
     L.mjs_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_debug_ur5e_ik.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.mjs_ur5e_tcp_to_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mjs_render.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.mjs_get_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_set_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -379,6 +379,13 @@ __device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_fla
   return o;
 }
 
+__device__ __noinline__ uint8_t disturb(DevRng rng, int i, uint8_t flags) {
+  RngCursor c = rng_open(rng, i);
+  double u = rng_uniform(rng, i, c, 0.0, 1.0);
+  rng_close(rng, i, c);
+  return u < 0.01 ? (uint8_t)(flags & ~FLAG_SWITCH_ACTIVE) : flags;
+}
+
 template <bool IS_RESET>
 __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   const int i = blockIdx.x * 64 + threadIdx.x;
@@ -449,6 +456,8 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
     st.time += MJS_RR_PHYSICS_DT;
     switch_update(touch, flags);  // Switch.after_substep (switch.py:71-72)
   }
+  // after_step (robot_push_button.py:159-165): rand() is drawn only for an active, released switch
+  if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = disturb(p.rng, i, flags);
 #pragma unroll
   for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);
   rr::fk_cs(cs, sn, c);

@@ -17,6 +17,7 @@ struct KernelParams {
   int autoreset;
   int terminate_on_success;
   int action_type;
+  int button_disturbances;
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]

@@ -94,6 +94,17 @@ __global__ void debug_ik_kernel(const double* T, const double* guess, double* q,
   ok[i] = found;
 }
 
+__global__ void tcp_to_joints_kernel(const double* pos, const double* guess, double* q, uint8_t* ok, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double p3[3], g[6], out[6];
+  for (int k = 0; k < 3; k++) p3[k] = pos[(size_t)i * 3 + k];
+  for (int k = 0; k < 6; k++) { g[k] = guess[(size_t)i * 6 + k]; out[k] = g[k]; }
+  bool found = rr::tcp_pose_to_joints(p3, g, out);
+  for (int k = 0; k < 6; k++) q[(size_t)i * 6 + k] = found ? out[k] : g[k];
+  ok[i] = found;
+}
+
 KernelParams make_params(const mjs_handle* h, const double* actions, const uint8_t* mask, const mjs_outputs* out) {
   KernelParams p;
   p.N = h->cfg.num_envs;
@@ -101,6 +112,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.autoreset = h->cfg.autoreset;
   p.terminate_on_success = h->cfg.terminate_on_success;
   p.action_type = h->cfg.action_type;
+  p.button_disturbances = h->cfg.button_disturbances;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -326,6 +338,13 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
 int mjs_debug_ur5e_ik(const double* T_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream) {
   if (!T_dev || !guess_dev || !q_dev || !ok_dev || n < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_debug_ur5e_ik: bad argument");
   debug_ik_kernel<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(T_dev, guess_dev, q_dev, ok_dev, n);
+  HIP_TRY(nullptr, hipGetLastError());
+  return MJS_OK;
+}
+
+int mjs_ur5e_tcp_to_joints(const double* tcp_pos_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream) {
+  if (!tcp_pos_dev || !guess_dev || !q_dev || !ok_dev || n < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_ur5e_tcp_to_joints: bad argument");
+  tcp_to_joints_kernel<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(tcp_pos_dev, guess_dev, q_dev, ok_dev, n);
   HIP_TRY(nullptr, hipGetLastError());
   return MJS_OK;
 }

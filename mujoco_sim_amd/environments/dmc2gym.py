@@ -53,6 +53,9 @@ class HipEnvironment:
         kwargs = {}
         if hasattr(task, "config") and getattr(task.config, "terminate_on_success", False):
             kwargs["terminate_on_success"] = True
+        if hasattr(task, "action_type") and task.task_name == "robot_push_button":
+            kwargs["action_type"] = task.action_type
+            kwargs["button_disturbances"] = task.button_disturbances
         self._venv = HipVectorEnv(task.task_name, 1, device=device, autoreset="next_step", reward_type=task.reward_type,
                                   time_limit=(1e300 if np.isinf(time_limit) else time_limit),
                                   observation_type=getattr(task, "observation_type", STATE_OBS),

@@ -91,7 +91,8 @@ class HipVectorEnv:
     def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
-                 observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None):
+                 observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
+                 button_disturbances: bool = False):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -117,7 +118,7 @@ class HipVectorEnv:
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
                             time_limit=float(time_limit) if time_limit is not None else -1.0,
-                            action_type=_ACTION_IDS.get(action_type, 0), reserved0=0)
+                            action_type=_ACTION_IDS.get(action_type, 0), button_disturbances=int(bool(button_disturbances)))
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -248,6 +249,19 @@ class HipVectorEnv:
         assert out.shape == (self.num_envs, height, width, 3) and out.dtype == torch.uint8 and out.is_contiguous()
         nat.check(self._lib.mjs_render(self._h, 0, height, width, C.c_void_p(out.data_ptr()), self._stream()), self._h)
         return out
+
+    def tcp_to_joints(self, tcp_positions, joint_guess):
+        """Robot.get_joint_positions_from_tcp_pose for the top-down orientation (robot.py:140-151), batched on
+        the device: ([n, 3], [n, 6]) -> (q [n, 6], ok [n] bool); q = the guess where no IK solution exists."""
+        pos = torch.as_tensor(tcp_positions, device=self.device).to(torch.float64).contiguous()
+        guess = torch.as_tensor(joint_guess, device=self.device).to(torch.float64).contiguous()
+        n = pos.shape[0]
+        assert pos.shape == (n, 3) and guess.shape == (n, 6)
+        q = torch.empty(n, 6, dtype=torch.float64, device=self.device)
+        ok = torch.empty(n, dtype=torch.uint8, device=self.device)
+        nat.check(self._lib.mjs_ur5e_tcp_to_joints(C.c_void_p(pos.data_ptr()), C.c_void_p(guess.data_ptr()), C.c_void_p(q.data_ptr()),
+                                                   C.c_void_p(ok.data_ptr()), n, self._stream()), self._h)
+        return q, ok.bool()
 
     def get_rng_state(self):
         """(mt uint32 [624, N], pos int32 [N]) — the per-env numpy-legacy MT19937 streams."""

@@ -140,6 +140,7 @@ typedef struct {
   double time_limit;         /* composer.Environment(time_limit=...) */
   int terminate_on_success;  /* Robot-Reach only: opt-in (deviation D-2) */
   int action_type;           /* Button-Push only */
+  int button_disturbances;   /* Button-Push only: robot_push_button.py:159-165 */
 } om_task_config;
 
 #define OM_MAXOBS 16

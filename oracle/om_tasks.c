@@ -408,6 +408,10 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) switch_update(e); /* Switch.after_substep (switch.py:71-72) */
   }
   /* after_step + reward/discount/termination */
+  if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.button_disturbances) {
+    /* robot_push_button.py:159-165: rand() is only drawn when the switch is active and not pressed */
+    if (e->switch_active && !e->switch_pressed && om_rng_uniform(&e->rng, 0.0, 1.0) < 0.01) e->switch_active = 0;
+  }
   int terminate = 0, success = 0;
   double reward = 0, discount = 1;
   if (e->cfg.task == OM_TASK_POINTMASS) {

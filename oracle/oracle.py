@@ -27,6 +27,7 @@ class TaskConfig(C.Structure):
         ("time_limit", C.c_double),
         ("terminate_on_success", C.c_int),
         ("action_type", C.c_int),
+        ("button_disturbances", C.c_int),
     ]
 
 
@@ -156,7 +157,8 @@ class OracleBatch:
 
     def __init__(self, task: int, n: int, base_seed: int = 0, *, reward_type: int | None = None,
                  autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
-                 terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None):
+                 terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None,
+                 button_disturbances: bool = False):
         L = lib()
         cfg = TaskConfig()
         L.om_default_config(task, C.byref(cfg))
@@ -168,6 +170,7 @@ class OracleBatch:
         cfg.terminate_on_success = int(terminate_on_success)
         if action_type is not None:
             cfg.action_type = action_type
+        cfg.button_disturbances = int(button_disturbances)
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
         self.obs_dim, self.action_dim = L.om_obs_dim(task), L.om_action_dim(task)
         if task == TASK_BUTTON_PUSH and cfg.action_type == ACTION_ABS_EEF:

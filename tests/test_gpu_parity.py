@@ -437,39 +437,26 @@ def test_button_push_parity_with_oracle(oracle_mod, action_type, autoreset):
         assert n_active > 0  # and some presses toggled the switch
 
 
-def _demo_actions(obs):
-    """create_demonstration_policy of the reference (robot_push_button.py:231-300), ABS_EEF variant, vectorised."""
-    tcp, sw, active = obs[:, 6:9], obs[:, 9:12], obs[:, 12] > 0.5
-    above = (tcp[:, 2] > sw[:, 2]) & (np.linalg.norm(tcp[:, :2] - sw[:, :2], axis=1) < 0.01)
-    a = sw.copy()
-    a[:, 2] += 0.05
-    low = tcp[:, 2] < sw[:, 2] + 0.02
-    a[low, :2] = tcp[low, :2]
-    a[above] = sw[above]
-    end = np.tile(np.array([-0.3, -0.2, 0.3]), (len(obs), 1))
-    near = np.linalg.norm(sw[:, :2] - tcp[:, :2], axis=1) < 0.05
-    end[near, 2] = sw[near, 2] + 0.1
-    a[active] = end[active]
-    diff = a - tcp
-    big = np.max(np.abs(diff), axis=1)
-    s = np.where(big > 0.05, 0.05 / np.maximum(big, 1e-12), 1.0)
-    return np.concatenate([tcp + diff * s[:, None], np.zeros((len(obs), 1))], axis=1)
-
-
-def test_button_push_demonstration_policy(oracle_mod):
-    # closed loop: the reference's scripted policy computed from the GPU observations drives both sides
+@pytest.mark.parametrize("action_type,disturb", [("absolute_eef_action", False), ("absolute_joint_action", False), ("absolute_eef_action", True)])
+def test_button_push_demonstration_policy(oracle_mod, action_type, disturb):
+    # closed loop: the reference's scripted policy (host mirror, computed from the GPU observations; the joint
+    # variant goes through the device IK entry point) drives both sides
     import mujoco_sim_amd as m
 
-    N = 64
-    venv = m.HipVectorEnv("robot_push_button", N, seed=77, autoreset="disabled", action_type="absolute_eef_action")
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 77, autoreset=2, nthreads=8, action_type=1)
+    N = 256 if disturb else 64
+    task = m.RobotPushButtonTask(observation_type="state_observations", action_type=action_type, button_disturbances=disturb)
+    venv = m.HipVectorEnv("robot_push_button", N, seed=77, autoreset="disabled", action_type=action_type, button_disturbances=disturb)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 77, autoreset=2, nthreads=8, action_type=int(action_type == "absolute_eef_action"),
+                                button_disturbances=disturb)
+    plain = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 77, autoreset=2, nthreads=8, action_type=int(action_type == "absolute_eef_action"))
     venv.reset()
     ob.reset()
-    obs = venv.flat_obs.cpu().numpy().copy()
+    plain.reset()
     done = np.zeros(N, bool)
     success = np.zeros(N, bool)
+    n_disturbed = 0
     for t in range(100):
-        a = _demo_actions(obs)
+        a = task.demonstration_actions(venv).cpu().numpy()
         venv.step(torch.from_numpy(a))
         o = ob.step(a)
         g = _gpu_result(venv)
@@ -477,9 +464,35 @@ def test_button_push_demonstration_policy(oracle_mod):
         np.testing.assert_allclose(g["obs"][live], o["obs"][live], rtol=0, atol=1e-8, err_msg=f"step {t}")
         for k in ("step_type", "terminated", "is_success", "ncon"):
             assert np.array_equal(np.asarray(g[k])[live].astype(int), np.asarray(o[k])[live].astype(int)), (k, t)
+        n_disturbed += int((plain.step(a)["obs"][:, 12] != o["obs"][:, 12]).sum())  # vs the same actions without disturbances
         success |= live & g["is_success"].astype(bool)
         done |= g["step_type"] == 2
-        obs = g["obs"]
         if done.all():
             break
     assert success.sum() >= N // 2, success.sum()  # the scripted policy solves most episodes
+    assert (n_disturbed > 0) == disturb, n_disturbed
+
+
+def test_button_push_state_env_id(oracle_mod):
+    # single-env gymnasium-style surface: dict keys follow the action type (robot_push_button.py:113-119)
+    import mujoco_sim_amd as m
+
+    env = m.make("mujoco_sim/robot_push_button_state-v0")
+    env.seed(5)
+    obs, _ = env.reset()
+    assert list(obs.keys()) == ["ur5e/joint_configuration", "unnamed_model/position", "unnamed_model/active"]
+    assert env.action_space.shape == (7,)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, 1, 5)
+    o = ob.reset()
+    np.testing.assert_allclose(obs["ur5e/joint_configuration"], o["obs"][0, :6], atol=ATOL)
+    np.testing.assert_allclose(obs["unnamed_model/position"], o["obs"][0, 9:12], atol=ATOL)
+    a = env.action_space.sample().astype(np.float64)
+    obs, reward, terminated, truncated, info = env.step(a)
+    o = ob.step(a[None])
+    np.testing.assert_allclose(obs["ur5e/joint_configuration"], o["obs"][0, :6], atol=ATOL)
+    assert reward == o["reward"][0] and not terminated and not truncated
+    env2 = m.make("mujoco_sim/robot_push_button_state-v0", action_type="absolute_eef_action")
+    obs, _ = env2.reset()
+    assert list(obs.keys()) == ["ur5e/tcp_position", "unnamed_model/position", "unnamed_model/active"] and env2.action_space.shape == (4,)
+    env.close()
+    env2.close()
