@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach"])
+    ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
@@ -59,6 +59,10 @@ def make_actions(task, T, N, device, seed):
     rs = np.random.RandomState(seed)
     if task == "point_mass_reach":
         a = rs.uniform(-0.05, 0.05, (T, N, 2)).astype(np.float32).astype(np.float64)
+    elif task == "robot_push_button":
+        # 7-D absolute joint targets (the registered action type): a top-down nominal pose +- a box that
+        # reaches the floor and the switch
+        a = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04]) + rs.uniform(-1, 1, (T, N, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04])
     else:
         a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (T, N, 3))
     return torch.from_numpy(a).to(device)
@@ -80,7 +84,7 @@ def host_cores():
 def cpu_baseline(task, n_envs, seconds):
     import oracle
 
-    tid = oracle.TASK_ROBOT_REACH if task == "robot_reach" else oracle.TASK_POINTMASS
+    tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH}[task]
     cores = host_cores()
     b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores)
     b.reset()
@@ -145,7 +149,8 @@ def main():
         bytes_per_launch = bytes_per_env_step * n_local
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         line = {
-            "metric": "env-steps/sec at N_envs=4096, Robot-Reach" if args.task == "robot_reach" else "env-steps/sec, Pointmass-Reach",
+            "metric": {"robot_reach": "env-steps/sec at N_envs=4096, Robot-Reach", "point_mass_reach": "env-steps/sec, Pointmass-Reach",
+                       "robot_push_button": "env-steps/sec, Button-Push (state obs)"}[args.task],
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

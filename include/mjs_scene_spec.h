@@ -263,6 +263,12 @@ MJS_K float MJS_UR_BLACK[3] = {0.033f, 0.033f, 0.033f};
 MJS_K int   MJS_UR_COL_IS_JOINT[MJS_UR_NCOLGEOM] = {1, 1, 0, 1, 0, 1, 1, 1, 0, 0};  /* urblue vs linkgray */
 MJS_K float MJS_UR_BASE_STANDIN[2] = {0.075f, 0.05f};           /* cylinder radius, half-height at z = 0.05 */
 MJS_K float MJS_G2F85_STANDIN_HALF[3] = {0.04f, 0.02f, 0.07f};   /* box in the flange frame, centred at z = 0.07 */
+/* Button-Push scene [REF]: switch.py:25-37 (white box, button red / green when active, switch.py:59),
+ * entities/camera.py:78-88 (camera bodies: black box + lens sphere) */
+MJS_K float MJS_SW_BOX_RGB[3] = {1.0f, 1.0f, 1.0f};
+MJS_K float MJS_SW_BUTTON_RGB_OFF[3] = {1.0f, 0.0f, 0.0f};
+MJS_K float MJS_SW_BUTTON_RGB_ON[3] = {0.0f, 1.0f, 0.0f};
+MJS_K float MJS_CAM_BODY_RGB[3] = {0.0f, 0.0f, 0.0f};
 /* [REF] empty_robot_arena.py:24-26: six positional lights at (x, +-x, 3), x in {-3, 3, 0.5} */
 MJS_K float MJS_RR_LIGHT_POS[6][3] = {{-3.0f, -3.0f, 3.0f}, {-3.0f, 3.0f, 3.0f}, {3.0f, 3.0f, 3.0f},
                                       {3.0f, -3.0f, 3.0f},  {0.5f, 0.5f, 3.0f},  {0.5f, -0.5f, 3.0f}};

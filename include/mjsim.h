@@ -135,9 +135,10 @@ int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_o
 
 /* Replaces Camera.get_rgb_image -> physics.render(height, width, camera_id) (entities/camera.py:94-103)
  * and DMCEnvironmentAdapter.render (dmc2gym.py:165-168) for the task's scene camera
- * (camera = MJS_CAMERA_SCENE): rgb_dev uint8 [N, height, width, 3]. Own ray caster, cannot match
- * OpenGL pixels. */
-enum { MJS_CAMERA_SCENE = 0 };
+ * (camera = MJS_CAMERA_SCENE) and, for Button-Push, the camera mounted on the flange
+ * (MJS_CAMERA_WRIST, robot_push_button.py:90-96): rgb_dev uint8 [N, height, width, 3]. Own ray caster,
+ * cannot match OpenGL pixels. */
+enum { MJS_CAMERA_SCENE = 0, MJS_CAMERA_WRIST = 1 };
 int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uint8_t* rgb_dev, void* stream);
 
 /* Test hook: the device implementation of ur5e.inverse_kinematics_closest (entities/robots/robot.py:33-37)

@@ -35,7 +35,7 @@ def _make_robot_reach_env(max_steps=100, device="cuda:0", **kwargs):
 
 
 # registry ids of the reference (mujoco_sim/__init__.py:26-40): point_mass_reach-v0 is the VISUAL
-# variant (64x64 top-down camera image + position). robot_push_button_visual-v0 is not built yet.
+# variant (64x64 top-down camera image + position); robot_push_button_visual-v0 is joints + wrist and scene camera images.
 # The two *_state ids are additions for the state-observation configs of BASELINE.json.
 registry = {
     "mujoco_sim/point_mass_reach-v0": (partial(make_point_mass_reach_env, PointMassReachTask, max_steps=50),
@@ -43,6 +43,10 @@ registry = {
     "mujoco_sim/point_mass_reach_state-v0": (partial(make_point_mass_reach_env, PointMassReachTask, max_steps=50),
                                              {"observation_type": "state_observations"}),
     "mujoco_sim/robot_reach_state-v0": (_make_robot_reach_env, {}),
+    # mujoco_sim/__init__.py:31-39
+    "mujoco_sim/robot_push_button_visual-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
+                                               {"observation_type": RobotPushButtonTask.VISUAL_OBS, "image_resolution": 96,
+                                                "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
     "mujoco_sim/robot_push_button_state-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
                                               {"observation_type": RobotPushButtonTask.STATE_OBS, "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
 }

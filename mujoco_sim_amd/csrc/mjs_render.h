@@ -14,6 +14,7 @@
 #include "mjs_kernel_common.h"
 #include "mjs_pointmass.h"
 #include "mjs_reach.h"
+#include "mjs_button.h"
 
 namespace rend {
 
@@ -28,7 +29,9 @@ struct Cam {
 struct RenderParams {
   int N, H, W;
   const double* state;  // [state_dim][N]
-  Cam cam;
+  Cam cam;              // fixed camera, or (env_cams != nullptr) only tan_half is used
+  const float* env_cams;  // [N][12] per-env camera pose (pos, right, up, back): body-mounted cameras
+  int nprim;              // robot scenes: primitives per env
   uint8_t* out;  // [N, H, W, 3]
 };
 
@@ -159,14 +162,14 @@ MJS_DEV uint8_t to_u8(float c) {
   return (uint8_t)(int)(c * 255.0f + 0.5f);
 }
 
-MJS_DEV F3 pixel_ray(const RenderParams& p, int row, int col) {
+MJS_DEV F3 pixel_ray_axes(const RenderParams& p, int row, int col, const float* right, const float* up, const float* back) {
   float aspect = (float)p.W / (float)p.H;
   float px = (2.0f * ((float)col + 0.5f) / (float)p.W - 1.0f) * p.cam.tan_half * aspect;
   float py = (1.0f - 2.0f * ((float)row + 0.5f) / (float)p.H) * p.cam.tan_half;
-  F3 d = f3(px * p.cam.right[0] + py * p.cam.up[0] - p.cam.back[0], px * p.cam.right[1] + py * p.cam.up[1] - p.cam.back[1],
-            px * p.cam.right[2] + py * p.cam.up[2] - p.cam.back[2]);
+  F3 d = f3(px * right[0] + py * up[0] - back[0], px * right[1] + py * up[1] - back[1], px * right[2] + py * up[2] - back[2]);
   return normalize(d);
 }
+MJS_DEV F3 pixel_ray(const RenderParams& p, int row, int col) { return pixel_ray_axes(p, row, col, p.cam.right, p.cam.up, p.cam.back); }
 
 // Pointmass-Reach scene: walled_pointmass_arena.xml:12-19 + pointmass sphere + target / mocap sites
 __global__ __launch_bounds__(256) void pointmass_kernel(RenderParams p) {
@@ -224,6 +227,9 @@ constexpr int RR_NPRIM = MJS_UR_NCOLGEOM + 3;  // proxies + base stand-in + grip
 MJS_DEV void put3(float* dst, V3 v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; }
 MJS_DEV void put_rgb(float* dst, const float* rgb) { dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2]; }
 
+// arm proxies + base stand-in + gripper stand-in: records 0 .. MJS_UR_NCOLGEOM + 1
+MJS_DEV void arm_prims(const rr::Chain& c, float* out);
+
 __global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, float* prims, int N) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= N) return;
@@ -233,6 +239,89 @@ __global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, fl
   rr::Chain c;
   rr::fk(q, c);
   float* out = prims + (size_t)i * RR_NPRIM * PRIM_FLOATS;
+  arm_prims(c, out);
+  {  // target site
+    float* pr = out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS;
+    pr[0] = (float)PRIM_SPHERE;
+    pr[1] = (float)state[(size_t)(rr::S_TARGET + 0) * N + i];
+    pr[2] = (float)state[(size_t)(rr::S_TARGET + 1) * N + i];
+    pr[3] = (float)state[(size_t)(rr::S_TARGET + 2) * N + i];
+    pr[13] = MJS_RR_TARGET_RADIUS;
+    put_rgb(pr + 14, MJS_RR_TARGET_RGB);
+  }
+}
+
+// rotation matrix (row-major) of a MuJoCo quaternion (w, x, y, z), normalised first
+MJS_DEV void quat_to_mat(const double* q, double* R) {
+  const double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+MJS_DEV void camera_body_prims(V3 pos, V3 ax, V3 ay, float* box, float* lens) {
+  box[0] = (float)PRIM_BOX;
+  put3(box + 1, pos); put3(box + 4, ax); put3(box + 7, ay);
+  box[10] = (float)MJS_CAM_BOX_HALF[0]; box[11] = (float)MJS_CAM_BOX_HALF[1]; box[12] = (float)MJS_CAM_BOX_HALF[2];
+  put_rgb(box + 14, MJS_CAM_BODY_RGB);
+  lens[0] = (float)PRIM_SPHERE;
+  put3(lens + 1, pos);
+  lens[13] = (float)MJS_CAM_SPHERE_RADIUS;
+  put_rgb(lens + 14, MJS_CAM_BODY_RGB);
+}
+
+// Button-Push scene (robot_push_button.py:66-96): arm + stand-ins, wrist camera body, scene camera body,
+// switch box and button. Also writes the wrist camera pose of every env (cams [N][12]).
+constexpr int BP_NPRIM = MJS_UR_NCOLGEOM + 2 + 6;
+__global__ __launch_bounds__(64) void button_prims_kernel(const double* state, const uint8_t* flags, float* prims, float* cams, int N) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  double q[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) q[j] = state[(size_t)(bp::S_Q + j) * N + i];
+  rr::Chain c;
+  rr::fk(q, c);
+  float* out = prims + (size_t)i * BP_NPRIM * PRIM_FLOATS;
+  arm_prims(c, out);
+  // flange frame: x = wrist_3 x, y = -wrist_3 z, z = wrist_3 y (MJS_UR_FLANGE_QUAT), origin on wrist_3 y
+  const M3 R6 = c.R[6];
+  const V3 fx = R6.cx, fy = -R6.cz, fz = R6.cy;
+  const V3 fp = madd(c.p[6], MJS_UR_FLANGE_POS[1], R6.cy);
+  double Rc[9];
+  quat_to_mat(MJS_WCAM_QUAT, Rc);
+  const V3 wpos = madd(madd(madd(fp, MJS_WCAM_POS[0], fx), MJS_WCAM_POS[1], fy), MJS_WCAM_POS[2], fz);
+  const V3 wright = madd(madd(Rc[0] * fx, Rc[3], fy), Rc[6], fz);  // camera local x, y, z axes in the world
+  const V3 wup = madd(madd(Rc[1] * fx, Rc[4], fy), Rc[7], fz);
+  const V3 wback = madd(madd(Rc[2] * fx, Rc[5], fy), Rc[8], fz);
+  camera_body_prims(wpos, wright, wup, out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS, out + (MJS_UR_NCOLGEOM + 3) * PRIM_FLOATS);
+  float* cm = cams + (size_t)i * 12;
+  put3(cm, wpos); put3(cm + 3, wright); put3(cm + 6, wup); put3(cm + 9, wback);
+  {  // scene camera body (seen by the wrist camera only)
+    double Rs[9];
+    quat_to_mat(MJS_BP_CAM_QUAT, Rs);
+    camera_body_prims(v3(MJS_BP_CAM_POS[0], MJS_BP_CAM_POS[1], MJS_BP_CAM_POS[2]), v3(Rs[0], Rs[3], Rs[6]), v3(Rs[1], Rs[4], Rs[7]),
+                      out + (MJS_UR_NCOLGEOM + 4) * PRIM_FLOATS, out + (MJS_UR_NCOLGEOM + 5) * PRIM_FLOATS);
+  }
+  const V3 sw = v3(state[(size_t)(bp::S_SWITCH + 0) * N + i], state[(size_t)(bp::S_SWITCH + 1) * N + i], state[(size_t)(bp::S_SWITCH + 2) * N + i]);
+  {  // switch box
+    float* pr = out + (MJS_UR_NCOLGEOM + 6) * PRIM_FLOATS;
+    pr[0] = (float)PRIM_BOX;
+    put3(pr + 1, v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF));
+    put3(pr + 4, v3(1, 0, 0)); put3(pr + 7, v3(0, 1, 0));
+    pr[10] = pr[11] = pr[12] = (float)MJS_SW_BOX_HALF;
+    put_rgb(pr + 14, MJS_SW_BOX_RGB);
+  }
+  {  // button: red, green while the switch is active (switch.py:59)
+    float* pr = out + (MJS_UR_NCOLGEOM + 7) * PRIM_FLOATS;
+    pr[0] = (float)PRIM_CYLINDER;
+    put3(pr + 1, v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z - MJS_SW_BUTTON_HALF));
+    put3(pr + 4, v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z + MJS_SW_BUTTON_HALF));
+    pr[13] = (float)MJS_SW_BUTTON_RADIUS;
+    put_rgb(pr + 14, (flags[i] & bp::FLAG_SWITCH_ACTIVE) ? MJS_SW_BUTTON_RGB_ON : MJS_SW_BUTTON_RGB_OFF);
+  }
+}
+
+MJS_DEV void arm_prims(const rr::Chain& c, float* out) {
 #pragma unroll
   for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
     float* pr = out + g * PRIM_FLOATS;
@@ -265,15 +354,6 @@ __global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, fl
     put3(pr + 7, -R.cz);  // box axis v (half[1]); w = u x v = flange z (half[2])
     pr[10] = MJS_G2F85_STANDIN_HALF[0]; pr[11] = MJS_G2F85_STANDIN_HALF[1]; pr[12] = MJS_G2F85_STANDIN_HALF[2];
     put_rgb(pr + 14, MJS_UR_BLACK);
-  }
-  {  // target site
-    float* pr = out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS;
-    pr[0] = (float)PRIM_SPHERE;
-    pr[1] = (float)state[(size_t)(rr::S_TARGET + 0) * N + i];
-    pr[2] = (float)state[(size_t)(rr::S_TARGET + 1) * N + i];
-    pr[3] = (float)state[(size_t)(rr::S_TARGET + 2) * N + i];
-    pr[13] = MJS_RR_TARGET_RADIUS;
-    put_rgb(pr + 14, MJS_RR_TARGET_RGB);
   }
 }
 
@@ -367,16 +447,23 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
   const int pix = blockIdx.x * 256 + threadIdx.x;
   if (pix >= p.H * p.W) return;
   const int row = pix / p.W, col = pix - row * p.W;
-  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-  const F3 d = pixel_ray(p, row, col);
+  F3 eye, d;
+  if (p.env_cams) {  // body-mounted camera: pose computed per env by the primitive stage
+    const float* cm = p.env_cams + (size_t)env * 12;
+    eye = f3(cm[0], cm[1], cm[2]);
+    d = pixel_ray_axes(p, row, col, cm + 3, cm + 6, cm + 9);
+  } else {
+    eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+    d = pixel_ray(p, row, col);
+  }
   Surf s;
   s.t = INFINITY;
   s.n = f3(0, 0, 1);
   s.rgb = f3(0, 0, 0);
   hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
-  const float* pe = prims + (size_t)env * RR_NPRIM * PRIM_FLOATS;
+  const float* pe = prims + (size_t)env * p.nprim * PRIM_FLOATS;
 #pragma unroll 1
-  for (int k = 0; k < RR_NPRIM; k++) {
+  for (int k = 0; k < p.nprim; k++) {
     const float* pr = pe + k * PRIM_FLOATS;
     const int type = (int)pr[0];
     const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]), rgb = f3(pr[14], pr[15], pr[16]);

@@ -22,7 +22,8 @@ struct mjs_handle {
   uint32_t* rng_mt;  // [624][N]
   int32_t* rng_pos;  // [N]
   unsigned long long* stamps;  // diagnostic builds only
-  float* prims;                // [N][RR_NPRIM][PRIM_FLOATS] render primitive list (robot scenes, lazily allocated)
+  float* prims;                // [N][nprim][PRIM_FLOATS] render primitive list (robot scenes)
+  float* cams;                 // [N][12] wrist-camera poses (Button-Push)
   std::string err;
 };
 
@@ -194,7 +195,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);
   h->act_dim = mjs_action_dim_for(cfg->task, cfg->action_type);
-  h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr;
+  h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr; h->cams = nullptr;
   const size_t N = (size_t)cfg->num_envs;
   hipError_t e = hipSetDevice(cfg->device);
   if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(double) * h->state_dim * N);
@@ -204,6 +205,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess) e = hipMemset(h->state, 0, sizeof(double) * h->state_dim * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_ROBOT_REACH)  // render primitive list (no allocation in launch paths)
     e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::RR_NPRIM * N);
+  if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
+  if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
 #ifdef MJS_STAMPS
   if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
@@ -249,6 +252,7 @@ void mjs_destroy(mjs_handle* h) {
   if (h->rng_mt) (void)hipFree(h->rng_mt);
   if (h->rng_pos) (void)hipFree(h->rng_pos);
   if (h->prims) (void)hipFree(h->prims);
+  if (h->cams) (void)hipFree(h->cams);
   delete h;
 }
 
@@ -303,16 +307,18 @@ int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_o
 
 int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uint8_t* rgb_dev, void* stream) {
   if (!h || !rgb_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: null argument");
-  if (camera != MJS_CAMERA_SCENE || height <= 0 || width <= 0) return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: bad camera or size");
-  if (h->cfg.task == MJS_TASK_BUTTON_PUSH) return fail(h, MJS_ERR_UNSUPPORTED, "mjs_render: Button-Push cameras are not built yet");
+  const int task = h->cfg.task;
+  const bool wrist = camera == MJS_CAMERA_WRIST;
+  if ((camera != MJS_CAMERA_SCENE && !(wrist && task == MJS_TASK_BUTTON_PUSH)) || height <= 0 || width <= 0)
+    return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: bad camera or size");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
-  const bool pointmass = h->cfg.task == MJS_TASK_POINTMASS_REACH;
   rend::RenderParams p;
   p.N = h->cfg.num_envs; p.H = height; p.W = width; p.state = h->state; p.out = rgb_dev;
+  p.env_cams = nullptr; p.nprim = 0;
   // camera frame from the MuJoCo quaternion (w,x,y,z): columns of R are the local x (right), y (up), z (back) axes
-  const double* q = pointmass ? MJS_PM_CAM_QUAT : MJS_RR_CAM_QUAT;
-  const double* cpos = pointmass ? MJS_PM_CAM_POS : MJS_RR_CAM_POS;
-  const double fovy = pointmass ? MJS_PM_CAM_FOVY : MJS_RR_CAM_FOVY;
+  const double* q = task == MJS_TASK_POINTMASS_REACH ? MJS_PM_CAM_QUAT : task == MJS_TASK_BUTTON_PUSH ? MJS_BP_CAM_QUAT : MJS_RR_CAM_QUAT;
+  const double* cpos = task == MJS_TASK_POINTMASS_REACH ? MJS_PM_CAM_POS : task == MJS_TASK_BUTTON_PUSH ? MJS_BP_CAM_POS : MJS_RR_CAM_POS;
+  const double fovy = wrist ? MJS_WCAM_FOVY : task == MJS_TASK_POINTMASS_REACH ? MJS_PM_CAM_FOVY : task == MJS_TASK_BUTTON_PUSH ? MJS_BP_CAM_FOVY : MJS_RR_CAM_FOVY;
   const double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   const double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
   const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
@@ -325,10 +331,16 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   }
   p.cam.tan_half = (float)std::tan(fovy * 3.14159265358979323846 / 360.0);
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
-  if (pointmass) {
+  if (task == MJS_TASK_POINTMASS_REACH) {
     rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
+  } else if (task == MJS_TASK_BUTTON_PUSH) {
+    rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
+    p.nprim = rend::BP_NPRIM;
+    if (wrist) p.env_cams = h->cams;
+    rend::robot_scene_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   } else {
     rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);
+    p.nprim = rend::RR_NPRIM;
     rend::robot_scene_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   }
   HIP_TRY(h, hipGetLastError());

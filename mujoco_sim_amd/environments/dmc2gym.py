@@ -56,6 +56,7 @@ class HipEnvironment:
         if hasattr(task, "action_type") and task.task_name == "robot_push_button":
             kwargs["action_type"] = task.action_type
             kwargs["button_disturbances"] = task.button_disturbances
+            kwargs["use_wrist_camera"] = task.use_wrist_camera
         self._venv = HipVectorEnv(task.task_name, 1, device=device, autoreset="next_step", reward_type=task.reward_type,
                                   time_limit=(1e300 if np.isinf(time_limit) else time_limit),
                                   observation_type=getattr(task, "observation_type", STATE_OBS),
@@ -191,8 +192,9 @@ class DMCEnvironmentAdapter(_EnvBase):
         obs = self._get_obs(time_step)
         truncated = time_step.last() and time_step.discount > 0
         terminated = time_step.last() and time_step.discount == 0
-        if self._env.task.task_name == "point_mass_reach":
-            # only tasks that define is_goal_reached report it (dmc2gym.py:149-150; point_reach.py:195-196)
+        if self._env.task.task_name in ("point_mass_reach", "robot_push_button"):
+            # only tasks that define is_goal_reached report it (dmc2gym.py:149-150; point_reach.py:195-196,
+            # robot_push_button.py:205-210)
             info["is_success"] = self._env.is_success * 1.0
         info["discount"] = time_step.discount
         return obs, reward, terminated, truncated, info

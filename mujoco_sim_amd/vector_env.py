@@ -92,7 +92,7 @@ class HipVectorEnv:
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
-                 button_disturbances: bool = False):
+                 button_disturbances: bool = False, use_wrist_camera: bool = True):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -161,12 +161,23 @@ class HipVectorEnv:
         self.observation_type = observation_type
         self.image_resolution = int(image_resolution)
         self._img = None
+        self._wrist_img = None
+        self.use_wrist_camera = bool(use_wrist_camera) and task == "robot_push_button"
         if observation_type == VISUAL_OBS:
             r = self.image_resolution
             self._img = torch.zeros(N, r, r, 3, dtype=torch.uint8, device=dev)
-            # point_reach.py:119-121 / robot_reach.py:139-141: proprioception + scene camera image
-            self._visual_keys = ("pointmass/position",) if task == "point_mass_reach" else ("ur5e/tcp_position",)
+            # point_reach.py:119-121 / robot_reach.py:139-141 / robot_push_button.py:113-124: proprioception +
+            # camera image(s); dict order = composer's entity order (robot, wrist camera on the robot, scene camera)
+            if task == "point_mass_reach":
+                self._visual_keys = ("pointmass/position",)
+            elif task == "robot_push_button":
+                self._visual_keys = ("ur5e/joint_configuration",) if action_type == ABS_JOINT_ACTION else ("ur5e/tcp_position",)
+            else:
+                self._visual_keys = ("ur5e/tcp_position",)
             spaces = [(k, Box(-np.inf, np.inf, shape=(n,), dtype=np.float64)) for k, _, n in self.spec.obs_layout if k in self._visual_keys]
+            if self.use_wrist_camera:
+                self._wrist_img = torch.zeros(N, r, r, 3, dtype=torch.uint8, device=dev)
+                spaces.append(("ur5e/Camera/rgb_image", Box(0, 255, shape=(r, r, 3), dtype=np.uint8)))
             spaces.append(("Camera/rgb_image", Box(0, 255, shape=(r, r, 3), dtype=np.uint8)))
             self.single_observation_space = Dict(OrderedDict(spaces))
             self.observation_space = Dict(OrderedDict((k, batch_box(s, N)) for k, s in self.single_observation_space.items()))
@@ -186,6 +197,8 @@ class HipVectorEnv:
             # entity observables first (pointmass position, camera image), as in the reference's dict order
             self.render(self.image_resolution, self.image_resolution, out=self._img)
             d = OrderedDict((k, flat[..., s:s + n]) for k, s, n in self.spec.obs_layout if k in self._visual_keys)
+            if self._wrist_img is not None:
+                d["ur5e/Camera/rgb_image"] = self.render(self.image_resolution, self.image_resolution, out=self._wrist_img, camera=1)
             d["Camera/rgb_image"] = self._img
             return d
         return OrderedDict((k, flat[..., s:s + n]) for k, s, n in self._state_layout)
@@ -241,13 +254,14 @@ class HipVectorEnv:
         assert s.shape == (self.state_dim, self.num_envs)
         nat.check(self._lib.mjs_set_state(self._h, C.c_void_p(s.data_ptr()), self._stream()), self._h)
 
-    def render(self, height: int = 64, width: int = 64, out: torch.Tensor | None = None) -> torch.Tensor:
-        """Scene-camera RGB images of all envs, uint8 [N, H, W, 3] on the GPU (replaces
-        Camera.get_rgb_image / physics.render, entities/camera.py:94-103; own ray caster, D-6)."""
+    def render(self, height: int = 64, width: int = 64, out: torch.Tensor | None = None, camera: int = 0) -> torch.Tensor:
+        """RGB images of all envs, uint8 [N, H, W, 3] on the GPU (replaces Camera.get_rgb_image /
+        physics.render, entities/camera.py:94-103; own ray caster, D-6). camera 0 = the task's scene camera,
+        1 = the Button-Push wrist camera."""
         if out is None:
             out = torch.empty(self.num_envs, height, width, 3, dtype=torch.uint8, device=self.device)
         assert out.shape == (self.num_envs, height, width, 3) and out.dtype == torch.uint8 and out.is_contiguous()
-        nat.check(self._lib.mjs_render(self._h, 0, height, width, C.c_void_p(out.data_ptr()), self._stream()), self._h)
+        nat.check(self._lib.mjs_render(self._h, int(camera), height, width, C.c_void_p(out.data_ptr()), self._stream()), self._h)
         return out
 
     def tcp_to_joints(self, tcp_positions, joint_guess):

@@ -180,6 +180,8 @@ void om_env_step(om_env* e, const double* action, om_step_out* out);
 /* scene-camera image (own ray caster, om_render.c): out uint8 [H, W, 3] */
 void om_render_pointmass(const om_env* e, int H, int W, uint8_t* out);
 void om_render_robot(const om_env* e, int H, int W, uint8_t* out);
+/* camera 0 = the task's scene camera, 1 = Button-Push wrist camera */
+void om_render_camera(const om_env* e, int camera, int H, int W, uint8_t* out);
 void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out);
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
 void om_debug_reach_dynamics(const double* q, const double* v, double* M_out, double* bias_out);

@@ -230,20 +230,52 @@ static void obb(v3 o, v3 d, v3 c, v3 u, v3 v, v3 half, v3 rgb, surf* s) {
 }
 static v3 Vd(const double* p) { return V((float)p[0], (float)p[1], (float)p[2]); }
 
-/* scene camera image of a Robot-Reach env (robot_reach.py:52 camera; arm drawn by its collision
- * proxies + stand-ins): out uint8 [H, W, 3] */
-void om_render_robot(const om_env* e, int H, int W, uint8_t* out) {
-  const om_model* m = &e->m;
-  const om_data* dd = &e->d;
-  const double* q = MJS_RR_CAM_QUAT;
+static void quat_to_mat(const double* q, double* R) {
   double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
   double w = q[0] / n, x = q[1] / n, y = q[2] / n, z = q[3] / n;
-  double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z),
-                 2 * (y * z - x * w), 2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)};
+  R[0] = 1 - 2 * (y * y + z * z); R[1] = 2 * (x * y - z * w); R[2] = 2 * (x * z + y * w);
+  R[3] = 2 * (x * y + z * w); R[4] = 1 - 2 * (x * x + z * z); R[5] = 2 * (y * z - x * w);
+  R[6] = 2 * (x * z - y * w); R[7] = 2 * (y * z + x * w); R[8] = 1 - 2 * (x * x + y * y);
+}
+
+/* Robot scenes (arm drawn by its collision proxies + stand-ins): Robot-Reach scene camera
+ * (robot_reach.py:52), Button-Push scene camera (robot_push_button.py:51-52,87-89) and wrist camera
+ * (robot_push_button.py:53-54,90-96; camera = 1). out uint8 [H, W, 3] */
+static void render_robot_scene(const om_env* e, int camera, int H, int W, uint8_t* out) {
+  const om_model* m = &e->m;
+  const om_data* dd = &e->d;
+  const int button = e->cfg.task == OM_TASK_BUTTON_PUSH;
+  /* flange frame (site 0) */
+  const double* sp = dd->site_xpos[0];
+  const double* sm = dd->site_xmat[0];
+  double fx[3], fy[3], fz[3];
+  for (int k = 0; k < 3; k++) { fx[k] = sm[3 * k]; fy[k] = sm[3 * k + 1]; fz[k] = sm[3 * k + 2]; }
+  /* wrist camera pose */
+  double Rc[9], wpos[3], wright[3], wup[3], wback[3];
+  quat_to_mat(MJS_WCAM_QUAT, Rc);
+  for (int k = 0; k < 3; k++) {
+    wpos[k] = ((sp[k] + MJS_WCAM_POS[0] * fx[k]) + MJS_WCAM_POS[1] * fy[k]) + MJS_WCAM_POS[2] * fz[k];
+    wright[k] = (Rc[0] * fx[k] + Rc[3] * fy[k]) + Rc[6] * fz[k];
+    wup[k] = (Rc[1] * fx[k] + Rc[4] * fy[k]) + Rc[7] * fz[k];
+    wback[k] = (Rc[2] * fx[k] + Rc[5] * fy[k]) + Rc[8] * fz[k];
+  }
+  /* camera used for this image */
+  double R[9];
+  quat_to_mat(button ? MJS_BP_CAM_QUAT : MJS_RR_CAM_QUAT, R);
+  const double* cpos = button ? MJS_BP_CAM_POS : MJS_RR_CAM_POS;
   float right[3], up[3], back[3];
-  for (int k = 0; k < 3; k++) { right[k] = (float)R[3 * k]; up[k] = (float)R[3 * k + 1]; back[k] = (float)R[3 * k + 2]; }
-  float tan_half = (float)tan(MJS_RR_CAM_FOVY * 3.14159265358979323846 / 360.0);
-  v3 eye = Vd(MJS_RR_CAM_POS);
+  v3 eye;
+  double fovy;
+  if (camera == 1) {
+    for (int k = 0; k < 3; k++) { right[k] = (float)wright[k]; up[k] = (float)wup[k]; back[k] = (float)wback[k]; }
+    eye = Vd(wpos);
+    fovy = MJS_WCAM_FOVY;
+  } else {
+    for (int k = 0; k < 3; k++) { right[k] = (float)R[3 * k]; up[k] = (float)R[3 * k + 1]; back[k] = (float)R[3 * k + 2]; }
+    eye = Vd(cpos);
+    fovy = button ? MJS_BP_CAM_FOVY : MJS_RR_CAM_FOVY;
+  }
+  float tan_half = (float)tan(fovy * 3.14159265358979323846 / 360.0);
   /* primitive list, float32 */
   v3 cap_a[MJS_UR_NCOLGEOM], cap_b[MJS_UR_NCOLGEOM];
   for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
@@ -253,12 +285,21 @@ void om_render_robot(const om_env* e, int H, int W, uint8_t* out) {
     for (int k = 0; k < 3; k++) { a[k] = gp[k] + -half * gm[3 * k + 2]; b[k] = gp[k] + half * gm[3 * k + 2]; }
     cap_a[g] = Vd(a); cap_b[g] = Vd(b);
   }
-  const double* sp = dd->site_xpos[0];
-  const double* sm = dd->site_xmat[0];
-  double bc[3], bu[3], bv[3];
-  for (int k = 0; k < 3; k++) { bc[k] = sp[k] + (double)MJS_G2F85_STANDIN_HALF[2] * sm[3 * k + 2]; bu[k] = sm[3 * k]; bv[k] = sm[3 * k + 1]; }
-  v3 box_c = Vd(bc), box_u = Vd(bu), box_v = Vd(bv);
+  double bc[3];
+  for (int k = 0; k < 3; k++) bc[k] = sp[k] + (double)MJS_G2F85_STANDIN_HALF[2] * fz[k];
+  v3 box_c = Vd(bc), box_u = Vd(fx), box_v = Vd(fy);
   v3 tgt = Vd(e->target_pos);
+  /* Button-Push extras */
+  double Rs[9], su[3], sv[3], swc[3], ba[3], bb[3];
+  quat_to_mat(MJS_BP_CAM_QUAT, Rs);
+  for (int k = 0; k < 3; k++) { su[k] = Rs[3 * k]; sv[k] = Rs[3 * k + 1]; }
+  const double* swp = button ? m->body_pos[m->nbody - 1] : MJS_RR_TARGET_DEFAULT_POS;
+  swc[0] = swp[0]; swc[1] = swp[1]; swc[2] = swp[2] + MJS_SW_BOX_HALF;
+  ba[0] = bb[0] = swp[0]; ba[1] = bb[1] = swp[1];
+  ba[2] = swp[2] + MJS_SW_BUTTON_Z - MJS_SW_BUTTON_HALF; bb[2] = swp[2] + MJS_SW_BUTTON_Z + MJS_SW_BUTTON_HALF;
+  const v3 cam_half = V((float)MJS_CAM_BOX_HALF[0], (float)MJS_CAM_BOX_HALF[1], (float)MJS_CAM_BOX_HALF[2]);
+  const v3 cam_rgb = V(MJS_CAM_BODY_RGB[0], MJS_CAM_BODY_RGB[1], MJS_CAM_BODY_RGB[2]);
+  const float* brgb = e->switch_active ? MJS_SW_BUTTON_RGB_ON : MJS_SW_BUTTON_RGB_OFF;
   float aspect = (float)W / (float)H;
   for (int row = 0; row < H; row++)
     for (int col = 0; col < W; col++) {
@@ -275,10 +316,24 @@ void om_render_robot(const om_env* e, int H, int W, uint8_t* out) {
       }
       cylinder(eye, d, V(0, 0, 0), V(0, 0, (float)(2.0 * MJS_UR_BASE_STANDIN[1])), MJS_UR_BASE_STANDIN[0], V(MJS_UR_JOINTGRAY[0], MJS_UR_JOINTGRAY[1], MJS_UR_JOINTGRAY[2]), &s);
       obb(eye, d, box_c, box_u, box_v, V(MJS_G2F85_STANDIN_HALF[0], MJS_G2F85_STANDIN_HALF[1], MJS_G2F85_STANDIN_HALF[2]), V(MJS_UR_BLACK[0], MJS_UR_BLACK[1], MJS_UR_BLACK[2]), &s);
-      sphere(eye, d, tgt, MJS_RR_TARGET_RADIUS, V(MJS_RR_TARGET_RGB[0], MJS_RR_TARGET_RGB[1], MJS_RR_TARGET_RGB[2]), &s);
+      if (!button) {
+        sphere(eye, d, tgt, MJS_RR_TARGET_RADIUS, V(MJS_RR_TARGET_RGB[0], MJS_RR_TARGET_RGB[1], MJS_RR_TARGET_RGB[2]), &s);
+      } else {
+        obb(eye, d, Vd(wpos), Vd(wright), Vd(wup), cam_half, cam_rgb, &s);
+        sphere(eye, d, Vd(wpos), (float)MJS_CAM_SPHERE_RADIUS, cam_rgb, &s);
+        obb(eye, d, Vd(MJS_BP_CAM_POS), Vd(su), Vd(sv), cam_half, cam_rgb, &s);
+        sphere(eye, d, Vd(MJS_BP_CAM_POS), (float)MJS_CAM_SPHERE_RADIUS, cam_rgb, &s);
+        obb(eye, d, Vd(swc), V(1, 0, 0), V(0, 1, 0), V((float)MJS_SW_BOX_HALF, (float)MJS_SW_BOX_HALF, (float)MJS_SW_BOX_HALF), V(MJS_SW_BOX_RGB[0], MJS_SW_BOX_RGB[1], MJS_SW_BOX_RGB[2]), &s);
+        cylinder(eye, d, Vd(ba), Vd(bb), (float)MJS_SW_BUTTON_RADIUS, V(brgb[0], brgb[1], brgb[2]), &s);
+      }
       v3 c = V(0, 0, 0);
       if (s.t < INFINITY) c = shade(vadd(eye, vmul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS, 6);
       uint8_t* o = out + ((size_t)row * W + col) * 3;
       o[0] = to_u8(c.x); o[1] = to_u8(c.y); o[2] = to_u8(c.z);
     }
+}
+void om_render_robot(const om_env* e, int H, int W, uint8_t* out) { render_robot_scene(e, 0, H, W, out); }
+void om_render_camera(const om_env* e, int camera, int H, int W, uint8_t* out) {
+  if (e->cfg.task == OM_TASK_POINTMASS) om_render_pointmass(e, H, W, out);
+  else render_robot_scene(e, camera, H, W, out);
 }

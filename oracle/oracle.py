@@ -92,6 +92,7 @@ def lib() -> C.CDLL:
         L.om_env_seed.argtypes = [C.c_void_p, C.c_uint32]
         L.om_render_pointmass.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.om_render_robot.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.om_render_camera.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         L.om_rng_seed.argtypes = [C.POINTER(_Rng), C.c_uint32]
         L.om_rng_uniform.argtypes = [C.POINTER(_Rng), C.c_double, C.c_double]
         L.om_rng_uniform.restype = C.c_double
@@ -215,12 +216,11 @@ class OracleBatch:
         for i in range(self.n):
             L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
 
-    def render(self, height: int, width: int) -> np.ndarray:
-        """scene-camera images of all envs: uint8 [N, H, W, 3]"""
-        fn = lib().om_render_pointmass if self.task == TASK_POINTMASS else lib().om_render_robot
+    def render(self, height: int, width: int, camera: int = 0) -> np.ndarray:
+        """camera images of all envs (0 = scene camera, 1 = Button-Push wrist camera): uint8 [N, H, W, 3]"""
         img = np.zeros((self.n, height, width, 3), dtype=np.uint8)
         for i in range(self.n):
-            fn(lib().om_batch_env(self._h, i), height, width, img[i].ctypes.data)
+            lib().om_render_camera(lib().om_batch_env(self._h, i), camera, height, width, img[i].ctypes.data)
         return img
 
     def close(self):

@@ -496,3 +496,48 @@ def test_button_push_state_env_id(oracle_mod):
     assert list(obs.keys()) == ["ur5e/tcp_position", "unnamed_model/position", "unnamed_model/active"] and env2.action_space.shape == (4,)
     env.close()
     env2.close()
+
+
+def test_button_push_cameras_match_oracle(oracle_mod):
+    """Scene camera and flange-mounted wrist camera of the Button-Push scene (robot_push_button.py:87-96),
+    after the scripted policy has pressed some switches (green buttons): same bar as the Robot-Reach render."""
+    import mujoco_sim_amd as m
+
+    N = 16
+    task = m.RobotPushButtonTask(observation_type="state_observations", action_type="absolute_eef_action")
+    venv = m.HipVectorEnv("robot_push_button", N, seed=3, autoreset="disabled", action_type="absolute_eef_action")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 3, autoreset=2, nthreads=8, action_type=1)
+    venv.reset()
+    ob.reset()
+    for t in range(24):
+        a = task.demonstration_actions(venv).cpu().numpy()
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+    assert 0 < (o["obs"][:, 12] > 0.5).sum()  # some buttons are green
+    for camera in (0, 1):
+        for res in (96, 128):
+            gpu = venv.render(res, res, camera=camera).cpu().numpy().astype(np.int16)
+            cpu = ob.render(res, res, camera).astype(np.int16)
+            diff = np.abs(gpu - cpu)
+            assert (diff > 0).mean() < 2e-4 and diff.max() <= 2, (camera, res, (diff > 0).mean(), diff.max())
+            assert gpu.std() > 10
+    venv.close()
+
+
+def test_registered_button_push_visual_env_id():
+    # mujoco_sim/__init__.py:31-39: visual observations, 96x96, absolute joint actions, wrist + scene camera
+    import mujoco_sim_amd as m
+
+    env = m.make("mujoco_sim/robot_push_button_visual-v0")
+    obs, _ = env.reset(seed=9)
+    assert list(obs.keys()) == ["ur5e/joint_configuration", "ur5e/Camera/rgb_image", "Camera/rgb_image"]
+    assert obs["Camera/rgb_image"].shape == (96, 96, 3) and obs["Camera/rgb_image"].dtype == np.uint8
+    assert obs["ur5e/Camera/rgb_image"].shape == (96, 96, 3) and obs["ur5e/Camera/rgb_image"].std() > 5
+    assert env.observation_space["ur5e/Camera/rgb_image"].shape == (96, 96, 3) and env.action_space.shape == (7,)
+    policy = env.dmc_env.task.create_demonstration_policy(env.dmc_env)
+    done, n = False, 0
+    while not done and n < 100:
+        obs, reward, term, trunc, info = env.step(policy(None))
+        done, n = term or trunc, n + 1
+    assert done and n <= 100 and "is_success" in info
+    env.close()
