@@ -38,7 +38,46 @@ def run(task, N, T, base_seed, autoreset):
     return dict(actions=acts, reset_obs=r0["obs"], **{k: np.stack(v) for k, v in traj.items()})
 
 
+def demo_actions(obs):
+    """the reference's scripted Button-Push policy (robot_push_button.py:231-296), ABS_EEF variant, on a batch"""
+    tcp, sw, active = obs[:, 6:9], obs[:, 9:12], obs[:, 12] > 0.5
+    planar = np.linalg.norm(tcp[:, :2] - sw[:, :2], axis=1)
+    press = ~active & (tcp[:, 2] > sw[:, 2]) & (planar < 0.01)
+    goal = sw.copy()
+    goal[:, 2] += 0.05
+    low = tcp[:, 2] < sw[:, 2] + 0.02
+    goal[low, :2] = tcp[low, :2]
+    goal[press] = sw[press]
+    end = np.tile(np.array([-0.3, -0.2, 0.3]), (len(obs), 1))
+    end[planar < 0.05, 2] = sw[planar < 0.05, 2] + 0.1
+    goal[active] = end[active]
+    diff = goal - tcp
+    big = np.abs(diff).max(axis=1)
+    diff = diff * np.where(big > 0.05, 0.05 / np.maximum(big, 1e-300), 1.0)[:, None]
+    return np.concatenate([tcp + diff, np.zeros((len(obs), 1))], axis=1)
+
+
+def run_button(N, T, base_seed):
+    # closed loop on the oracle; the recorded actions make the fixture open-loop for the GPU test.
+    # Covers: approach, press (contact rows, touch sensor, rising-edge toggle), success termination
+    # (discount 0), next-step auto-reset with device-side re-draws, second episodes.
+    b = oracle.OracleBatch(oracle.TASK_BUTTON_PUSH, N, base_seed, action_type=oracle.ACTION_ABS_EEF)
+    r = b.reset()
+    keys = ["obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon"]
+    traj = {k: [] for k in keys}
+    acts = []
+    reset_obs = r["obs"]
+    for t in range(T):
+        a = demo_actions(r["obs"])
+        acts.append(a)
+        r = b.step(a)
+        for k in keys:
+            traj[k].append(r[k])
+    return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
+
+
 if __name__ == "__main__":
+    np.savez_compressed(OUT / "button_push_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025))
     np.savez_compressed(OUT / "pointmass_n8_t70_seed2025.npz", **run(oracle.TASK_POINTMASS, 8, 70, 2025, oracle.AUTORESET_NEXT_STEP))
     np.savez_compressed(OUT / "robot_reach_n8_t110_seed2025.npz", **run(oracle.TASK_ROBOT_REACH, 8, 110, 2025, oracle.AUTORESET_NEXT_STEP))
     print("golden fixtures written to", OUT)

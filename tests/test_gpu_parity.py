@@ -86,13 +86,14 @@ def test_pointmass_wall_contacts_parity(oracle_mod):
     assert saw_contact and (o["ncon"].max() == 3)
 
 
-@pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", "point_mass_reach"), ("robot_reach_n8_t110_seed2025", "robot_reach")])
+@pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", "point_mass_reach"), ("robot_reach_n8_t110_seed2025", "robot_reach"),
+                                       ("button_push_eef_n8_t80_seed2025", "robot_push_button")])
 def test_gpu_matches_committed_golden(name, task):
     import mujoco_sim_amd as m
 
     g = np.load(GOLDEN / f"{name}.npz")
     T, N = g["actions"].shape[:2]
-    venv = m.HipVectorEnv(task, N, seed=2025)
+    venv = m.HipVectorEnv(task, N, seed=2025, **({"action_type": "absolute_eef_action"} if task == "robot_push_button" else {}))
     venv.reset()
     np.testing.assert_allclose(venv.flat_obs.cpu().numpy(), g["reset_obs"], rtol=0, atol=ATOL)
     out = venv.rollout(torch.from_numpy(g["actions"]))  # T launches through mjs_rollout

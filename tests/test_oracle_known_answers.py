@@ -202,11 +202,11 @@ def test_pointmass_wall_contacts_detected(oracle_mod):
 
 
 # ------------------------------------------------------------------------- golden regression
-@pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", 0), ("robot_reach_n8_t110_seed2025", 1)])
+@pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", 0), ("robot_reach_n8_t110_seed2025", 1), ("button_push_eef_n8_t80_seed2025", 3)])
 def test_oracle_matches_golden(oracle_mod, name, task):
     g = np.load(GOLDEN / f"{name}.npz")
     N, T = g["actions"].shape[1], g["actions"].shape[0]
-    b = oracle_mod.OracleBatch(task, N, 2025)
+    b = oracle_mod.OracleBatch(task, N, 2025, action_type=1 if task == 3 else None)
     r0 = b.reset()
     assert np.array_equal(r0["obs"], g["reset_obs"])
     for t in range(T):
@@ -264,3 +264,74 @@ def test_oracle_render_robot_scene(oracle_mod):
     r, c = pix(tcp + np.array([0.0, 0.0, 0.08]))  # inside the gripper stand-in, above the TCP (tool points down)
     assert (img[r, c] < 40).all(), img[r, c]
     assert (img[H - 1, 0] > 30).all() and abs(int(img[H - 1, 0, 0]) - int(img[H - 1, 0, 2])) < 3  # grey floor
+
+
+# ------------------------------------------------------------------------------------ Button-Push
+def test_button_push_reset_draw_order(oracle_mod):
+    """initialize_episode (robot_push_button.py:126-134): robot spawn xyz, then switch xyz, each three sequential
+    uniform() calls (spaces.py:24-31) of RandomState(seed); switch observable = button xpos + 0.5*size[1] on all axes
+    (switch.py:86-87); the IK places the TCP on the drawn position (to the DH-vs-MJCF model mismatch)."""
+    for seed in (0, 5, 2025):
+        rs = np.random.RandomState(seed)
+        robot = [rs.uniform(lo, hi) for lo, hi in ((-0.2, 0.2), (-0.6, -0.3), (0.02, 0.3))]
+        switch = [rs.uniform(lo, hi) for lo, hi in ((-0.2, 0.2), (-0.6, -0.3), (0.0, 0.1))]
+        o = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, 1, seed).reset()["obs"][0]
+        np.testing.assert_allclose(o[6:9], robot, atol=1.5e-3)  # DH IK vs MJCF body chain: < 1 mm apart, as in the reference's own frame test
+        np.testing.assert_allclose(o[9:12], np.array(switch) + [0.01, 0.01, 0.05 + 0.01], atol=1e-15)
+        assert o[12] == 0.0
+
+
+def _demo_eef(obs):
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("make_golden", GOLDEN / "make_golden.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.demo_actions(obs)
+
+
+def test_button_push_scripted_policy_solves_task(oracle_mod):
+    """The reference's own demonstration policy is the behavioural known answer for the contact + touch-sensor +
+    switch chain: approach, press (a touch force inside [5, 200] N flips the switch on each rising edge, switch.py:51-60),
+    retreat to the end pose -> sparse reward 1, terminated with discount 0 (robot_push_button.py:167-219). With the
+    rigid gripper stand-in (D-1) the press force can leave and re-enter the band within one control step, so an
+    episode shows an odd number of flips when it succeeds; most episodes do."""
+    N = 16
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 100, autoreset=2, action_type=1, nthreads=4)
+    r = b.reset()
+    toggles = np.zeros(N, int)
+    active = np.zeros(N, bool)
+    done = np.zeros(N, bool)
+    success = np.zeros(N, bool)
+    touched = np.zeros(N, bool)
+    for t in range(100):
+        r = b.step(_demo_eef(r["obs"]))
+        now = r["obs"][:, 12] > 0.5
+        toggles += (now != active) & ~done
+        active = now
+        touched |= r["ncon"] > 0
+        newly = (r["step_type"] == 2) & ~done
+        won = newly & r["is_success"]
+        assert (r["reward"][won] == 1.0).all() and (r["discount"][won] == 0.0).all() and r["terminated"][won].all()
+        lost = newly & ~r["is_success"]
+        assert t == 99 or not lost.any()  # the only other way out is the time limit ...
+        assert (r["reward"][lost] == 0.0).all() and (r["discount"][lost] == 1.0).all() and r["truncated"][lost].all()
+        assert (r["reward"][~newly & ~done] == 0.0).all()
+        assert (np.linalg.norm(r["obs"][won, 6:9] - [-0.3, -0.2, 0.3], axis=1) < 0.05).all() and now[won].all()
+        success |= won
+        done |= newly
+    assert done.all() and touched.all()
+    assert success.sum() >= N // 2
+    assert (toggles[success] % 2 == 1).all()
+
+
+def test_button_push_time_limit_truncates(oracle_mod):
+    # an idle policy never presses: episode ends by the 100-step time limit with discount 1 (truncated)
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, 1, 3, action_type=1)
+    r = b.reset()
+    hold = np.concatenate([r["obs"][0, 6:9], [0.0]])[None]
+    for t in range(100):
+        r = b.step(hold)
+        assert (r["step_type"][0] == 2) == (t == 99)
+    assert r["truncated"][0] and not r["terminated"][0] and r["discount"][0] == 1.0 and r["reward"][0] == 0.0
+    np.testing.assert_allclose(r["obs"][0, 6:9], hold[0, :3], atol=4e-3)  # the servo holds the pose (payload sag + DH/MJCF offset only)
