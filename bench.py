@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
+    ap.add_argument("--visual", type=int, default=0, metavar="RES",
+                    help="also render the task's camera(s) at RESxRES every step (BASELINE config 5: Button-Push, 64)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time box of the CPU oracle sample")
     return ap.parse_args()
 
@@ -119,13 +121,21 @@ def main():
     venv.reset()
     chunk = 64  # distinct action slabs resident in HBM, cycled
     acts = make_actions(args.task, chunk, n_local, device, 12345 + rank)
-    for i in range(args.warmup):
+    cams = ([0, 1] if args.task == "robot_push_button" else [0]) if args.visual else []
+    imgs = [torch.empty(n_local, args.visual, args.visual, 3, dtype=torch.uint8, device=device) for _ in cams]
+
+    def one_step(i):
         venv.step_flat(acts[i % chunk])
+        for cam, img in zip(cams, imgs):  # visual observations: what Camera.get_rgb_image does per control step
+            venv.render(args.visual, args.visual, out=img, camera=cam)
+
+    for i in range(args.warmup):
+        one_step(i)
     D.barrier()
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for i in range(args.steps):
-        venv.step_flat(acts[i % chunk])
+        one_step(i)
     torch.cuda.synchronize(device)
     D.barrier()
     elapsed = time.perf_counter() - t0
@@ -155,7 +165,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task}: {n_local} envs per GPU, {venv._lib.mjs_substeps(venv.spec.task_id)} substeps/step, "
-                                   f"state obs + joint_configuration, uniform workspace actions, next-step auto-reset",
+                                   f"state obs, uniform workspace actions, next-step auto-reset"
+                                   + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,

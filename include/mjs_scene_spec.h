@@ -243,6 +243,7 @@ MJS_K float MJS_PM_LIGHT_POS[2][3] = {{0.25f, 0.25f, 1.0f}, {-0.25f, -0.25f, 1.0
 MJS_K float MJS_LIGHT_DIFFUSE = 0.7f;
 MJS_K float MJS_LIGHT_SPECULAR = 0.3f;
 MJS_K float MJS_LIGHT_CUTOFF_COS = 0.70710678f;  /* cutoff 45 deg */
+MJS_K float MJS_LIGHT_CUTOFF_COS2 = 0.5f;
 MJS_K int   MJS_LIGHT_EXPONENT = 10;
 MJS_K float MJS_HEADLIGHT_AMBIENT = 0.1f;
 MJS_K float MJS_HEADLIGHT_DIFFUSE = 0.4f;

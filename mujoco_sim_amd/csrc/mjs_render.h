@@ -141,9 +141,11 @@ MJS_DEV F3 shade(F3 p, F3 n, F3 eye, F3 rgb, const float (*lights)[3]) {
   }
 #pragma unroll
   for (int k = 0; k < NLIGHT; k++) {
-    F3 l = normalize(sub(f3(lights[k][0], lights[k][1], lights[k][2]), p));
+    F3 lv = sub(f3(lights[k][0], lights[k][1], lights[k][2]), p);
+    // outside the 45 degree cone (cos^2 = 1/2), decided on the un-normalised vector
+    if (lv.z <= 0.0f || lv.z * lv.z < MJS_LIGHT_CUTOFF_COS2 * dotf(lv, lv)) continue;
+    F3 l = normalize(lv);
     float spotcos = l.z;  // cos between -l and the light direction (0,0,-1)
-    if (spotcos < MJS_LIGHT_CUTOFF_COS) continue;
     float spot = pow_pow2(spotcos, 3) * pow_pow2(spotcos, 1);  // exponent 10
     float ndl = dotf(n, l);
     if (ndl > 0.0f) {
@@ -222,12 +224,18 @@ __global__ __launch_bounds__(256) void pointmass_kernel(RenderParams p) {
 // the float64 forward kinematics feeding stage 1 (1e-16 before the float32 rounding).
 constexpr int PRIM_FLOATS = 20;
 enum { PRIM_SPHERE = 1, PRIM_CAPSULE = 2, PRIM_CYLINDER = 3, PRIM_BOX = 4 };
-constexpr int RR_NPRIM = MJS_UR_NCOLGEOM + 3;  // proxies + base stand-in + gripper stand-in + target site
+// arm records: shoulder/upper-arm proxies g0..g2, base stand-in, forearm/wrist proxies g3..g9, gripper stand-in
+constexpr int ARM_NREC = MJS_UR_NCOLGEOM + 2;
+constexpr int RR_NPRIM = ARM_NREC + 1;  // + target site
+constexpr int MAX_NPRIM = 32;           // the scene kernel keeps one candidate bit per primitive
 
+// conservative bounding-sphere radius of a primitive (about p0 for spheres/boxes, about the segment midpoint
+// for capsules/cylinders), with slack for float32 rounding: used only to SKIP exact tests that cannot hit
+MJS_DEV float bound_radius(float r) { return r * 1.02f + 1.0e-3f; }
 MJS_DEV void put3(float* dst, V3 v) { dst[0] = (float)v.x; dst[1] = (float)v.y; dst[2] = (float)v.z; }
 MJS_DEV void put_rgb(float* dst, const float* rgb) { dst[0] = rgb[0]; dst[1] = rgb[1]; dst[2] = rgb[2]; }
 
-// arm proxies + base stand-in + gripper stand-in: records 0 .. MJS_UR_NCOLGEOM + 1
+// arm proxies + base stand-in + gripper stand-in: ARM_NREC records in the order given above
 MJS_DEV void arm_prims(const rr::Chain& c, float* out);
 
 __global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, float* prims, int N) {
@@ -241,12 +249,13 @@ __global__ __launch_bounds__(64) void reach_prims_kernel(const double* state, fl
   float* out = prims + (size_t)i * RR_NPRIM * PRIM_FLOATS;
   arm_prims(c, out);
   {  // target site
-    float* pr = out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS;
+    float* pr = out + ARM_NREC * PRIM_FLOATS;
     pr[0] = (float)PRIM_SPHERE;
     pr[1] = (float)state[(size_t)(rr::S_TARGET + 0) * N + i];
     pr[2] = (float)state[(size_t)(rr::S_TARGET + 1) * N + i];
     pr[3] = (float)state[(size_t)(rr::S_TARGET + 2) * N + i];
     pr[13] = MJS_RR_TARGET_RADIUS;
+    pr[17] = bound_radius(MJS_RR_TARGET_RADIUS);
     put_rgb(pr + 14, MJS_RR_TARGET_RGB);
   }
 }
@@ -263,16 +272,19 @@ MJS_DEV void camera_body_prims(V3 pos, V3 ax, V3 ay, float* box, float* lens) {
   box[0] = (float)PRIM_BOX;
   put3(box + 1, pos); put3(box + 4, ax); put3(box + 7, ay);
   box[10] = (float)MJS_CAM_BOX_HALF[0]; box[11] = (float)MJS_CAM_BOX_HALF[1]; box[12] = (float)MJS_CAM_BOX_HALF[2];
+  box[17] = bound_radius((float)(MJS_CAM_BOX_HALF[0] + MJS_CAM_BOX_HALF[1] + MJS_CAM_BOX_HALF[2]));
   put_rgb(box + 14, MJS_CAM_BODY_RGB);
   lens[0] = (float)PRIM_SPHERE;
   put3(lens + 1, pos);
   lens[13] = (float)MJS_CAM_SPHERE_RADIUS;
+  lens[17] = bound_radius((float)MJS_CAM_SPHERE_RADIUS);
   put_rgb(lens + 14, MJS_CAM_BODY_RGB);
 }
 
 // Button-Push scene (robot_push_button.py:66-96): arm + stand-ins, wrist camera body, scene camera body,
 // switch box and button. Also writes the wrist camera pose of every env (cams [N][12]).
-constexpr int BP_NPRIM = MJS_UR_NCOLGEOM + 2 + 6;
+constexpr int BP_NPRIM = ARM_NREC + 2 + 2 + 2;  // arm, wrist camera body, scene camera body, switch box + button
+static_assert(BP_NPRIM <= MAX_NPRIM && RR_NPRIM <= MAX_NPRIM, "one candidate bit per primitive");
 __global__ __launch_bounds__(64) void button_prims_kernel(const double* state, const uint8_t* flags, float* prims, float* cams, int N) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= N) return;
@@ -293,30 +305,32 @@ __global__ __launch_bounds__(64) void button_prims_kernel(const double* state, c
   const V3 wright = madd(madd(Rc[0] * fx, Rc[3], fy), Rc[6], fz);  // camera local x, y, z axes in the world
   const V3 wup = madd(madd(Rc[1] * fx, Rc[4], fy), Rc[7], fz);
   const V3 wback = madd(madd(Rc[2] * fx, Rc[5], fy), Rc[8], fz);
-  camera_body_prims(wpos, wright, wup, out + (MJS_UR_NCOLGEOM + 2) * PRIM_FLOATS, out + (MJS_UR_NCOLGEOM + 3) * PRIM_FLOATS);
+  camera_body_prims(wpos, wright, wup, out + ARM_NREC * PRIM_FLOATS, out + (ARM_NREC + 1) * PRIM_FLOATS);
   float* cm = cams + (size_t)i * 12;
   put3(cm, wpos); put3(cm + 3, wright); put3(cm + 6, wup); put3(cm + 9, wback);
   {  // scene camera body (seen by the wrist camera only)
     double Rs[9];
     quat_to_mat(MJS_BP_CAM_QUAT, Rs);
     camera_body_prims(v3(MJS_BP_CAM_POS[0], MJS_BP_CAM_POS[1], MJS_BP_CAM_POS[2]), v3(Rs[0], Rs[3], Rs[6]), v3(Rs[1], Rs[4], Rs[7]),
-                      out + (MJS_UR_NCOLGEOM + 4) * PRIM_FLOATS, out + (MJS_UR_NCOLGEOM + 5) * PRIM_FLOATS);
+                      out + (ARM_NREC + 2) * PRIM_FLOATS, out + (ARM_NREC + 3) * PRIM_FLOATS);
   }
   const V3 sw = v3(state[(size_t)(bp::S_SWITCH + 0) * N + i], state[(size_t)(bp::S_SWITCH + 1) * N + i], state[(size_t)(bp::S_SWITCH + 2) * N + i]);
   {  // switch box
-    float* pr = out + (MJS_UR_NCOLGEOM + 6) * PRIM_FLOATS;
+    float* pr = out + (ARM_NREC + 4) * PRIM_FLOATS;
     pr[0] = (float)PRIM_BOX;
     put3(pr + 1, v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF));
     put3(pr + 4, v3(1, 0, 0)); put3(pr + 7, v3(0, 1, 0));
     pr[10] = pr[11] = pr[12] = (float)MJS_SW_BOX_HALF;
+    pr[17] = bound_radius((float)(3 * MJS_SW_BOX_HALF));
     put_rgb(pr + 14, MJS_SW_BOX_RGB);
   }
   {  // button: red, green while the switch is active (switch.py:59)
-    float* pr = out + (MJS_UR_NCOLGEOM + 7) * PRIM_FLOATS;
+    float* pr = out + (ARM_NREC + 5) * PRIM_FLOATS;
     pr[0] = (float)PRIM_CYLINDER;
     put3(pr + 1, v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z - MJS_SW_BUTTON_HALF));
     put3(pr + 4, v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z + MJS_SW_BUTTON_HALF));
     pr[13] = (float)MJS_SW_BUTTON_RADIUS;
+    pr[17] = bound_radius((float)(MJS_SW_BUTTON_RADIUS + MJS_SW_BUTTON_HALF));
     put_rgb(pr + 14, (flags[i] & bp::FLAG_SWITCH_ACTIVE) ? MJS_SW_BUTTON_RGB_ON : MJS_SW_BUTTON_RGB_OFF);
   }
 }
@@ -324,7 +338,7 @@ __global__ __launch_bounds__(64) void button_prims_kernel(const double* state, c
 MJS_DEV void arm_prims(const rr::Chain& c, float* out) {
 #pragma unroll
   for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
-    float* pr = out + g * PRIM_FLOATS;
+    float* pr = out + (g < 3 ? g : g + 1) * PRIM_FLOATS;
     const int b = MJS_UR_COL_BODY[g];
     const M3 R = c.R[b];
     V3 gp = madd(madd(madd(c.p[b], MJS_UR_COL_POS[g][0], R.cx), MJS_UR_COL_POS[g][1], R.cy), MJS_UR_COL_POS[g][2], R.cz);
@@ -334,18 +348,20 @@ MJS_DEV void arm_prims(const rr::Chain& c, float* out) {
     put3(pr + 1, madd(gp, -half, axis));
     put3(pr + 4, madd(gp, half, axis));
     pr[13] = (float)MJS_UR_COL_SIZE[g][0];
+    pr[17] = bound_radius((float)(half + MJS_UR_COL_SIZE[g][0]));
     put_rgb(pr + 14, MJS_UR_COL_IS_JOINT[g] ? MJS_UR_URBLUE : MJS_UR_LINKGRAY);
   }
   {  // base stand-in: vertical cylinder on the floor
-    float* pr = out + MJS_UR_NCOLGEOM * PRIM_FLOATS;
+    float* pr = out + 3 * PRIM_FLOATS;
     pr[0] = (float)PRIM_CYLINDER;
     put3(pr + 1, v3(0, 0, 0));
     put3(pr + 4, v3(0, 0, 2.0 * MJS_UR_BASE_STANDIN[1]));
     pr[13] = MJS_UR_BASE_STANDIN[0];
+    pr[17] = bound_radius(MJS_UR_BASE_STANDIN[0] + MJS_UR_BASE_STANDIN[1]);
     put_rgb(pr + 14, MJS_UR_JOINTGRAY);
   }
   {  // gripper stand-in: box in the flange frame (x = wrist_3 x, y = -wrist_3 z, z = wrist_3 y)
-    float* pr = out + (MJS_UR_NCOLGEOM + 1) * PRIM_FLOATS;
+    float* pr = out + (ARM_NREC - 1) * PRIM_FLOATS;
     const M3 R = c.R[6];
     V3 centre = madd(c.p[6], MJS_UR_FLANGE_POS[1] + (double)MJS_G2F85_STANDIN_HALF[2], R.cy);
     pr[0] = (float)PRIM_BOX;
@@ -353,6 +369,7 @@ MJS_DEV void arm_prims(const rr::Chain& c, float* out) {
     put3(pr + 4, R.cx);   // box axis u (half[0])
     put3(pr + 7, -R.cz);  // box axis v (half[1]); w = u x v = flange z (half[2])
     pr[10] = MJS_G2F85_STANDIN_HALF[0]; pr[11] = MJS_G2F85_STANDIN_HALF[1]; pr[12] = MJS_G2F85_STANDIN_HALF[2];
+    pr[17] = bound_radius(MJS_G2F85_STANDIN_HALF[0] + MJS_G2F85_STANDIN_HALF[1] + MJS_G2F85_STANDIN_HALF[2]);
     put_rgb(pr + 14, MJS_UR_BLACK);
   }
 }
@@ -442,39 +459,92 @@ MJS_DEV void hit_obb(F3 o, F3 d, F3 c, F3 u, F3 v, F3 half, F3 rgb, Surf& s) {
   s.rgb = rgb;
 }
 
+// One wavefront per 8x8 pixel tile (4 tiles per workgroup). The env's primitive list is staged in LDS once per
+// workgroup; lane k of every wavefront tests primitive k against the cone that bounds the tile's 64 rays, and the
+// ballot of that test is the list of primitives the wavefront walks (typically 0-3 of ~20). All of this only
+// SKIPS exact tests that cannot hit: the image is unchanged.
 __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const float* prims) {
+  __shared__ float lds_prims[MAX_NPRIM * PRIM_FLOATS];
   const int env = blockIdx.y;
-  const int pix = blockIdx.x * 256 + threadIdx.x;
-  if (pix >= p.H * p.W) return;
-  const int row = pix / p.W, col = pix - row * p.W;
+  const int nprim = p.nprim;
+  {
+    const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
+    for (int k = threadIdx.x; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
+  }
+  __syncthreads();
+  const int tiles_x = (p.W + 7) >> 3;
+  const int tile = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int row0 = (tile / tiles_x) * 8, col0 = (tile % tiles_x) * 8;
+  const int row = row0 + (lane >> 3), col = col0 + (lane & 7);
+  const bool inside = row < p.H && col < p.W;
   F3 eye, d;
+  const float* right = p.cam.right;
+  const float* up = p.cam.up;
+  const float* back = p.cam.back;
   if (p.env_cams) {  // body-mounted camera: pose computed per env by the primitive stage
     const float* cm = p.env_cams + (size_t)env * 12;
     eye = f3(cm[0], cm[1], cm[2]);
-    d = pixel_ray_axes(p, row, col, cm + 3, cm + 6, cm + 9);
+    right = cm + 3; up = cm + 6; back = cm + 9;
   } else {
     eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-    d = pixel_ray(p, row, col);
+  }
+  d = pixel_ray_axes(p, row, col, right, up, back);
+  // cone bounding the tile's rays: axis = ray through the tile centre, cos(half-angle) = min over the lanes
+  F3 dc;
+  float cosa;
+  {
+    float aspect = (float)p.W / (float)p.H;
+    float px = (2.0f * ((float)col0 + 4.0f) / (float)p.W - 1.0f) * p.cam.tan_half * aspect;
+    float py = (1.0f - 2.0f * ((float)row0 + 4.0f) / (float)p.H) * p.cam.tan_half;
+    dc = normalize(f3(px * right[0] + py * up[0] - back[0], px * right[1] + py * up[1] - back[1], px * right[2] + py * up[2] - back[2]));
+    cosa = dotf(d, dc);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) cosa = fminf(cosa, __shfl_xor(cosa, m));
+    cosa = cosa - 1.0e-5f;
+  }
+  unsigned cand = 0;
+  {
+    bool c = false;
+    if (lane < nprim) {
+      const float* pr = lds_prims + lane * PRIM_FLOATS;
+      const int type = (int)pr[0];
+      const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+      const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
+      const float L2 = dotf(oc, oc), br = pr[17];
+      if (L2 <= br * br) c = true;  // the eye is inside the bound
+      else {
+        const float L = sqrtf(L2), cost = dotf(oc, dc) / L, sinb = br / L;
+        const float cosb = sqrtf(fmaxf(0.0f, 1.0f - sinb * sinb)), sina = sqrtf(fmaxf(0.0f, 1.0f - cosa * cosa));
+        c = cost >= cosa * cosb - sina * sinb - 1.0e-4f;  // angle(oc, axis) <= half-angle + asin(R / L)
+      }
+    }
+    cand = (unsigned)__ballot(c);
   }
   Surf s;
   s.t = INFINITY;
   s.n = f3(0, 0, 1);
   s.rgb = f3(0, 0, 0);
   hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
-  const float* pe = prims + (size_t)env * p.nprim * PRIM_FLOATS;
-#pragma unroll 1
-  for (int k = 0; k < p.nprim; k++) {
-    const float* pr = pe + k * PRIM_FLOATS;
+  while (cand) {  // ascending primitive index = the oracle's test order
+    const int k = __ffs(cand) - 1;
+    cand &= cand - 1;
+    const float* pr = lds_prims + k * PRIM_FLOATS;
     const int type = (int)pr[0];
-    const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]), rgb = f3(pr[14], pr[15], pr[16]);
+    const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+    // per-ray bounding-sphere reject
+    const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
+    const float along = dotf(oc, d), off2 = dotf(oc, oc) - along * along, br = pr[17];
+    if (!(inside && off2 <= br * br && along + br > 0.0f)) continue;
+    const F3 rgb = f3(pr[14], pr[15], pr[16]);
     if (type == PRIM_SPHERE) hit_sphere(eye, d, p0, pr[13], rgb, s);
     else if (type == PRIM_CAPSULE) hit_capsule(eye, d, p0, p1, pr[13], rgb, s);
     else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
     else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
   }
+  if (!inside) return;
   F3 c = f3(0, 0, 0);
   if (s.t < INFINITY) c = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
-  uint8_t* o = p.out + ((size_t)env * p.H * p.W + pix) * 3;
+  uint8_t* o = p.out + ((size_t)env * p.H * p.W + (size_t)row * p.W + col) * 3;
   o[0] = to_u8(c.x);
   o[1] = to_u8(c.y);
   o[2] = to_u8(c.z);

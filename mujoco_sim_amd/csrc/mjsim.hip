@@ -331,17 +331,19 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   }
   p.cam.tan_half = (float)std::tan(fovy * 3.14159265358979323846 / 360.0);
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
+  const int tiles = ((height + 7) / 8) * ((width + 7) / 8);  // robot scenes: one wavefront per 8x8 tile
+  dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
   if (task == MJS_TASK_POINTMASS_REACH) {
     rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
   } else if (task == MJS_TASK_BUTTON_PUSH) {
     rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
     p.nprim = rend::BP_NPRIM;
     if (wrist) p.env_cams = h->cams;
-    rend::robot_scene_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   } else {
     rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);
     p.nprim = rend::RR_NPRIM;
-    rend::robot_scene_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   }
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;

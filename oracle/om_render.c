@@ -87,9 +87,11 @@ static v3 shade(v3 p, v3 n, v3 eye, v3 rgb, const float (*lights)[3], int nlight
     spec = spec + MJS_HEADLIGHT_SPECULAR * pow2k(ndl, MJS_MATERIAL_SHININESS_POW2);
   }
   for (int k = 0; k < nlight; k++) {
-    v3 l = vnorm(vsub(V(lights[k][0], lights[k][1], lights[k][2]), p));
+    v3 lv = vsub(V(lights[k][0], lights[k][1], lights[k][2]), p);
+    /* outside the 45 degree cone (cos^2 = 1/2), decided on the un-normalised vector */
+    if (lv.z <= 0.0f || lv.z * lv.z < MJS_LIGHT_CUTOFF_COS2 * vdot(lv, lv)) continue;
+    v3 l = vnorm(lv);
     float spotcos = l.z;
-    if (spotcos < MJS_LIGHT_CUTOFF_COS) continue;
     float spot = pow2k(spotcos, 3) * pow2k(spotcos, 1);
     float nl = vdot(n, l);
     if (nl > 0.0f) {
@@ -311,10 +313,11 @@ static void render_robot_scene(const om_env* e, int camera, int H, int W, uint8_
       rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, V(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), 0, &s);
       for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
         const float* c = MJS_UR_COL_IS_JOINT[g] ? MJS_UR_URBLUE : MJS_UR_LINKGRAY;
+        if (g == 3) /* test order = the GPU primitive list: shoulder/upper arm, base stand-in, forearm/wrist, gripper */
+          cylinder(eye, d, V(0, 0, 0), V(0, 0, (float)(2.0 * MJS_UR_BASE_STANDIN[1])), MJS_UR_BASE_STANDIN[0], V(MJS_UR_JOINTGRAY[0], MJS_UR_JOINTGRAY[1], MJS_UR_JOINTGRAY[2]), &s);
         if (MJS_UR_COL_TYPE[g] == 3) capsule(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
         else cylinder(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
       }
-      cylinder(eye, d, V(0, 0, 0), V(0, 0, (float)(2.0 * MJS_UR_BASE_STANDIN[1])), MJS_UR_BASE_STANDIN[0], V(MJS_UR_JOINTGRAY[0], MJS_UR_JOINTGRAY[1], MJS_UR_JOINTGRAY[2]), &s);
       obb(eye, d, box_c, box_u, box_v, V(MJS_G2F85_STANDIN_HALF[0], MJS_G2F85_STANDIN_HALF[1], MJS_G2F85_STANDIN_HALF[2]), V(MJS_UR_BLACK[0], MJS_UR_BLACK[1], MJS_UR_BLACK[2]), &s);
       if (!button) {
         sphere(eye, d, tgt, MJS_RR_TARGET_RADIUS, V(MJS_RR_TARGET_RGB[0], MJS_RR_TARGET_RGB[1], MJS_RR_TARGET_RGB[2]), &s);
