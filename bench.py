@@ -62,9 +62,10 @@ def make_actions(task, T, N, device, seed):
     if task == "point_mass_reach":
         a = rs.uniform(-0.05, 0.05, (T, N, 2)).astype(np.float32).astype(np.float64)
     elif task == "robot_push_button":
-        # 7-D absolute joint targets (the registered action type): a top-down nominal pose +- a box that
-        # reaches the floor and the switch
-        a = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04]) + rs.uniform(-1, 1, (T, N, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04])
+        # SURVEY.md section 8d, cfg 5: joint targets q_home +- U(0.2) (robot.py:307) + gripper U(0, 0.085); 7-D absolute
+        # joint actions are the registered action type
+        home = np.array([-0.5, -0.5, 0.5, -0.5, -0.5, -0.5]) * np.pi
+        a = np.concatenate([home + rs.uniform(-0.2, 0.2, (T, N, 6)), rs.uniform(0.0, 0.085, (T, N, 1))], axis=2)
     else:
         a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (T, N, 3))
     return torch.from_numpy(a).to(device)
@@ -165,7 +166,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task}: {n_local} envs per GPU, {venv._lib.mjs_substeps(venv.spec.task_id)} substeps/step, "
-                                   f"state obs, uniform workspace actions, next-step auto-reset"
+                                   f"state obs, {'joint targets q_home +- U(0.2)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
                                    + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

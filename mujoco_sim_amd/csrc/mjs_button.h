@@ -24,113 +24,6 @@ using rr::NJ;
 constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, STATE_DIM = 16;
 constexpr int OBS_DIM = 13, ACT_DIM_JOINT = 7, ACT_DIM_EEF = 4;
 enum { FLAG_SWITCH_ACTIVE = 4, FLAG_SWITCH_PRESSED = 8 };
-constexpr int MAXROW = 24;  // 12 joint-limit slots + 3 contacts x 4 pyramid edges
-
-// ---------------------------------------------------------------- generic small Newton (nv = 6)
-// rows: J [nrow][6], D, aref; all rows are inequality rows (limits, contacts). Cold start at
-// qacc_smooth. Mirrors oracle/om_engine.c om_solve_constraint (MuJoCo mj_solPrimal, Newton).
-__device__ __noinline__ void solve_rows(const double (*Mf)[NJ], const double* qfrc_smooth, int nrow, const double (*J)[NJ], const double* D,
-                                        const double* aref, double* force, double* qfrc_constraint) {
-  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], jar[MAXROW], jv[MAXROW];
-  bool active[MAXROW];
-  for (int i = 0; i < NJ; i++) {
-    for (int j = 0; j < NJ; j++) L[i][j] = Mf[i][j];
-    a_s[i] = qfrc_smooth[i];
-  }
-  rr::chol6(L);
-  rr::chol6_solve(L, a_s);
-  for (int i = 0; i < NJ; i++) a[i] = a_s[i];
-  auto refresh = [&]() {
-    for (int i = 0; i < NJ; i++) {
-      double m = 0;
-      for (int k = 0; k < NJ; k++) m += Mf[i][k] * a[k];
-      Ma[i] = m;
-    }
-    for (int r = 0; r < nrow; r++) {
-      double x = -aref[r];
-      for (int k = 0; k < NJ; k++) x += J[r][k] * a[k];
-      jar[r] = x;
-    }
-  };
-  auto update = [&]() {
-    double cost = 0;
-    for (int r = 0; r < nrow; r++) {
-      bool act = jar[r] < 0;
-      active[r] = act;
-      force[r] = act ? -D[r] * jar[r] : 0.0;
-      if (act) cost += 0.5 * D[r] * jar[r] * jar[r];
-    }
-    double gauss = 0;
-    for (int i = 0; i < NJ; i++) gauss += (Ma[i] - qfrc_smooth[i]) * (a[i] - a_s[i]);
-    return cost + 0.5 * gauss;
-  };
-  refresh();
-  double cost = update();
-  const double scale = 1 / (UR5E_BP_MEANINERTIA * NJ);
-  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
-    double grad[NJ], search[NJ], Mv[NJ], H[NJ][NJ];
-    for (int i = 0; i < NJ; i++) {
-      double g = Ma[i] - qfrc_smooth[i];
-      for (int r = 0; r < nrow; r++) g -= J[r][i] * force[r];
-      grad[i] = g;
-      for (int j = 0; j <= i; j++) {
-        double h = Mf[i][j];
-        for (int r = 0; r < nrow; r++)
-          if (active[r]) h += J[r][i] * D[r] * J[r][j];
-        H[i][j] = h;
-      }
-      search[i] = -g;
-    }
-    if (!rr::chol6(H)) break;
-    rr::chol6_solve(H, search);
-    double g1 = 0, g2 = 0, snorm = 0;
-    for (int i = 0; i < NJ; i++) {
-      double m = 0;
-      for (int k = 0; k < NJ; k++) m += Mf[i][k] * search[k];
-      Mv[i] = m;
-    }
-    for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
-    if (sqrt(snorm) < MJS_MINVAL) break;
-    for (int r = 0; r < nrow; r++) {
-      double x = 0;
-      for (int k = 0; k < NJ; k++) x += J[r][k] * search[k];
-      jv[r] = x;
-    }
-    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
-    double alpha = 0, lo = 0, hi = INFINITY;
-    for (int it = 0; it < 50; it++) {
-      double d1 = g1 + alpha * g2, d2 = g2;
-      for (int r = 0; r < nrow; r++) {
-        double x = jar[r] + alpha * jv[r];
-        if (x < 0) { d1 += D[r] * x * jv[r]; d2 += D[r] * jv[r] * jv[r]; }
-      }
-      if (fabs(d1) < gtol) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
-      if (d2 <= 0) break;
-      double next = alpha + (-d1 / d2);
-      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
-      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
-      alpha = next;
-    }
-    if (alpha == 0) break;
-    for (int i = 0; i < NJ; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
-    for (int r = 0; r < nrow; r++) jar[r] += alpha * jv[r];
-    double oldcost = cost;
-    cost = update();
-    double gn = 0;
-    for (int i = 0; i < NJ; i++) {
-      double g = Ma[i] - qfrc_smooth[i];
-      for (int r = 0; r < nrow; r++) g -= J[r][i] * force[r];
-      gn += g * g;
-    }
-    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
-  }
-  for (int i = 0; i < NJ; i++) {
-    double f = 0;
-    for (int r = 0; r < nrow; r++) f += J[r][i] * force[r];
-    qfrc_constraint[i] = f;
-  }
-}
 
 // mju_makeFrame: two tangents for a unit normal
 MJS_DEV void make_frame(V3 n, V3& t1, V3& t2) {
@@ -143,7 +36,8 @@ MJS_DEV void make_frame(V3 n, V3& t1, V3& t2) {
 }
 
 struct ContactSet {
-  int n;             // detected contacts (dist <= 0) of the proxy sphere: floor, switch box, button cylinder
+  int n;             // number of detected contacts (dist <= 0) of the stand-in sphere
+  bool hit[3];       // fixed slots in MuJoCo's detection order: 0 floor, 1 switch box, 2 button cylinder
   double dist[3];
   V3 pos[3], nrm[3];
   double sgn[3];     // +1: the sphere is geom2 (plane-sphere), -1: the sphere is geom1
@@ -155,12 +49,16 @@ struct ContactSet {
 MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
   const double rp = MJS_G2F85_PROXY_RADIUS;
   cs.n = 0;
-  auto add = [&](double dist, V3 n, double sgn, bool on_switch) {
-    int k = cs.n++;
-    cs.dist[k] = dist; cs.nrm[k] = n; cs.sgn[k] = sgn; cs.on_switch[k] = on_switch;
-    cs.pos[k] = sgn > 0 ? madd(c, -(rp + 0.5 * dist), n) : madd(c, rp + 0.5 * dist, n);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    cs.hit[k] = false; cs.dist[k] = 0; cs.nrm[k] = v3(0, 0, 1); cs.pos[k] = v3(0, 0, 0); cs.sgn[k] = k == 0 ? 1.0 : -1.0; cs.on_switch[k] = k != 0;
+  }
+  auto add = [&](int k, double dist, V3 n) {
+    cs.n++;
+    cs.hit[k] = true; cs.dist[k] = dist; cs.nrm[k] = n;
+    cs.pos[k] = cs.sgn[k] > 0 ? madd(c, -(rp + 0.5 * dist), n) : madd(c, rp + 0.5 * dist, n);
   };
-  if (!(c.z > rp)) add(c.z - rp, v3(0, 0, 1), 1.0, false);
+  if (!(c.z > rp)) add(0, c.z - rp, v3(0, 0, 1));
   {  // box: clamp the centre into the box
     const double h = MJS_SW_BOX_HALF;
     V3 bc = v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF);
@@ -170,7 +68,7 @@ MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
     if (!inside) {
       V3 v = (bc + cl) - c;
       double len = sqrt(dot(v, v)), dist = len - rp;
-      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+      if (!(dist > 0.0)) add(1, dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v);
     } else {
       double best = INFINITY, sg = 1;
       int ax = 0;
@@ -181,7 +79,7 @@ MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
         if (h + l[k] < best) { best = h + l[k]; ax = k; sg = -1; }
       }
       V3 n = ax == 0 ? v3(-sg, 0, 0) : ax == 1 ? v3(0, -sg, 0) : v3(0, 0, -sg);
-      add(-(best + rp), n, -1.0, true);
+      add(1, -(best + rp), n);
     }
   }
   {  // button cylinder (axis z): side / cap / rim
@@ -195,16 +93,16 @@ MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
       V3 p = v3(cc.x, cc.y, cc.z + x);
       V3 v = p - c;
       double len = sqrt(dot(v, v)), dist = len - rp - r2;
-      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+      if (!(dist > 0.0)) add(2, dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v);
     } else if (a2 <= r2 * r2) {
       double sg = x > 0 ? 1.0 : -1.0, dist = fabs(x) - h2 - rp;
-      if (!(dist > 0.0)) add(dist, v3(0, 0, -sg), -1.0, true);
+      if (!(dist > 0.0)) add(2, dist, v3(0, 0, -sg));
     } else {
       double sg = x > 0 ? 1.0 : -1.0, la = sqrt(a2);
       V3 p = v3(cc.x + a.x / la * r2, cc.y + a.y / la * r2, cc.z + h2 * sg + a.z / la * r2);
       V3 v = p - c;
       double len = sqrt(dot(v, v)), dist = len - rp;
-      if (!(dist > 0.0)) add(dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v, -1.0, true);
+      if (!(dist > 0.0)) add(2, dist, len < MJS_MINVAL ? v3(1, 0, 0) : (1.0 / len) * v);
     }
   }
 }
@@ -213,78 +111,279 @@ MJS_DEV V3 proxy_centre(const rr::Chain& c) {
   return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS, c.R[6].cy);
 }
 
-// Constraint stage of one physics step for a lane that may have rows: joint limits + proxy contacts.
-// In: q, v, cos/sin, M (lower, no armature), qfrc_smooth. Out: qfrc_constraint added into rhs,
-// touch sensor value, number of detected proxy contacts, whether any row was active.
-__device__ __noinline__ void constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, const double A[NJ][NJ],
-                                              double* rhs, double& touch, int& ncon_proxy, bool& rows_active) {
-  double J[MAXROW][NJ], D[MAXROW], aref[MAXROW], force[MAXROW];
-  int nrow = 0;
-  touch = 0;
+// Constraint stage of one physics step for a lane that has rows: joint limits + stand-in sphere contacts.
+// STATIC row slots, everything unrolled (no indexed memory): 12 limit slots (2j = lower side of joint j, 2j+1 =
+// upper; J = +-e_j) and 3 contact slots (floor, switch box, button: the only pairs of this scene, in MuJoCo's
+// detection order) with 4 pyramid edges each, stored as the contact-frame Jacobian (normal, tangent 1, tangent 2)
+// so that edge e = Jn +- mu * Jt: the oracle's row order. Primal Newton of mj_solPrimal (cost, gradient, exact
+// Hessian, Cholesky, 1-D Newton line search with MuJoCo's stopping rules), cold-started at qacc_smooth.
+// Cold path (noinline, works on copies): `Mf` = full symmetric M + armature, `qs` = qfrc_smooth in, += qfrc_constraint out.
+constexpr int NCS = 3;
+struct ContactRows {
+  bool on[NCS];
+  double Jc[NCS][3][NJ];  // rows: normal, tangent 1, tangent 2 (already signed: geom2 - geom1)
+  double D[NCS], aref[NCS][4];
+};
+__device__ __noinline__ void constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, const double (*Mf)[NJ],
+                                              double* qs, double& touch) {
+  const double mu = MJS_GEOM_FRICTION_SLIDE;
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
   const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
   const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
-  // joint limits (mj_instantiateLimit), lower side first
-  for (int j = 0; j < NJ; j++)
-    for (int side = 0; side < 2; side++) {
-      double sgn = side == 0 ? 1.0 : -1.0;
-      double dist = side == 0 ? q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - q[j];
-      if (dist < 0.0) {
-        for (int k = 0; k < NJ; k++) J[nrow][k] = 0;
-        J[nrow][j] = sgn;
-        double imp = impedance_default(dist);
-        D[nrow] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_BP_DOF_INVWEIGHT0[j] / imp);
-        aref[nrow] = -B * (sgn * v[j]) - K * imp * dist;
-        nrow++;
-      }
+  // ---- rows
+  bool lon[rr::NLIM], any_lim = false;
+  double lD[rr::NLIM], laref[rr::NLIM];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+#pragma unroll
+    for (int side = 0; side < 2; side++) {  // mj_instantiateLimit, jnt_margin = 0
+      const int k = 2 * j + side;
+      const double sgn = side == 0 ? 1.0 : -1.0;
+      const double dist = side == 0 ? q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - q[j];
+      const double imp = impedance_default(dist);
+      lon[k] = dist < 0.0;
+      lD[k] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_BP_DOF_INVWEIGHT0[j] / imp);
+      laref[k] = -B * (sgn * v[j]) - K * imp * dist;
+      any_lim = any_lim || lon[k];
     }
-  // contacts of the gripper stand-in sphere
-  rr::Chain ch;
-  rr::fk_cs(cs, sn, ch);
-  ContactSet con;
-  detect_contacts(proxy_centre(ch), sw, con);
-  ncon_proxy = con.n;
-  int first_row[3] = {-1, -1, -1};
-  const double mu = MJS_GEOM_FRICTION_SLIDE;
-  for (int c = 0; c < con.n; c++) {
-    if (!(con.dist[c] < 0.0)) continue;  // detected but not active (dist == margin)
-    V3 t1, t2;
-    make_frame(con.nrm[c], t1, t2);
-    double Jc[3][NJ];
-    for (int j = 0; j < NJ; j++) {
-      V3 col = con.sgn[c] * cross(rr::joint_axis(ch, j), con.pos[c] - ch.p[j + 1]);  // (jac2 - jac1) column
-      Jc[0][j] = dot(con.nrm[c], col); Jc[1][j] = dot(t1, col); Jc[2][j] = dot(t2, col);
-    }
-    double imp = impedance_default(con.dist[c]);
-    double dA = UR5E_BP_EEF_BODY_INVWEIGHT0[0] + mu * mu * UR5E_BP_EEF_BODY_INVWEIGHT0[0];
-    double R0 = fmax(MJS_MINVAL, (1 - imp) * dA / imp);
-    double Dc = 1 / (2 * mu * mu * R0);
-    first_row[c] = nrow;
-    for (int k = 1; k < 3; k++)
-      for (int s = 1; s >= -1; s -= 2) {
-        double vel = 0;
-        for (int j = 0; j < NJ; j++) { J[nrow][j] = Jc[0][j] + s * mu * Jc[k][j]; vel += J[nrow][j] * v[j]; }
-        D[nrow] = Dc;
-        aref[nrow] = -B * vel - K * imp * con.dist[c];
-        nrow++;
-      }
   }
-  if (nrow == 0) return;
-  rows_active = true;
-  double Mf[NJ][NJ], fc[NJ];
+  // wave-uniform slot masks: a slot no lane of the wavefront uses costs nothing below (scalar branches)
+  const bool use_lim = __any(any_lim);
+  bool use_c[NCS];
+  ContactRows cr;
+  V3 cpos[NCS];
+  bool on_switch[NCS];
+  {
+    rr::Chain ch;
+    rr::fk_cs(cs, sn, ch);
+    ContactSet con;
+    detect_contacts(proxy_centre(ch), sw, con);
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      cr.on[c] = con.hit[c] && con.dist[c] < 0.0;  // detected but dist == margin creates no rows
+      use_c[c] = __any(cr.on[c]);
+      cpos[c] = con.pos[c];
+      on_switch[c] = con.on_switch[c];
+      if (!use_c[c]) continue;
+      V3 t1, t2;
+      make_frame(con.nrm[c], t1, t2);
+      double vel[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        V3 col = con.sgn[c] * cross(rr::joint_axis(ch, j), con.pos[c] - ch.p[j + 1]);  // (jac2 - jac1) column
+        cr.Jc[c][0][j] = dot(con.nrm[c], col); cr.Jc[c][1][j] = dot(t1, col); cr.Jc[c][2][j] = dot(t2, col);
+#pragma unroll
+        for (int r = 0; r < 3; r++) vel[r] += cr.Jc[c][r][j] * v[j];
+      }
+      const double imp = impedance_default(con.dist[c]);
+      const double dA = UR5E_BP_EEF_BODY_INVWEIGHT0[0] + mu * mu * UR5E_BP_EEF_BODY_INVWEIGHT0[0];
+      cr.D[c] = 1 / (2 * mu * mu * fmax(MJS_MINVAL, (1 - imp) * dA / imp));
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double ve = vel[0] + ((e & 1) ? -mu : mu) * vel[1 + (e >> 1)];
+        cr.aref[c][e] = -B * ve - K * imp * con.dist[c];
+      }
+    }
+  }
+  // ---- Newton
+  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], ljar[rr::NLIM], lforce[rr::NLIM], cjar[NCS][4], cforce[NCS][4];
+  bool lact[rr::NLIM], cact[NCS][4];
+#pragma unroll
   for (int i = 0; i < NJ; i++) {
-    for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? A[i][j] : A[j][i];
-    Mf[i][i] += MJS_UR_ARMATURE;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) L[i][j] = Mf[i][j];
+    a_s[i] = qs[i];
   }
-  solve_rows(Mf, rhs, nrow, J, D, aref, force, fc);
-  for (int j = 0; j < NJ; j++) rhs[j] += fc[j];
+  rr::chol6(L);
+  rr::chol6_solve(L, a_s);  // qacc_smooth
+#pragma unroll
+  for (int i = 0; i < NJ; i++) a[i] = a_s[i];
+  auto edge_values = [&](const double* x, int c, double* out4) {  // J_edge . x for the 4 edges of slot c
+    double u[3] = {0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) u[r] += cr.Jc[c][r][j] * x[j];
+    }
+    out4[0] = u[0] + mu * u[1]; out4[1] = u[0] - mu * u[1]; out4[2] = u[0] + mu * u[2]; out4[3] = u[0] - mu * u[2];
+  };
+  auto refresh = [&]() {
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * a[k];
+      Ma[i] = m;
+    }
+    if (use_lim) {
+#pragma unroll
+      for (int k = 0; k < rr::NLIM; k++) ljar[k] = -laref[k] + ((k & 1) ? -a[k >> 1] : a[k >> 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (!use_c[c]) continue;
+      double ja[4];
+      edge_values(a, c, ja);
+#pragma unroll
+      for (int e = 0; e < 4; e++) cjar[c][e] = ja[e] - cr.aref[c][e];
+    }
+  };
+  auto update = [&]() {
+    double cost = 0;
+    if (use_lim) {
+#pragma unroll
+      for (int k = 0; k < rr::NLIM; k++) {
+        const bool act = lon[k] && ljar[k] < 0;
+        lact[k] = act;
+        lforce[k] = act ? -lD[k] * ljar[k] : 0.0;
+        if (act) cost += 0.5 * lD[k] * ljar[k] * ljar[k];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (!use_c[c]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const bool act = cr.on[c] && cjar[c][e] < 0;
+        cact[c][e] = act;
+        cforce[c][e] = act ? -cr.D[c] * cjar[c][e] : 0.0;
+        if (act) cost += 0.5 * cr.D[c] * cjar[c][e] * cjar[c][e];
+      }
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) gauss += (Ma[i] - qs[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+  auto constraint_force = [&](double* f) {  // J^T force
+#pragma unroll
+    for (int i = 0; i < NJ; i++) f[i] = use_lim ? lforce[2 * i] - lforce[2 * i + 1] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (!use_c[c]) continue;
+      const double fn = cforce[c][0] + cforce[c][1] + cforce[c][2] + cforce[c][3];
+      const double f1 = mu * (cforce[c][0] - cforce[c][1]), f2 = mu * (cforce[c][2] - cforce[c][3]);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) f[i] += fn * cr.Jc[c][0][i] + f1 * cr.Jc[c][1][i] + f2 * cr.Jc[c][2][i];
+    }
+  };
+  refresh();
+  double cost = update();
+  const double scale = 1 / (UR5E_BP_MEANINERTIA * NJ);
+#pragma unroll 1
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[NJ], search[NJ], Mv[NJ], H[NJ][NJ], fc[NJ];
+    constraint_force(fc);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      grad[i] = Ma[i] - qs[i] - fc[i];
+      search[i] = -grad[i];
+#pragma unroll
+      for (int j = 0; j <= i; j++) H[i][j] = Mf[i][j];
+      if (use_lim && lact[2 * i]) H[i][i] += lD[2 * i];
+      if (use_lim && lact[2 * i + 1]) H[i][i] += lD[2 * i + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (!use_c[c]) continue;
+      // sum over active edges of D (Jn + s mu Jt_k)(Jn + s mu Jt_k)^T
+      const double n0 = cact[c][0], n1 = cact[c][1], n2 = cact[c][2], n3 = cact[c][3];
+      const double wn = cr.D[c] * (n0 + n1 + n2 + n3), w1 = cr.D[c] * mu * (n0 - n1), w2 = cr.D[c] * mu * (n2 - n3);
+      const double w11 = cr.D[c] * mu * mu * (n0 + n1), w22 = cr.D[c] * mu * mu * (n2 + n3);
+      if (wn != 0.0) {
+#pragma unroll
+        for (int i = 0; i < NJ; i++) {
+          const double jn = cr.Jc[c][0][i], j1 = cr.Jc[c][1][i], j2 = cr.Jc[c][2][i];
+          const double rn = wn * jn + w1 * j1 + w2 * j2, r1 = w1 * jn + w11 * j1, r2 = w2 * jn + w22 * j2;
+#pragma unroll
+          for (int j = 0; j <= i; j++) H[i][j] += rn * cr.Jc[c][0][j] + r1 * cr.Jc[c][1][j] + r2 * cr.Jc[c][2][j];
+        }
+      }
+    }
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m += Mf[i][k] * search[k];
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - qs[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    double cjv[NCS][4];
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (use_c[c]) edge_values(search, c, cjv[c]);
+    }
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+      if (use_lim) {
+#pragma unroll
+        for (int k = 0; k < rr::NLIM; k++) {
+          const double jv = (k & 1) ? -search[k >> 1] : search[k >> 1];
+          const double x = ljar[k] + alpha * jv;
+          if (lon[k] && x < 0) { d1 += lD[k] * x * jv; d2 += lD[k] * jv * jv; }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < NCS; c++) {
+        if (!use_c[c]) continue;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double x = cjar[c][e] + alpha * cjv[c][e];
+          if (cr.on[c] && x < 0) { d1 += cr.D[c] * x * cjv[c][e]; d2 += cr.D[c] * cjv[c][e] * cjv[c][e]; }
+        }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+    if (use_lim) {
+#pragma unroll
+      for (int k = 0; k < rr::NLIM; k++) ljar[k] += alpha * ((k & 1) ? -search[k >> 1] : search[k >> 1]);
+    }
+#pragma unroll
+    for (int c = 0; c < NCS; c++) {
+      if (!use_c[c]) continue;
+#pragma unroll
+      for (int e = 0; e < 4; e++) cjar[c][e] += alpha * cjv[c][e];
+    }
+    const double oldcost = cost;
+    cost = update();
+    constraint_force(fc);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      const double g = Ma[i] - qs[i] - fc[i];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  double fc[NJ];
+  constraint_force(fc);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) qs[j] += fc[j];
   // touch sensor (mj_sensorAcc): normal forces of contacts with the switch whose point is inside the site
   const double sr = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE, sh = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
-  for (int c = 0; c < con.n; c++) {
-    if (first_row[c] < 0 || !con.on_switch[c]) continue;
-    V3 loc = con.pos[c] - v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z);
-    if (loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh) continue;
-    touch += force[first_row[c]] + force[first_row[c] + 1] + force[first_row[c] + 2] + force[first_row[c] + 3];
+  touch = 0;
+#pragma unroll
+  for (int c = 0; c < NCS; c++) {
+    const V3 loc = cpos[c] - v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z);
+    const bool in_site = !(loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh);
+    if (use_c[c] && cr.on[c] && on_switch[c] && in_site) touch += cforce[c][0] + cforce[c][1] + cforce[c][2] + cforce[c][3];
   }
 }
 
@@ -305,7 +404,33 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
   touch = 0;
   ncon_proxy = 0;
-  if (maybe_rows) constraint_stage(q, v, cs, sn, sw, A, rhs, touch, ncon_proxy, rows_active);
+  if (maybe_rows) {
+    // cheap in-line detection: any joint beyond its range, any active contact of the stand-in sphere?
+    bool rows = false;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) rows = rows || (q[j] < MJS_UR_JNT_RANGE[j][0]) || (q[j] > MJS_UR_JNT_RANGE[j][1]);
+    rr::Chain ch;
+    rr::fk_cs(cs, sn, ch);
+    ContactSet con;
+    detect_contacts(proxy_centre(ch), sw, con);
+    ncon_proxy = con.n;
+#pragma unroll
+    for (int c = 0; c < 3; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
+    if (rows) {  // rare: hand copies to the out-of-line constraint stage, nothing of the hot path lives in memory
+      double Mf[NJ][NJ], qs[NJ];
+#pragma unroll
+      for (int i = 0; i < NJ; i++) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? A[i][j] : A[j][i];
+        Mf[i][i] += MJS_UR_ARMATURE;
+        qs[i] = rhs[i];
+      }
+      constraint_stage(q, v, cs, sn, sw, Mf, qs, touch);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) rhs[i] = qs[i];
+      rows_active = true;
+    }
+  }
   rr::factor_system(A, clamped, Dinv);
   rr::udu_solve(A, Dinv, rhs);
 #pragma unroll
@@ -386,14 +511,81 @@ __device__ __noinline__ uint8_t disturb(DevRng rng, int i, uint8_t flags) {
   return u < 0.01 ? (uint8_t)(flags & ~FLAG_SWITCH_ACTIVE) : flags;
 }
 
-template <bool IS_RESET>
-__global__ __launch_bounds__(64) void kernel(KernelParams p) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
+// The 20 substeps of one control step on ONE wavefront with the constraint stage available (robust path: taken
+// by a workgroup in which some env may get joint-limit or contact rows during this control step, and by
+// kernel_variant = single wave). noinline + by value, as rr::solo_control_step.
+struct SoloIn {
+  double q[NJ], v[NJ], q0[NJ], q1[NJ], cs[NJ], sn[NJ], time, t0, t1, sw[3];
+  uint8_t flags;
+  bool maybe_rows;
+};
+struct SoloOut {
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], time;
+  uint8_t flags;
+  bool bad, rows_active;
+};
+__device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { q[j] = in.q[j]; v[j] = in.v[j]; cs[j] = in.cs[j]; sn[j] = in.sn[j]; q0[j] = in.q0[j]; q1[j] = in.q1[j]; }
+  double time = in.time;
+  const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
+  const V3 sw = v3(in.sw[0], in.sw[1], in.sw[2]);
+  const bool maybe_rows = in.maybe_rows;
+  uint8_t flags = in.flags;
+  bool bad = false, rows_active = false;
+  int ncon_proxy = 0;
+#pragma unroll 1
+  for (int s = 0; s < MJS_RR_NSUB; s++) {
+    double t = fmin(fmax(time, t0), t1);
+    double ctrl[NJ], qacc[NJ], touch;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    physics_forces(q, v, ctrl, cs, sn, sw, maybe_rows, qacc, touch, ncon_proxy, rows_active);
+    double acc2 = 0, dq2 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      acc2 = fma(qacc[j], qacc[j], acc2);
+      v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+      double dq = MJS_RR_PHYSICS_DT * v[j];
+      q[j] += dq;
+      dq2 = fma(dq, dq, dq2);
+      rr::rotate_small(cs[j], sn[j], dq);
+    }
+    bad = bad || !(acc2 <= 1e20);
+    if (!(dq2 <= 0.01)) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(q[j], &sn[j], &cs[j]);
+    }
+    time += MJS_RR_PHYSICS_DT;
+    switch_update(touch, flags);  // Switch.after_substep (switch.py:71-72)
+  }
+  SoloOut o;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; }
+  o.time = time;
+  o.flags = flags;
+  o.bad = bad;
+  o.rows_active = rows_active;
+  return o;
+}
+
+// ROLES == 2 (default for stepping): the role-specialised pair of wavefronts of rr::kernel (role 0: M(q), U D U^T,
+// U^-1; role 1: servo set-point, actuators, bias forces; two LDS exchanges per substep) with this scene's
+// generated dynamics, for workgroups in which no env can get constraint rows during the control step; the others
+// take solo_control_step on role 0.
+template <bool IS_RESET, int ROLES>
+__global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
+  const int lane = threadIdx.x & 63;
+  const int role = (ROLES == 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  const int i = blockIdx.x * 64 + lane;
+  __shared__ double xch[ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
   double obs[OBS_DIM];
   rr::Chain c;
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
     ResetOut r = episode_init(p.rng, i, flags);
     rr::store_state(p, i, r.st);
@@ -405,7 +597,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   }
   rr::State st = rr::load_state(p, i);
   const V3 sw = v3(st.target[0], st.target[1], st.target[2]);
-  // before_step (robot_push_button.py:143-157)
+  // before_step (robot_push_button.py:143-157); evaluated by both roles (same result)
   const int adim = p.action_type == MJS_ACTION_ABS_EEF ? ACT_DIM_EEF : ACT_DIM_JOINT;
   double q0[NJ], q1[NJ];
 #pragma unroll
@@ -430,32 +622,86 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p) {
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
   rr::fk_cs(cs, sn, c);
   const bool maybe_rows = rows_possible(st.q, c, sw);
-  int ncon_proxy = 0;
+  const bool solo = (ROLES == 1) || __any(maybe_rows);  // both roles: same data, same decision
+  if (solo) {
+    if (role != 0) return;
+    SoloIn in;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
+    in.time = st.time; in.t0 = t0; in.t1 = t1;
+    in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
+    in.flags = flags; in.maybe_rows = maybe_rows;
+    SoloOut o = solo_control_step(in);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
+    st.time = o.time;
+    flags = o.flags;
+    bad = o.bad;
+    rows_active = o.rows_active;
+  } else if constexpr (ROLES == 2) {
 #pragma unroll 1
-  for (int s = 0; s < MJS_RR_NSUB; s++) {
-    double t = fmin(fmax(st.time, t0), t1);
-    double ctrl[NJ], qacc[NJ], touch;
+    for (int s = 0; s < MJS_RR_NSUB; s++) {
+      double qacc[NJ];
+      const double t = fmin(fmax(st.time, t0), t1);
+      double ctrl[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    physics_forces(st.q, st.v, ctrl, cs, sn, sw, maybe_rows, qacc, touch, ncon_proxy, rows_active);
-    double acc2 = 0, dq2 = 0;
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+      if (role == 1) {
+        double bias[NJ], fact[NJ];
+        rr::actuator_forces(st.q, st.v, ctrl, fact);
+        ur5e_bp_bias_gen(cs, sn, st.v, bias);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      acc2 = fma(qacc[j], qacc[j], acc2);
-      st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
-      double dq = MJS_RR_PHYSICS_DT * st.v[j];
-      st.q[j] += dq;
-      dq2 = fma(dq, dq, dq2);
-      rr::rotate_small(cs[j], sn[j], dq);
+        for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+        __syncthreads();  // qfrc_smooth published
+        __syncthreads();  // qacc published
+#pragma unroll
+        for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
+      } else {
+        double fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+        const int clamped = rr::actuator_forces(st.q, st.v, ctrl, fdummy);
+        ur5e_bp_M_gen(cs, sn, M);
+#pragma unroll
+        for (int r = 0; r < NJ; r++) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+        }
+        rr::factor_system(A, clamped, Dinv);
+        rr::invert_unit_upper(A, W);
+#pragma unroll
+        for (int r = 0; r < NJ; r++) {  // opaque register uses pin the whole factorisation before the barrier
+          asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+          for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+        }
+        __syncthreads();  // qfrc_smooth published
+#pragma unroll
+        for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
+        rr::apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
+        __syncthreads();  // qacc published
+      }
+      double acc2 = 0, dq2 = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        acc2 = fma(qacc[j], qacc[j], acc2);
+        st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+        double dq = MJS_RR_PHYSICS_DT * st.v[j];
+        st.q[j] += dq;
+        dq2 = fma(dq, dq, dq2);
+        rr::rotate_small(cs[j], sn[j], dq);
+      }
+      bad = bad || !(acc2 <= 1e20);
+      if (!(dq2 <= 0.01)) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+      }
+      st.time += MJS_RR_PHYSICS_DT;
     }
-    bad = bad || !(acc2 <= 1e20);
-    if (!(dq2 <= 0.01)) {
-#pragma unroll
-      for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-    }
-    st.time += MJS_RR_PHYSICS_DT;
-    switch_update(touch, flags);  // Switch.after_substep (switch.py:71-72)
+    // no contact was possible: the touch sensor read 0 after every substep (Switch.after_substep)
+    flags = (uint8_t)(flags & ~FLAG_SWITCH_PRESSED);
   }
+  if (role != 0) return;
   // after_step (robot_push_button.py:159-165): rand() is drawn only for an active, released switch
   if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = disturb(p.rng, i, flags);
 #pragma unroll

@@ -131,7 +131,10 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) bp::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
+    if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+    else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
+  }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);  // two role-specialised waves per 64 envs
   HIP_TRY(h, hipGetLastError());

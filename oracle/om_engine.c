@@ -786,6 +786,7 @@ static double constraint_update(const om_model* m, om_data* d, const double* jar
 
 /* exact minimiser of the piecewise-quadratic cost along `search` (role of PrimalSearch) */
 /* debug statistics (tests / tuning only) */
+int om_dbg_cold_start = 0; /* test knob: ignore qacc_warmstart */
 long om_dbg_ls_calls = 0, om_dbg_ls_iters = 0, om_dbg_ls_max = 0, om_dbg_newton_calls = 0, om_dbg_newton_iters = 0, om_dbg_newton_max = 0;
 
 /* 1-D Newton with bracketing on the piecewise-quadratic cost along `search`. Stops like MuJoCo's
@@ -828,7 +829,7 @@ static void om_solve_constraint(const om_model* m, om_data* d) {
   double qacc[OM_MAXV], Ma[OM_MAXV], grad[OM_MAXV], search[OM_MAXV], Mv[OM_MAXV];
   /* warmstart: pick the cheaper of qacc_warmstart and qacc_smooth */
   double best = INFINITY;
-  for (int trial = 0; trial < 2; trial++) {
+  for (int trial = om_dbg_cold_start ? 1 : 0; trial < 2; trial++) {
     const double* q0 = trial == 0 ? d->qacc_warmstart : d->qacc_smooth;
     double ma[OM_MAXV], jr[OM_MAXEFC];
     for (int i = 0; i < nv; i++) { ma[i] = 0; for (int k = 0; k < nv; k++) ma[i] += d->M[i][k] * q0[k]; }
