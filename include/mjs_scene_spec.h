@@ -214,6 +214,37 @@ MJS_K double MJS_CAM_SPHERE_RADIUS = 0.0125;
 MJS_K double MJS_BP_CAM_POS[3] = {0.0, -1.7, 0.7};             /* scene camera, robot_push_button.py:51-52 */
 MJS_K double MJS_BP_CAM_QUAT[4] = {-0.7, -0.35, 0.0, 0.0};
 MJS_K double MJS_BP_CAM_FOVY = 70.0;
+/* ------------------------------------------------------------ Planar-Push (a13) [REF] tasks/robot_planar_push.py
+ * :29-73 config, :81-117 scene, :149-176 reset; entities/eef/cylinder.py:23-33; entities/props/google_block.py:37-49;
+ * mjcf/google_language_table_blocks/cube.{xml,obj}. The block is a bevelled-cube MESH in the reference (bounding box
+ * x,z in +-0.019826, y in [0, 0.0381], geom quat (1,1,0,0): mesh y -> body z, body origin = centre of the bottom face);
+ * here it is a BOX of that bounding box (deviation D-9). */
+MJS_K int    MJS_PP_MAX_OBJECTS = 2;              /* BASELINE config 4: 2 objects (reference default n_objects = 5) */
+MJS_K int    MJS_PP_MAX_CONTROL_STEPS = 500;      /* :53 */
+MJS_K double MJS_PP_TARGET_RADIUS = 0.05;         /* :60 */
+MJS_K double MJS_PP_NEAREST_COEF = 0.1;           /* :59 */
+MJS_K double MJS_PP_REWARD_SCALE = 0.1;           /* :220 */
+MJS_K double MJS_PP_ACTION_Z = 0.02;              /* :199 */
+MJS_K int    MJS_PP_SETTLE_STEPS = 150;           /* :160-161 */
+MJS_K double MJS_PP_ROBOT_SPACE_LO[3] = {-0.2, -0.6, 0.02};   /* :103 */
+MJS_K double MJS_PP_ROBOT_SPACE_HI[3] = {0.2, -0.3, 0.02};
+MJS_K double MJS_PP_OBJECT_SPACE_LO[3] = {-0.15, -0.55, 0.05}; /* :104 */
+MJS_K double MJS_PP_OBJECT_SPACE_HI[3] = {0.15, -0.35, 0.2};
+MJS_K double MJS_PP_TARGET_SPACE_LO[3] = {-0.15, -0.55, 0.001}; /* :105 */
+MJS_K double MJS_PP_TARGET_SPACE_HI[3] = {0.15, -0.35, 0.005};
+MJS_K double MJS_PP_TARGET_DEFAULT_POS[3] = {0.0, -0.5, 0.001};
+/* CylinderEEF: MJS_CYL_* above */
+/* block stand-in: box half extents, mass (google_block.py:33), geom centre above the body origin, contact parameters
+ * (google_block.py:47-49: condim 4, friction (1, 0.05, 0)) */
+MJS_K double MJS_BLOCK_HALF[3] = {0.019826, 0.019826, 0.01905};
+MJS_K double MJS_BLOCK_MASS = 0.1;
+MJS_K double MJS_BLOCK_GEOM_Z = 0.01905;
+MJS_K int    MJS_BLOCK_CONDIM = 4;
+MJS_K double MJS_BLOCK_FRICTION[3] = {1.0, 0.05, 0.0};
+/* own MPR (Minkowski portal refinement) parameters for convex-convex pairs (cylinder-box, box-box) */
+MJS_K int    MJS_MPR_MAX_ITER = 48;
+MJS_K double MJS_MPR_TOLERANCE = 1e-6;
+
 /* collision stand-in for the CLOSED 2F-85 finger tips (deviation D-1): a sphere whose lowest point is
  * the TCP, on the lumped gripper body. Own choice, not in the reference. */
 MJS_K double MJS_G2F85_PROXY_RADIUS = 0.012;

@@ -12,6 +12,7 @@ from .oracle import (  # noqa: F401
     TASK_POINTMASS,
     TASK_ROBOT_REACH,
     TASK_BUTTON_PUSH,
+    TASK_PLANAR_PUSH,
     ACTION_ABS_JOINT,
     ACTION_ABS_EEF,
     OracleBatch,

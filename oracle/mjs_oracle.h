@@ -141,6 +141,8 @@ typedef struct {
   int terminate_on_success;  /* Robot-Reach only: opt-in (deviation D-2) */
   int action_type;           /* Button-Push only */
   int button_disturbances;   /* Button-Push only: robot_push_button.py:159-165 */
+  int n_objects;             /* Planar-Push only: 1..MJS_PP_MAX_OBJECTS blocks */
+  int max_episode_steps;     /* Planar-Push only: RobotTask step limit (base.py:47-51), default 500 */
 } om_task_config;
 
 #define OM_MAXOBS 16
@@ -167,6 +169,8 @@ typedef struct {
   /* Switch entity state (entities/props/switch.py:10-16,51-60) */
   int switch_active, switch_pressed, switch_num_pressed;
   double switch_pos[3];
+  /* Planar-Push: RobotTask.episode_step (base.py:29-32) */
+  int episode_step;
 } om_env;
 
 void om_default_config(int task, om_task_config* cfg);
@@ -184,6 +188,11 @@ void om_render_robot(const om_env* e, int H, int W, uint8_t* out);
 void om_render_camera(const om_env* e, int camera, int H, int W, uint8_t* out);
 void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out);
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
+int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time);
+void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);
+void om_debug_substeps(om_env* e, int n);
+int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,
+                    const double* mat2, double* out);
 void om_debug_reach_dynamics(const double* q, const double* v, double* M_out, double* bias_out);
 
 /* batch helpers for the CPU baseline / parity tests (OpenMP over envs) */

@@ -388,6 +388,20 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
       }
     }
     (void)cnt;
+  } else if (m->geom_type[g2] == OM_GEOM_BOX) {
+    /* mjc_PlaneBox: every corner at or below the plane (margin 0) is a contact, at most 4; corner order
+     * (-,-,-), (+,-,-), (-,+,-), (+,+,-), (-,-,+), ... (x fastest) */
+    int cnt = 0;
+    for (int i = 0; i < 8 && cnt < 4; i++) {
+      double loc[3] = {(i & 1 ? sz[0] : -sz[0]), (i & 2 ? sz[1] : -sz[1]), (i & 4 ? sz[2] : -sz[2])}, corner[3];
+      mulMatVec3(corner, gm, loc);
+      for (int k = 0; k < 3; k++) corner[k] += gp[k];
+      for (int k = 0; k < 3; k++) tmp[k] = corner[k] - pp[k];
+      double dist = dot3(tmp, n);
+      if (dist > margin) continue;
+      for (int k = 0; k < 3; k++) pos[k] = corner[k] - n[k] * dist * 0.5;
+      cnt += add_contact(m, d, g1, g2, dist, pos, n);
+    }
   }
 }
 
@@ -465,6 +479,153 @@ static void collide_sphere_box(const om_model* m, om_data* d, int g1, int g2) {
   }
 }
 
+/* ------------------------------------------------------------------ convex-convex (own MPR)
+ * Minkowski portal refinement (Snethen, "XenoCollide", Game Programming Gems 7) on the Minkowski difference
+ * geom1 - geom2 for the convex pairs of the Planar-Push scene (cylinder-box, box-box); the role of MuJoCo's
+ * mjc_Convex -> libccd ccdMPRPenetration for mesh / cylinder pairs. One contact per pair: normal = the final
+ * portal's normal (pointing from geom1 to geom2), depth = distance of that portal's plane from the origin,
+ * position = midpoint of the two witness points (barycentric weights of the origin ray in the portal).
+ * Plain + - * / sqrt arithmetic, compiled without FMA contraction: the HIP kernel repeats the same operations. */
+typedef struct { double v[3], a[3], b[3]; } mpr_vert; /* v = a - b, a on geom1, b on geom2 */
+
+static void support_geom(const om_model* m, const om_data* d, int g, const double* dir, double* out) {
+  const double* gp = d->geom_xpos[g];
+  const double* gm = d->geom_xmat[g];
+  const double* sz = m->geom_size[g];
+  double loc[3], res[3];
+  for (int k = 0; k < 3; k++) loc[k] = gm[k] * dir[0] + gm[3 + k] * dir[1] + gm[6 + k] * dir[2]; /* R^T dir */
+  if (m->geom_type[g] == OM_GEOM_BOX) {
+    for (int k = 0; k < 3; k++) res[k] = loc[k] >= 0 ? sz[k] : -sz[k];
+  } else { /* cylinder, axis = local z */
+    double len = sqrt(loc[0] * loc[0] + loc[1] * loc[1]);
+    if (len > 1e-12) { res[0] = sz[0] * loc[0] / len; res[1] = sz[0] * loc[1] / len; } else { res[0] = 0; res[1] = 0; }
+    res[2] = loc[2] >= 0 ? sz[1] : -sz[1];
+  }
+  mulMatVec3(out, gm, res);
+  for (int k = 0; k < 3; k++) out[k] += gp[k];
+}
+static void mpr_support(const om_model* m, const om_data* d, int g1, int g2, const double* dir, mpr_vert* s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  support_geom(m, d, g1, dir, s->a);
+  support_geom(m, d, g2, nd, s->b);
+  for (int k = 0; k < 3; k++) s->v[k] = s->a[k] - s->b[k];
+}
+static int normalize3(double* v) {
+  double n = norm3(v);
+  if (n < 1e-14) return 0;
+  for (int k = 0; k < 3; k++) v[k] /= n;
+  return 1;
+}
+static void any_perpendicular(double* out, const double* v) {
+  double ax[3] = {0, 0, 0};
+  int k = fabs(v[0]) <= fabs(v[1]) ? (fabs(v[0]) <= fabs(v[2]) ? 0 : 2) : (fabs(v[1]) <= fabs(v[2]) ? 1 : 2);
+  ax[k] = 1;
+  cross3(out, v, ax);
+}
+/* returns 1 and fills (depth >= 0, normal geom1->geom2, pos) when the geoms overlap */
+static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, double* depth, double* normal, double* pos) {
+  mpr_vert v0, v1, v2, v3, v4;
+  double dir[3], t1[3], t2[3];
+  for (int k = 0; k < 3; k++) { v0.a[k] = d->geom_xpos[g1][k]; v0.b[k] = d->geom_xpos[g2][k]; v0.v[k] = v0.a[k] - v0.b[k]; }
+  if (norm3(v0.v) < 1e-12) v0.v[0] = 1e-5; /* coincident centres: any interior direction */
+  for (int k = 0; k < 3; k++) dir[k] = -v0.v[k];
+  normalize3(dir);
+  mpr_support(m, d, g1, g2, dir, &v1);
+  if (dot3(v1.v, dir) <= 0) return 0;
+  cross3(dir, v0.v, v1.v);
+  if (!normalize3(dir)) { any_perpendicular(dir, v0.v); normalize3(dir); } /* origin on the line v0-v1 */
+  mpr_support(m, d, g1, g2, dir, &v2);
+  if (dot3(v2.v, dir) <= 0) return 0;
+  for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
+  cross3(dir, t1, t2);
+  if (!normalize3(dir)) return 0;
+  if (dot3(dir, v0.v) > 0) { mpr_vert t = v1; v1 = v2; v2 = t; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
+  /* portal discovery */
+  for (int it = 0;; it++) {
+    if (it >= MJS_MPR_MAX_ITER) return 0;
+    mpr_support(m, d, g1, g2, dir, &v3);
+    if (dot3(v3.v, dir) <= 0) return 0;
+    int cont = 0;
+    cross3(t1, v1.v, v3.v);
+    if (dot3(t1, v0.v) < 0) { v2 = v3; cont = 1; }
+    else {
+      cross3(t1, v3.v, v2.v);
+      if (dot3(t1, v0.v) < 0) { v1 = v3; cont = 1; }
+    }
+    if (!cont) break;
+    for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
+    cross3(dir, t1, t2);
+    if (!normalize3(dir)) return 0;
+  }
+  /* portal refinement */
+  int hit = 0;
+  for (int it = 0; it < MJS_MPR_MAX_ITER; it++) {
+    for (int k = 0; k < 3; k++) { t1[k] = v2.v[k] - v1.v[k]; t2[k] = v3.v[k] - v1.v[k]; }
+    cross3(dir, t1, t2);
+    if (!normalize3(dir)) return 0;
+    if (dot3(dir, v1.v) >= 0) hit = 1; /* the origin is on the inner side of the portal: the shapes overlap */
+    mpr_support(m, d, g1, g2, dir, &v4);
+    double reach = dot3(v4.v, dir);
+    if (!hit && reach < 0) return 0; /* the support plane separates the origin */
+    for (int k = 0; k < 3; k++) t1[k] = v4.v[k] - v3.v[k];
+    double progress = dot3(t1, dir);
+    if (progress <= MJS_MPR_TOLERANCE || it == MJS_MPR_MAX_ITER - 1) {
+      if (!hit) return 0;
+      /* converged: the portal v1 v2 v3 lies on the surface of the Minkowski difference */
+      *depth = dot3(v1.v, dir);
+      for (int k = 0; k < 3; k++) normal[k] = dir[k]; /* portal normal points away from v0 = c1 - c2: geom1 -> geom2 */
+      /* barycentric coordinates of the origin in the tetrahedron (v0, v1, v2, v3) by Cramer's rule:
+       * [v1 v2 v3] v0 - [v0 v2 v3] v1 + [v0 v1 v3] v2 - [v0 v1 v2] v3 = 0 */
+      double c23[3], c13[3], c12[3], b0, b1, b2, b3, sum;
+      cross3(c23, v2.v, v3.v); cross3(c13, v1.v, v3.v); cross3(c12, v1.v, v2.v);
+      b0 = dot3(v1.v, c23); b1 = -dot3(v0.v, c23); b2 = dot3(v0.v, c13); b3 = -dot3(v0.v, c12);
+      sum = b0 + b1 + b2 + b3;
+      if (fabs(sum) < 1e-30) { b0 = 0; b1 = b2 = b3 = 1; sum = 3; } /* degenerate: portal centroid */
+      for (int k = 0; k < 3; k++) {
+        double pa = (b0 * v0.a[k] + b1 * v1.a[k] + b2 * v2.a[k] + b3 * v3.a[k]) / sum;
+        double pb = (b0 * v0.b[k] + b1 * v1.b[k] + b2 * v2.b[k] + b3 * v3.b[k]) / sum;
+        pos[k] = 0.5 * (pa + pb);
+      }
+      return 1;
+    }
+    /* expand the portal with v4: keep the face the ray origin->(-v0) passes through */
+    cross3(t1, v4.v, v0.v);
+    if (dot3(v1.v, t1) > 0) {
+      if (dot3(v2.v, t1) > 0) v1 = v4; else v3 = v4;
+    } else {
+      if (dot3(v3.v, t1) > 0) v2 = v4; else v1 = v4;
+    }
+  }
+  return 0;
+}
+static double geom_rbound(const om_model* m, int g) {
+  const double* sz = m->geom_size[g];
+  if (m->geom_type[g] == OM_GEOM_BOX) return sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+  return sqrt(sz[0] * sz[0] + sz[1] * sz[1]); /* cylinder */
+}
+static void collide_convex(const om_model* m, om_data* d, int g1, int g2) {
+  double diff[3], depth, normal[3], pos[3];
+  for (int k = 0; k < 3; k++) diff[k] = d->geom_xpos[g2][k] - d->geom_xpos[g1][k];
+  double bound = geom_rbound(m, g1) + geom_rbound(m, g2);
+  if (dot3(diff, diff) > bound * bound) return; /* bounding-sphere filter (margin 0) */
+  if (!mpr_penetration(m, d, g1, g2, &depth, normal, pos)) return;
+  add_contact(m, d, g1, g2, -depth, pos, normal);
+}
+
+/* debug hook for tests: penetration of two convex geoms (type, size[3], pos[3], xmat[9] row-major each);
+ * returns 1 when overlapping and fills out = {depth, normal[3], pos[3]} */
+int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,
+                    const double* mat2, double* out) {
+  static __thread om_model m;
+  static __thread om_data d;
+  m.ngeom = 2;
+  m.geom_type[0] = type1; m.geom_type[1] = type2;
+  memcpy(m.geom_size[0], size1, sizeof(double) * 3); memcpy(m.geom_size[1], size2, sizeof(double) * 3);
+  memcpy(d.geom_xpos[0], pos1, sizeof(double) * 3); memcpy(d.geom_xpos[1], pos2, sizeof(double) * 3);
+  memcpy(d.geom_xmat[0], mat1, sizeof(double) * 9); memcpy(d.geom_xmat[1], mat2, sizeof(double) * 9);
+  return mpr_penetration(&m, &d, 0, 1, out, out + 1, out + 4);
+}
+
 static int body_weld(const om_model* m, int b) { return m->body_weldid[b]; }
 
 static void om_collision(const om_model* m, om_data* d) {
@@ -485,6 +646,7 @@ static void om_collision(const om_model* m, om_data* d) {
       if (t1 == OM_GEOM_PLANE && t2 != OM_GEOM_PLANE) collide_plane(m, d, ga, gb);
       else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_CYLINDER) collide_sphere_cylinder(m, d, ga, gb);
       else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_BOX) collide_sphere_box(m, d, ga, gb);
+      else if ((t1 == OM_GEOM_CYLINDER || t1 == OM_GEOM_BOX) && t2 == OM_GEOM_BOX) collide_convex(m, d, ga, gb);
       /* other pairs (capsule-capsule, capsule-box, ...): not evaluated */
     }
 }

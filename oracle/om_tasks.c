@@ -216,6 +216,31 @@ static void build_button(om_model* m) {
   om_set_const(m);
 }
 
+/* Planar-Push scene (robot_planar_push.py:81-117): UR5e + CylinderEEF (cylinder.py:23-33) + n free blocks
+ * (box stand-in for the cube mesh of google_block.py, deviation D-9); the target is a site (no collision). */
+static void build_push(om_model* m, int n_objects) {
+  build_robot(m, 0);
+  const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
+  int wrist3 = m->nbody - 1;
+  double r = MJS_CYL_RADIUS, h = MJS_CYL_HALFLEN, mc = MJS_CYL_MASS;
+  double ixx = mc * (3 * r * r + 4 * h * h) / 12;
+  const double cyl_inertia[3] = {ixx, ixx, 0.5 * mc * r * r}, cyl_pos[3] = {0, 0, MJS_CYL_POS_Z};
+  int eef = add_body(m, wrist3, MJS_UR_FLANGE_POS, MJS_UR_FLANGE_QUAT, mc, cyl_pos, ident, cyl_inertia, 0.0);
+  add_geom(m, eef, OM_GEOM_CYLINDER, cyl_pos, ident, r, h, 0);
+  for (int i = 0; i < n_objects; i++) {
+    double a = MJS_BLOCK_HALF[0], b = MJS_BLOCK_HALF[1], c = MJS_BLOCK_HALF[2], mb = MJS_BLOCK_MASS;
+    const double inertia[3] = {mb * (b * b + c * c) / 3, mb * (a * a + c * c) / 3, mb * (a * a + b * b) / 3};
+    const double gpos[3] = {0, 0, MJS_BLOCK_GEOM_Z};
+    int blk = add_body(m, 0, zero3, ident, mb, gpos, ident, inertia, 0.0);
+    int j = add_joint(m, blk, OM_JNT_FREE, NULL, 0, 0, 0, 0);
+    m->qpos0[m->jnt_qposadr[j] + 3] = 1.0;
+    int g = add_geom(m, blk, OM_GEOM_BOX, gpos, ident, a, b, c);
+    m->geom_condim[g] = MJS_BLOCK_CONDIM;
+    for (int k = 0; k < 3; k++) m->geom_friction[g][k] = MJS_BLOCK_FRICTION[k];
+  }
+  om_set_const(m);
+}
+
 /* ------------------------------------------------------------ task API */
 void om_default_config(int task, om_task_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
@@ -224,6 +249,11 @@ void om_default_config(int task, om_task_config* cfg) {
   if (task == OM_TASK_POINTMASS) {
     cfg->reward_type = OM_REW_DENSE_BIASED_NEG_DISTANCE;                  /* point_reach.py:63 */
     cfg->time_limit = MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT;      /* __init__.py:21,28 */
+  } else if (task == OM_TASK_PLANAR_PUSH) {
+    cfg->reward_type = OM_REW_DENSE_NEG_DISTANCE;                         /* robot_planar_push.py:69 */
+    cfg->time_limit = 1e300;                                              /* scripts/sb3/planar_push.py:72: no Environment time limit */
+    cfg->n_objects = MJS_PP_MAX_OBJECTS;                                  /* BASELINE config 4 */
+    cfg->max_episode_steps = MJS_PP_MAX_CONTROL_STEPS;                    /* robot_planar_push.py:53 */
   } else if (task == OM_TASK_BUTTON_PUSH) {
     cfg->reward_type = OM_REW_SPARSE;                                     /* robot_push_button.py:47 */
     cfg->time_limit = MJS_BP_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      /* __init__.py:32-34 */
@@ -234,8 +264,9 @@ void om_default_config(int task, om_task_config* cfg) {
   }
 }
 /* Button-Push flat obs: ur5e/joint_configuration(6), ur5e/tcp_position(3), switch position(3), active(1) */
-int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : task == OM_TASK_BUTTON_PUSH ? 13 : 12; }
-int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : task == OM_TASK_BUTTON_PUSH ? 7 : 3; }
+/* Planar-Push flat obs: ur5e/tcp_position(3), target_position(2), block_positions(2 per block, MAX_OBJECTS slots) */
+int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : task == OM_TASK_BUTTON_PUSH ? 13 : task == OM_TASK_PLANAR_PUSH ? 5 + 2 * MJS_PP_MAX_OBJECTS : 12; }
+int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : task == OM_TASK_BUTTON_PUSH ? 7 : task == OM_TASK_PLANAR_PUSH ? 2 : 3; }
 int om_sizeof_step_out(void) { return (int)sizeof(om_step_out); }
 
 void om_env_seed(om_env* e, uint32_t seed) { om_rng_seed(&e->rng, seed); }
@@ -245,6 +276,7 @@ void om_env_init(om_env* e, const om_task_config* cfg, uint32_t seed) {
   e->cfg = *cfg;
   if (cfg->task == OM_TASK_POINTMASS) { build_pointmass(&e->m); e->n_sub = (int)round(MJS_PM_CONTROL_DT / MJS_PM_PHYSICS_DT); }
   else if (cfg->task == OM_TASK_BUTTON_PUSH) { build_button(&e->m); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
+  else if (cfg->task == OM_TASK_PLANAR_PUSH) { build_push(&e->m, cfg->n_objects); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   else { build_robot(&e->m, 1); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   e->distance_to_target = 1.0;          /* point_reach.py:112-113 */
   e->previous_distance_to_target = 1.0;
@@ -270,13 +302,19 @@ static void get_tcp_position(const om_env* e, double* tcp) {
   /* robot.py:153-168: flange site pose, then the TCP offset along the flange z axis */
   const double* p = e->d.site_xpos[0];
   const double* R = e->d.site_xmat[0];
-  for (int k = 0; k < 3; k++) tcp[k] = p[k] + R[3 * k + 2] * MJS_G2F85_TCP_Z;
+  const double tcp_z = e->cfg.task == OM_TASK_PLANAR_PUSH ? MJS_CYL_TCP_Z : MJS_G2F85_TCP_Z;
+  for (int k = 0; k < 3; k++) tcp[k] = p[k] + R[3 * k + 2] * tcp_z;
 }
 
 static void write_obs(const om_env* e, double* obs) {
   if (e->cfg.task == OM_TASK_POINTMASS) {
     obs[0] = e->d.xpos[2][0]; obs[1] = e->d.xpos[2][1];     /* pointmass/position (pointmass.py:87-98) */
     obs[2] = e->target_pos[0]; obs[3] = e->target_pos[1];   /* goal_position (point_reach.py:211-212) */
+  } else if (e->cfg.task == OM_TASK_PLANAR_PUSH) {
+    get_tcp_position(e, obs);                                /* ur5e/tcp_position */
+    obs[3] = e->target_pos[0]; obs[4] = e->target_pos[1];   /* target_position = site.pos[:2] (robot_planar_push.py:120) */
+    for (int i = 0; i < MJS_PP_MAX_OBJECTS; i++)             /* block_positions = body xpos[:2] per block (:178-179) */
+      for (int k = 0; k < 2; k++) obs[5 + 2 * i + k] = i < e->cfg.n_objects ? e->d.qpos[6 + 7 * i + k] : 0.0;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
     for (int j = 0; j < 6; j++) obs[j] = e->d.qpos[j];       /* ur5e/joint_configuration (robot.py:296-298) */
     get_tcp_position(e, obs + 6);                            /* ur5e/tcp_position */
@@ -313,6 +351,26 @@ static void episode_init(om_env* e) {
     double px = om_rng_uniform(&e->rng, lo, hi), py = om_rng_uniform(&e->rng, lo, hi);
     d->qpos[0] = px; d->qpos[1] = py; d->qvel[0] = d->qvel[1] = 0;
     d->mocap_pos[0][0] = px; d->mocap_pos[0][1] = py;
+  } else if (e->cfg.task == OM_TASK_PLANAR_PUSH) {
+    /* robot_planar_push.py:149-176 (intended semantics): robot xyz -> IK; target xyz; then the
+     * blocks' xyz (identity orientation), ALL blocks re-drawn until mj_forward reports no contact; 150 settle steps */
+    double rp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
+    e->episode_step = 0; /* base.py:29 */
+    for (int k = 0; k < 3; k++) rp[k] = om_rng_uniform(&e->rng, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
+    if (tcp_pose_to_joints(rp, MJS_TOP_DOWN_QUAT_XYZW, MJS_CYL_TCP_Z, zeros, q))
+      for (int j = 0; j < 6; j++) { d->qpos[j] = q[j]; d->qvel[j] = 0; d->ctrl[j] = q[j]; }
+    for (int k = 0; k < 3; k++) e->target_pos[k] = om_rng_uniform(&e->rng, MJS_PP_TARGET_SPACE_LO[k], MJS_PP_TARGET_SPACE_HI[k]);
+    for (;;) {
+      for (int i = 0; i < e->cfg.n_objects; i++) {
+        double* qp = d->qpos + 6 + 7 * i;
+        for (int k = 0; k < 3; k++) qp[k] = om_rng_uniform(&e->rng, MJS_PP_OBJECT_SPACE_LO[k], MJS_PP_OBJECT_SPACE_HI[k]);
+        qp[3] = 1; qp[4] = qp[5] = qp[6] = 0;
+      }
+      om_forward(m, d);
+      if (d->ncon == 0) break;
+    }
+    for (int s = 0; s < MJS_PP_SETTLE_STEPS; s++) om_physics_step(m, d);
+    return;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
     /* robot_push_button.py:126-134: robot xyz -> IK -> joints; switch xyz -> switch.set_pose (model edit) */
     double rp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
@@ -375,6 +433,20 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       t = fmin(fmax(t, MJS_PM_ARENA_LO), MJS_PM_ARENA_HI);
       d->mocap_pos[0][k] = t;
     }
+  } else if (e->cfg.task == OM_TASK_PLANAR_PUSH) {
+    /* base.py:31-32 + robot_planar_push.py:185-201: the 2-D action is the absolute TCP xy in metres, z = 0.02 */
+    e->episode_step++;
+    double q_now[6], q_ik[6], tp[3] = {action[0], action[1], MJS_PP_ACTION_Z};
+    memcpy(q_now, d->qpos, sizeof q_now);
+    if (!tcp_pose_to_joints(tp, MJS_TOP_DOWN_QUAT_XYZW, MJS_CYL_TCP_Z, q_now, q_ik)) {
+      e->ik_failed = 1;
+      memcpy(q_ik, q_now, sizeof q_ik);
+    }
+    memcpy(e->traj_q0, q_now, sizeof q_now);
+    memcpy(e->traj_q1, q_ik, sizeof q_ik);
+    e->traj_t0 = d->time;
+    e->traj_t1 = d->time + MJS_RR_CONTROL_DT;
+    e->traj_active = 1;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.action_type == OM_ACTION_ABS_JOINT) {
     /* robot_push_button.py:151-157: gripper.move(a[6]) only sets the finger actuator's ctrl (no finger
      * DoF under D-1); servoJ(a[:6]) -> robot.py:227-259 */
@@ -427,6 +499,24 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       default: reward = -e->distance_to_target + 0.5; break;
     }
     terminate = success;
+    discount = success ? 0.0 : 1.0;
+  } else if (e->cfg.task == OM_TASK_PLANAR_PUSH) {
+    /* robot_planar_push.py:203-241 + base.py:47-57 */
+    double tcp[3], sum = 0, nearest = INFINITY;
+    int n = e->cfg.n_objects, inside = 0;
+    get_tcp_position(e, tcp);
+    for (int i = 0; i < n; i++) {
+      const double* bp = d->qpos + 6 + 7 * i; /* body xpos of a free body = its qpos */
+      double dt = sqrt((bp[0] - e->target_pos[0]) * (bp[0] - e->target_pos[0]) + (bp[1] - e->target_pos[1]) * (bp[1] - e->target_pos[1]));
+      double dr = sqrt((tcp[0] - bp[0]) * (tcp[0] - bp[0]) + (tcp[1] - bp[1]) * (tcp[1] - bp[1]));
+      sum += dt;
+      inside += dt < MJS_PP_TARGET_RADIUS;
+      if (dr < nearest) nearest = dr;
+    }
+    success = inside == n;
+    if (e->cfg.reward_type == OM_REW_SPARSE) reward = inside;
+    else reward = (-sum / n - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
+    terminate = success || e->episode_step >= e->cfg.max_episode_steps;
     discount = success ? 0.0 : 1.0;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
     /* robot_push_button.py:167-170,205-219: goal = switch active AND tcp within 0.05 of the end position */
@@ -499,6 +589,28 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
   invw_out[1] = m.body_invweight0[8][1];
   invw_out[2] = m.meaninertia;
   for (int i = 0; i < 6; i++) invw_out[3 + i] = m.dof_invweight0[i];
+}
+
+/* debug hook for tests: copy out qpos[nq], qvel[nv] and time of an env; returns nq */
+int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time) {
+  memcpy(qpos, e->d.qpos, sizeof(double) * e->m.nq);
+  memcpy(qvel, e->d.qvel, sizeof(double) * e->m.nv);
+  *time = e->d.time;
+  return e->m.nq;
+}
+
+/* debug hooks for tests: overwrite the whole state (then mj_forward); run n raw Physics.step() with the current ctrl */
+void om_debug_set_state(om_env* e, const double* qpos, const double* qvel) {
+  memcpy(e->d.qpos, qpos, sizeof(double) * e->m.nq);
+  memcpy(e->d.qvel, qvel, sizeof(double) * e->m.nv);
+  memset(e->d.qacc_warmstart, 0, sizeof e->d.qacc_warmstart);
+  for (int j = 0; j < e->m.nu; j++) e->d.ctrl[j] = qpos[j];
+  e->traj_active = 0;
+  e->reset_pending = 0;
+  om_forward(&e->m, &e->d);
+}
+void om_debug_substeps(om_env* e, int n) {
+  for (int s = 0; s < n; s++) om_physics_step(&e->m, &e->d);
 }
 
 /* debug hook for tests: overwrite joint positions / velocities of a robot env (then mj_forward) */

@@ -11,7 +11,7 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 _LIB_PATH = _HERE / "_build" / "liboracle.so"
 
-TASK_POINTMASS, TASK_ROBOT_REACH, TASK_BUTTON_PUSH = 0, 1, 3
+TASK_POINTMASS, TASK_ROBOT_REACH, TASK_PLANAR_PUSH, TASK_BUTTON_PUSH = 0, 1, 2, 3
 ACTION_ABS_JOINT, ACTION_ABS_EEF = 0, 1
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DISTANCE = 0, 1, 2, 3
@@ -28,6 +28,8 @@ class TaskConfig(C.Structure):
         ("terminate_on_success", C.c_int),
         ("action_type", C.c_int),
         ("button_disturbances", C.c_int),
+        ("n_objects", C.c_int),
+        ("max_episode_steps", C.c_int),
     ]
 
 
@@ -159,7 +161,7 @@ class OracleBatch:
     def __init__(self, task: int, n: int, base_seed: int = 0, *, reward_type: int | None = None,
                  autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
                  terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None,
-                 button_disturbances: bool = False):
+                 button_disturbances: bool = False, n_objects: int | None = None, max_episode_steps: int | None = None):
         L = lib()
         cfg = TaskConfig()
         L.om_default_config(task, C.byref(cfg))
@@ -172,6 +174,10 @@ class OracleBatch:
         if action_type is not None:
             cfg.action_type = action_type
         cfg.button_disturbances = int(button_disturbances)
+        if n_objects is not None:
+            cfg.n_objects = n_objects
+        if max_episode_steps is not None:
+            cfg.max_episode_steps = max_episode_steps
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
         self.obs_dim, self.action_dim = L.om_obs_dim(task), L.om_action_dim(task)
         if task == TASK_BUTTON_PUSH and cfg.action_type == ACTION_ABS_EEF:
@@ -215,6 +221,32 @@ class OracleBatch:
         L.om_debug_set_robot_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         for i in range(self.n):
             L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
+
+    def get_state(self):
+        """debug: (qpos [N, nq], qvel [N, nv], time [N]) of every env"""
+        L = lib()
+        L.om_debug_get_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        qp, qv, tm = np.zeros((self.n, 48)), np.zeros((self.n, 36)), np.zeros(self.n)
+        nq = 0
+        for i in range(self.n):
+            nq = L.om_debug_get_state(L.om_batch_env(self._h, i), qp[i].ctypes.data, qv[i].ctypes.data, tm[i:].ctypes.data)
+        nv = nq - (nq - 6) // 7 if nq > 6 else nq
+        return qp[:, :nq].copy(), qv[:, :nv].copy(), tm
+
+    def set_state(self, qpos, qvel):
+        """debug: overwrite qpos [N, nq] / qvel [N, nv] of every env (ctrl = arm joints), then mj_forward"""
+        L = lib()
+        L.om_debug_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        qpos = np.ascontiguousarray(qpos, dtype=np.float64); qvel = np.ascontiguousarray(qvel, dtype=np.float64)
+        for i in range(self.n):
+            L.om_debug_set_state(L.om_batch_env(self._h, i), qpos[i].ctypes.data, qvel[i].ctypes.data)
+
+    def substeps(self, n: int):
+        """debug: n raw Physics.step() of every env with the current ctrl"""
+        L = lib()
+        L.om_debug_substeps.argtypes = [C.c_void_p, C.c_int]
+        for i in range(self.n):
+            L.om_debug_substeps(L.om_batch_env(self._h, i), n)
 
     def render(self, height: int, width: int, camera: int = 0) -> np.ndarray:
         """camera images of all envs (0 = scene camera, 1 = Button-Push wrist camera): uint8 [N, H, W, 3]"""

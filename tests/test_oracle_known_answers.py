@@ -10,6 +10,8 @@ everything that CAN be checked here:
   * closed-form answers (weld spring response, servo interpolation),
   * committed golden vectors (regression).
 """
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -335,3 +337,133 @@ def test_button_push_time_limit_truncates(oracle_mod):
         assert (r["step_type"][0] == 2) == (t == 99)
     assert r["truncated"][0] and not r["terminated"][0] and r["discount"][0] == 1.0 and r["reward"][0] == 0.0
     np.testing.assert_allclose(r["obs"][0, 6:9], hold[0, :3], atol=4e-3)  # the servo holds the pose (payload sag + DH/MJCF offset only)
+
+
+# ------------------------------------------------------------------------------------ Planar-Push
+def _convex(L, t1, s1, p1, R1, t2, s2, p2, R2):
+    out = np.zeros(7)
+    a = [np.ascontiguousarray(x, dtype=np.float64) for x in (s1, p1, R1, s2, p2, R2)]
+    hit = L.om_debug_convex(t1, a[0].ctypes.data_as(C.c_void_p), a[1].ctypes.data_as(C.c_void_p), a[2].ctypes.data_as(C.c_void_p),
+                            t2, a[3].ctypes.data_as(C.c_void_p), a[4].ctypes.data_as(C.c_void_p), a[5].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return bool(hit), out[0], out[1:4], out[4:7]
+
+
+def _rot(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+
+def test_convex_penetration_known_answers(oracle_mod):
+    """Own MPR for the convex pairs of the Planar-Push scene (role of mjc_Convex/libccd): closed-form cases, then the
+    defining properties on random poses: translating geom2 by depth along the normal separates the pair, half of it
+    does not, and the contact point lies inside both (depth-inflated) shapes."""
+    L = oracle_mod.lib()
+    BOX, CYL, I = 6, 5, np.eye(3)
+    h, cyl = [0.02, 0.02, 0.019], [0.02, 0.05, 0.0]
+    hit, depth, n, pos = _convex(L, BOX, h, [0, 0, 0], I, BOX, h, [0.03, 0.001, 0.002], I)
+    assert hit and abs(depth - 0.01) < 1e-9 and np.allclose(n, [1, 0, 0], atol=1e-9) and abs(pos[0] - 0.015) < 1e-9
+    assert not _convex(L, BOX, h, [0, 0, 0], I, BOX, h, [0.0401, 0, 0], I)[0]
+    hit, depth, n, pos = _convex(L, CYL, cyl, [-0.035, 0.003, 0.05], I, BOX, h, [0, 0, 0.019], I)   # cylinder side vs box face
+    assert hit and abs(depth - 0.005) < 1e-7 and np.allclose(n, [1, 0, 0], atol=1e-5) and abs(pos[0] + 0.0175) < 1e-7
+    hit, depth, n, pos = _convex(L, CYL, cyl, [0.005, 0, 0.038 + 0.05 - 0.002], I, BOX, h, [0, 0, 0.019], I)  # flat cap on the top face
+    assert hit and abs(depth - 0.002) < 1e-9 and np.allclose(n, [0, 0, -1], atol=1e-9) and 0.036 - 1e-12 <= pos[2] <= 0.038 + 1e-12  # inside the overlap slab
+    assert not _convex(L, CYL, cyl, [-0.0401, 0, 0.05], I, BOX, h, [0, 0, 0.019], I)[0]
+
+    def inside(tp, s, p, R, x, tol):
+        loc = R.T @ (x - p)
+        if tp == BOX:
+            return bool(np.all(np.abs(loc) <= np.array(s) + tol))
+        return np.hypot(loc[0], loc[1]) <= s[0] + tol and abs(loc[2]) <= s[1] + tol
+
+    rs = np.random.RandomState(0)
+    hits = 0
+    for t in range(600):
+        R1, R2 = _rot(rs.normal(size=3), rs.uniform(0, 3)), _rot(rs.normal(size=3), rs.uniform(0, 3))
+        p2 = rs.uniform(-0.05, 0.05, 3)
+        t1, s1 = (CYL, cyl) if t % 2 else (BOX, h)
+        hit, depth, n, pos = _convex(L, t1, s1, [0, 0, 0], R1, BOX, h, p2, R2)
+        if not hit:
+            continue
+        hits += 1
+        assert depth >= 0 and abs(np.linalg.norm(n) - 1) < 1e-12
+        assert not _convex(L, t1, s1, [0, 0, 0], R1, BOX, h, p2 + (depth + 1e-4) * n, R2)[0]
+        assert _convex(L, t1, s1, [0, 0, 0], R1, BOX, h, p2 + 0.5 * depth * n, R2)[0]
+        assert inside(t1, s1, np.zeros(3), R1, pos, depth + 1e-6) and inside(BOX, h, p2, R2, pos, depth + 1e-6)
+    assert hits > 200
+
+
+def test_planar_push_reset_and_settle(oracle_mod):
+    """robot_planar_push.py:149-176 (intended semantics): draw order robot xyz, target xyz, then block xyz per block
+    (re-drawn together while anything touches), 150 physics steps to settle: blocks end flat on the floor, 4 corner
+    contacts each, at their drawn xy; physics time = 150 * 0.005."""
+    for seed in (2025, 3):
+        b = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, seed)
+        r = b.reset()
+        rs = np.random.RandomState(seed)
+        robot = [rs.uniform(lo, hi) for lo, hi in ((-0.2, 0.2), (-0.6, -0.3), (0.02, 0.02))]
+        target = [rs.uniform(lo, hi) for lo, hi in ((-0.15, 0.15), (-0.55, -0.35), (0.001, 0.005))]
+        blocks = [[rs.uniform(lo, hi) for lo, hi in ((-0.15, 0.15), (-0.55, -0.35), (0.05, 0.2))] for _ in range(2)]
+        o = r["obs"][0]
+        np.testing.assert_allclose(o[0:3], robot, atol=1.5e-3)
+        np.testing.assert_allclose(o[3:5], target[:2], atol=1e-15)
+        qpos, qvel, tm = b.get_state()
+        apart = np.linalg.norm(np.array(blocks[0]) - np.array(blocks[1])) > 0.08  # first draw accepted when nothing overlaps
+        if apart:
+            np.testing.assert_allclose(o[5:9], np.array(blocks)[:, :2].ravel(), atol=1e-6)
+        assert r["ncon"][0] == 8 and abs(tm[0] - 0.75) < 1e-12
+        for i in range(2):
+            z, quat = qpos[0, 6 + 7 * i + 2], qpos[0, 6 + 7 * i + 3: 6 + 7 * i + 7]
+            assert -1e-3 < z < 1e-4 and abs(abs(quat[0]) - 1) < 1e-6   # resting on the floor (soft contact: tiny penetration), upright
+        assert np.abs(qvel[0, 6:]).max() < 1e-3
+
+
+def test_planar_push_free_body_closed_forms(oracle_mod):
+    """Free-joint integration known answers (no contact): semi-implicit Euler free fall
+    z_k = z_0 - g dt^2 k (k + 1) / 2, x_k = x_0 + v_x k dt; a block spinning about a principal axis keeps its
+    body-frame angular velocity and turns by w k dt (quaternion integration on the local angular velocity)."""
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, 1)
+    b.reset()
+    qpos, qvel, _ = b.get_state()
+    qpos[0, 6:13] = [0.1, -0.45, 0.6, 1, 0, 0, 0]
+    qpos[0, 13:20] = [-0.1, -0.45, 0.7, 1, 0, 0, 0]
+    qvel[:] = 0
+    qvel[0, 6] = 0.2          # block 0 drifts in x
+    qvel[0, 12 + 5] = 3.0     # block 1 spins about its local z (a principal axis)
+    b.set_state(qpos, qvel)
+    k, dt, g = 40, 0.005, 9.81
+    b.substeps(k)
+    q, v, _ = b.get_state()
+    np.testing.assert_allclose(q[0, 8], 0.6 - g * dt * dt * k * (k + 1) / 2, atol=1e-12)
+    np.testing.assert_allclose(q[0, 6], 0.1 + 0.2 * k * dt, atol=1e-12)
+    np.testing.assert_allclose(v[0, 8], -g * k * dt, atol=1e-12)
+    ang = 3.0 * k * dt
+    np.testing.assert_allclose(q[0, 16:20], [np.cos(ang / 2), 0, 0, np.sin(ang / 2)], atol=1e-12)
+    np.testing.assert_allclose(v[0, 12 + 3: 12 + 6], [0, 0, 3.0], atol=1e-12)
+
+
+def test_planar_push_pushing_moves_the_block(oracle_mod):
+    # the cylinder EEF driven through a block's position pushes it along (contact solver path, condim-4 pyramids)
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 4, 2025, nthreads=4)
+    r = b.reset()
+    start = r["obs"][:, 5:7].copy()
+    saw_eef_contact = False
+    for t in range(80):
+        tcp, blk = r["obs"][:, :2], r["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02)
+        r = b.step(a)
+        saw_eef_contact |= bool((r["ncon"] > 8).any() or (r["ncon"] < 8).any())
+        assert not r["fault"].any()
+    moved = np.linalg.norm(r["obs"][:, 5:7] - start, axis=1)
+    assert saw_eef_contact and (moved > 0.02).all(), moved
+    assert (r["reward"] < 0).all()  # dense reward = 0.1 * (-mean distance - 0.1 * nearest)
+
+
+def test_planar_push_step_limit_truncates(oracle_mod):
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, 5, max_episode_steps=7)
+    r = b.reset()
+    hold = r["obs"][:, :2].copy()
+    for t in range(7):
+        r = b.step(hold)
+        assert (r["step_type"][0] == 2) == (t == 6)
+    assert r["truncated"][0] and not r["terminated"][0] and r["discount"][0] == 1.0

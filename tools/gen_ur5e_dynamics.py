@@ -272,6 +272,13 @@ def wrist_camera_part():
     return flange_part(mb + ms, spec_array("MJS_WCAM_POS"), spec_array("MJS_WCAM_QUAT"), diag)
 
 
+def cylinder_eef_part():
+    """CylinderEEF (entities/eef/cylinder.py:23-33): uniform cylinder, axis = flange z, mass given explicitly"""
+    r, h, m = spec_scalar("MJS_CYL_RADIUS"), spec_scalar("MJS_CYL_HALFLEN"), spec_scalar("MJS_CYL_MASS")
+    ixx = m * (3 * r * r + (2 * h) ** 2) / 12
+    return flange_part(m, [0.0, 0.0, spec_scalar("MJS_CYL_POS_Z")], None, [ixx, ixx, 0.5 * m * r * r])
+
+
 def make_links(extra_parts):
     """per joint j: dict(C, r, axis, m, c, I); extra_parts = un-gravity-compensated rigid parts on link 6.
     Returns (links, (mass, com) of the un-compensated parts together)"""
@@ -529,6 +536,9 @@ def main():
     cam = wrist_camera_part()
     links2, uncomp2 = make_links([GRIPPER, cam])
     text += emit_variant("ur5e_bp", links2, uncomp2, GRIPPER[1], "Button-Push: + wrist-camera geoms' mass at the flange (robot_push_button.py:90-96)")
+    cyl = cylinder_eef_part()
+    links3, uncomp3 = make_links([cyl])
+    text += emit_variant("ur5e_pp", links3, uncomp3, cyl[1], "Planar-Push: UR5e + CylinderEEF (robot_planar_push.py:81-87)")
     text += """
 MJS_DEV void ur5e_dynamics_gen(const double* c, const double* s, const double* qd, double* M, double* bias) {
   ur5e_M_gen(c, s, M);
