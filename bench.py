@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button"])
+    ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button", "robot_planar_push"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
@@ -61,6 +61,9 @@ def make_actions(task, T, N, device, seed):
     rs = np.random.RandomState(seed)
     if task == "point_mass_reach":
         a = rs.uniform(-0.05, 0.05, (T, N, 2)).astype(np.float32).astype(np.float64)
+    elif task == "robot_planar_push":
+        # SURVEY.md section 8d, cfg 4: absolute TCP xy uniform in the robot workspace x in [-0.2, 0.2], y in [-0.6, -0.3]
+        a = rs.uniform([-0.2, -0.6], [0.2, -0.3], (T, N, 2))
     elif task == "robot_push_button":
         # SURVEY.md section 8d, cfg 5: joint targets q_home +- U(0.2) (robot.py:307) + gripper U(0, 0.085); 7-D absolute
         # joint actions are the registered action type
@@ -87,7 +90,8 @@ def host_cores():
 def cpu_baseline(task, n_envs, seconds):
     import oracle
 
-    tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH}[task]
+    tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH,
+           "robot_planar_push": oracle.TASK_PLANAR_PUSH}[task]
     cores = host_cores()
     b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores)
     b.reset()
@@ -161,7 +165,8 @@ def main():
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": {"robot_reach": "env-steps/sec at N_envs=4096, Robot-Reach", "point_mass_reach": "env-steps/sec, Pointmass-Reach",
-                       "robot_push_button": "env-steps/sec, Button-Push (state obs)"}[args.task],
+                       "robot_push_button": "env-steps/sec, Button-Push (state obs)",
+                       "robot_planar_push": "env-steps/sec, Planar-Push, 2 objects (state obs)"}[args.task],
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

@@ -28,7 +28,7 @@ extern "C" {
 enum {
   MJS_TASK_POINTMASS_REACH = 0, /* tasks/point_reach.py */
   MJS_TASK_ROBOT_REACH = 1,     /* tasks/robot_reach.py */
-  MJS_TASK_PLANAR_PUSH = 2,     /* tasks/robot_planar_push.py: id reserved, mjs_create returns MJS_ERR_UNSUPPORTED */
+  MJS_TASK_PLANAR_PUSH = 2,     /* tasks/robot_planar_push.py (intended semantics; box stand-in blocks, DESIGN D-9) */
   MJS_TASK_BUTTON_PUSH = 3      /* tasks/robot_push_button.py */
 };
 /* Button-Push action spaces (robot_push_button.py:35-36,143-157): absolute joints + gripper (7-D, the
@@ -45,7 +45,7 @@ enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_D
 /* kernel variants (results identical up to rounding; used for A/B profiles) */
 enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1 };
 /* mjs_outputs.fault bits */
-enum { MJS_FAULT_BAD_STATE = 1, MJS_FAULT_IK_FAILED = 2, MJS_FAULT_LIMIT_COLDSTART = 4 };
+enum { MJS_FAULT_BAD_STATE = 1, MJS_FAULT_IK_FAILED = 2, MJS_FAULT_LIMIT_COLDSTART = 4, MJS_FAULT_UNSUPPORTED_CONTACT = 8 };
 
 enum {
   MJS_OK = 0,
@@ -71,6 +71,8 @@ typedef struct {
   int32_t action_type;          /* MJS_ACTION_* (Button-Push only) */
   int32_t button_disturbances;  /* Button-Push only: after each control step an active, released switch is
                                  * deactivated with probability 0.01 from the env's stream (robot_push_button.py:159-165) */
+  int32_t n_objects;            /* Planar-Push only: number of blocks, 1..2 (<= 0: 2, BASELINE config 4) */
+  int32_t max_episode_steps;    /* Planar-Push only: RobotTask step limit (tasks/base.py:47-51); <= 0: 500 */
 } mjs_config;
 
 /* Per-step outputs. Device pointers, caller-owned, any may be NULL.

@@ -16,6 +16,7 @@ from .environments.dmc2gym import DMCEnvironmentAdapter, HipEnvironment, TimeSte
 from .environments.tasks.point_reach import PointMassReachTask
 from .environments.tasks.robot_reach import RobotReachConfig, RobotReachTask
 from .environments.tasks.robot_push_button import RobotPushButtonTask
+from .environments.tasks.robot_planar_push import RobotPushConfig, RobotPushTask
 from .vector_env import TASKS, HipVectorEnv  # noqa: F401
 
 __version__ = "0.1.0"
@@ -25,6 +26,13 @@ def make_point_mass_reach_env(task_class, max_steps, device="cuda:0", **kwargs):
     """mujoco_sim/__init__.py:19-23: task -> Environment(time_limit = max_steps * CONTROL_TIMESTEP) -> adapter."""
     task = task_class(**kwargs)
     env = HipEnvironment(task, time_limit=max_steps * task.CONTROL_TIMESTEP, device=device)
+    return DMCEnvironmentAdapter(env, flatten_observation_space=False)
+
+
+def _make_robot_planar_push_env(device="cuda:0", **kwargs):
+    """scripts/sb3/planar_push.py:66-74: task -> Environment (no time limit: the task counts its steps) -> adapter"""
+    task = RobotPushTask(RobotPushConfig(**kwargs))
+    env = HipEnvironment(task, device=device)
     return DMCEnvironmentAdapter(env, flatten_observation_space=False)
 
 
@@ -47,6 +55,7 @@ registry = {
     "mujoco_sim/robot_push_button_visual-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
                                                {"observation_type": RobotPushButtonTask.VISUAL_OBS, "image_resolution": 96,
                                                 "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
+    "mujoco_sim/robot_planar_push_state-v0": (_make_robot_planar_push_env, {}),
     "mujoco_sim/robot_push_button_state-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
                                               {"observation_type": RobotPushButtonTask.STATE_OBS, "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
 }

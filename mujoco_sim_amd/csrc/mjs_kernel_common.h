@@ -18,6 +18,8 @@ struct KernelParams {
   int terminate_on_success;
   int action_type;
   int button_disturbances;
+  int n_objects;          // Planar-Push
+  int max_episode_steps;  // Planar-Push
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]

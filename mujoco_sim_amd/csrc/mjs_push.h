@@ -1,0 +1,1088 @@
+// mjs_push.h — Robot Planar-Push fused control-step kernel (BASELINE config 4: the contact-solver path).
+//
+// Path replaced (reference, paths under /root/reference/mujoco_sim/; INTENDED semantics where the reference is
+// broken at HEAD):
+//   environments/tasks/robot_planar_push.py:185-201 before_step (episode_step += 1, servoL to (ax, ay, 0.02)),
+//   per substep robot.py:261-263 servo interpolation + Physics.step() on the scene of :81-117 (UR5e + CylinderEEF +
+//   n free blocks on the floor), :203-241 + tasks/base.py:47-57 reward / accomplished / step limit / discount,
+//   :149-176 initialize_episode (robot, target, blocks re-drawn until nothing touches, 150 settle steps).
+// Deviation D-9: the blocks are BOXES of the cube mesh's bounding box (google_block.py loads a bevelled-cube mesh);
+// convex pairs (cylinder-box, box-box) go through an own MPR (role of mjc_Convex -> libccd), one contact per pair;
+// box-floor gives up to 4 corner contacts. Contacts are condim 4 (block) pyramids: 6 rows each.
+//
+// First correct version: lane per env, one wavefront per 64 envs, generic dense in-lane Newton over nv = 6 + 6 n
+// dofs with the rows in per-lane scratch arrays. The arm's M and bias come from the generated code (ur5e_pp_*),
+// the free blocks' from closed forms. Collision arithmetic is + - * / sqrt without FMA contraction so that contact
+// sets match the CPU restatement bit for bit.
+#pragma once
+#include "mjs_kernel_common.h"
+#include "mjs_reach.h"
+
+namespace pp {
+
+using rr::NJ;
+constexpr int NB = MJS_PP_MAX_OBJECTS, NV = NJ + 6 * NB;
+constexpr int OBS_DIM = 5 + 2 * NB, ACT_DIM = 2;
+// state rows (float64 SoA): arm q, v, time, target xyz, episode_step, then per block pos3 quat4 vel6
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK = 17, BLOCK_DIM = 13;
+constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
+constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
+constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
+
+struct Block {
+  V3 p;          // body origin = centre of the bottom face (free joint qpos[0:3])
+  double q[4];   // orientation (w, x, y, z)
+  V3 v, w;       // linear velocity of the origin (world), angular velocity (body frame)
+};
+struct World {
+  double q[NJ], v[NJ], time, target[3], episode_step;
+  Block b[NB];
+};
+
+MJS_DEV World load_world(const KernelParams& p, int i) {
+  World s;
+  const size_t N = p.N;
+  const double* st = p.state + i;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { s.q[j] = st[(S_Q + j) * N]; s.v[j] = st[(S_V + j) * N]; }
+  s.time = st[S_TIME * N];
+#pragma unroll
+  for (int k = 0; k < 3; k++) s.target[k] = st[(S_TARGET + k) * N];
+  s.episode_step = st[S_STEP * N];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const double* bs = st + (size_t)(S_BLOCK + BLOCK_DIM * b) * N;
+    s.b[b].p = v3(bs[0], bs[N], bs[2 * N]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.b[b].q[k] = bs[(3 + k) * N];
+    s.b[b].v = v3(bs[7 * N], bs[8 * N], bs[9 * N]);
+    s.b[b].w = v3(bs[10 * N], bs[11 * N], bs[12 * N]);
+  }
+  return s;
+}
+MJS_DEV void store_world(const KernelParams& p, int i, const World& s) {
+  const size_t N = p.N;
+  double* st = p.state + i;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st[(S_Q + j) * N] = s.q[j]; st[(S_V + j) * N] = s.v[j]; }
+  st[S_TIME * N] = s.time;
+#pragma unroll
+  for (int k = 0; k < 3; k++) st[(S_TARGET + k) * N] = s.target[k];
+  st[S_STEP * N] = s.episode_step;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    double* bs = st + (size_t)(S_BLOCK + BLOCK_DIM * b) * N;
+    bs[0] = s.b[b].p.x; bs[N] = s.b[b].p.y; bs[2 * N] = s.b[b].p.z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) bs[(3 + k) * N] = s.b[b].q[k];
+    bs[7 * N] = s.b[b].v.x; bs[8 * N] = s.b[b].v.y; bs[9 * N] = s.b[b].v.z;
+    bs[10 * N] = s.b[b].w.x; bs[11 * N] = s.b[b].w.y; bs[12 * N] = s.b[b].w.z;
+  }
+}
+
+MJS_DEV M3 quat_to_m3(const double* q) {  // unit quaternion -> rotation (columns = body axes in the world)
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  return M3{v3(1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)), v3(2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w)),
+            v3(2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y))};
+}
+MJS_DEV V3 rot(const M3& R, V3 a) { return madd(madd(a.x * R.cx, a.y, R.cy), a.z, R.cz); }
+MJS_DEV V3 rot_t(const M3& R, V3 a) { return v3(dot(R.cx, a), dot(R.cy, a), dot(R.cz, a)); }
+
+// ------------------------------------------------------------------------------------------------ collision
+// Same operations, in the same order, as oracle/om_engine.c (collide_plane box branch, mpr_penetration): the two
+// sides are written independently but must take the same branches, hence no FMA contraction here.
+#pragma clang fp contract(off)
+
+// biased tie-break thresholds, identical to oracle/om_engine.c (see the comment there)
+constexpr double MPR_EPS_DIR = 1e-10, MPR_EPS_LEN = 1e-13, MPR_EPS_VOL = 1e-16;
+
+struct Geom {  // a convex collision geom in the world: box (half extents s) or cylinder (radius s.x, half length s.y)
+  V3 c;
+  M3 R;
+  V3 s;
+  bool box;
+};
+struct Contact {
+  double dist;
+  V3 pos, n;
+  int ba, bb;  // bodies: 0 = world, 1 = arm (a geom welded to link 6), 2 + i = block i; normal points from a to b
+  double tran; // body_invweight0 (translation) of the two bodies, summed: diagApprox of the pyramid rows
+};
+
+MJS_DEV V3 support(const Geom& g, V3 dir) {
+  const V3 loc = rot_t(g.R, dir);
+  V3 res;
+  if (g.box) {
+    res = v3(loc.x >= -MPR_EPS_DIR ? g.s.x : -g.s.x, loc.y >= -MPR_EPS_DIR ? g.s.y : -g.s.y, loc.z >= -MPR_EPS_DIR ? g.s.z : -g.s.z);
+  } else {
+    const double len = sqrt(loc.x * loc.x + loc.y * loc.y);
+    if (len > MPR_EPS_DIR) res = v3(g.s.x * loc.x / len, g.s.x * loc.y / len, 0); else res = v3(0, 0, 0);
+    res.z = loc.z >= -MPR_EPS_DIR ? g.s.y : -g.s.y;
+  }
+  const V3 w = v3(g.R.cx.x * res.x + g.R.cy.x * res.y + g.R.cz.x * res.z, g.R.cx.y * res.x + g.R.cy.y * res.y + g.R.cz.y * res.z,
+                  g.R.cx.z * res.x + g.R.cy.z * res.y + g.R.cz.z * res.z);
+  return v3(w.x + g.c.x, w.y + g.c.y, w.z + g.c.z);
+}
+struct MprVert { V3 v, a, b; };
+MJS_DEV MprVert mpr_support(const Geom& g1, const Geom& g2, V3 dir) {
+  MprVert s;
+  s.a = support(g1, dir);
+  s.b = support(g2, v3(-dir.x, -dir.y, -dir.z));
+  s.v = v3(s.a.x - s.b.x, s.a.y - s.b.y, s.a.z - s.b.z);
+  return s;
+}
+MJS_DEV double dot_nc(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MJS_DEV V3 cross_nc(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MJS_DEV bool normalize_nc(V3& v) {
+  const double n = sqrt(dot_nc(v, v));
+  if (n < 1e-14) return false;
+  v = v3(v.x / n, v.y / n, v.z / n);
+  return true;
+}
+MJS_DEV V3 sub_nc(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MJS_DEV V3 any_perpendicular(V3 v) {
+  const double ax = fabs(v.x), ay = fabs(v.y), az = fabs(v.z);
+  const int k = ax <= ay ? (ax <= az ? 0 : 2) : (ay <= az ? 1 : 2);
+  return cross_nc(v, v3(k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0));
+}
+// Minkowski portal refinement on g1 - g2; true + (depth, normal g1 -> g2, pos) when the geoms overlap
+__device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
+  MprVert v0, v1, v2, v3_, v4;
+  v0.a = g1.c; v0.b = g2.c; v0.v = sub_nc(g1.c, g2.c);
+  if (sqrt(dot_nc(v0.v, v0.v)) < 1e-12) v0.v.x = 1e-5;
+  V3 dir = v3(-v0.v.x, -v0.v.y, -v0.v.z);
+  normalize_nc(dir);
+  v1 = mpr_support(g1, g2, dir);
+  if (dot_nc(v1.v, dir) <= 0) return false;
+  dir = cross_nc(v0.v, v1.v);
+  if (!normalize_nc(dir)) { dir = any_perpendicular(v0.v); normalize_nc(dir); }
+  v2 = mpr_support(g1, g2, dir);
+  if (dot_nc(v2.v, dir) <= 0) return false;
+  dir = cross_nc(sub_nc(v1.v, v0.v), sub_nc(v2.v, v0.v));
+  if (!normalize_nc(dir)) return false;
+  if (dot_nc(dir, v0.v) > MPR_EPS_LEN) { MprVert t = v1; v1 = v2; v2 = t; dir = v3(-dir.x, -dir.y, -dir.z); }
+  for (int it = 0;; it++) {  // portal discovery
+    if (it >= MJS_MPR_MAX_ITER) return false;
+    v3_ = mpr_support(g1, g2, dir);
+    if (dot_nc(v3_.v, dir) <= 0) return false;
+    bool cont = false;
+    if (dot_nc(cross_nc(v1.v, v3_.v), v0.v) < -MPR_EPS_VOL) { v2 = v3_; cont = true; }
+    else if (dot_nc(cross_nc(v3_.v, v2.v), v0.v) < -MPR_EPS_VOL) { v1 = v3_; cont = true; }
+    if (!cont) break;
+    dir = cross_nc(sub_nc(v1.v, v0.v), sub_nc(v2.v, v0.v));
+    if (!normalize_nc(dir)) return false;
+  }
+  bool hit = false;
+  for (int it = 0; it < MJS_MPR_MAX_ITER; it++) {  // portal refinement
+    dir = cross_nc(sub_nc(v2.v, v1.v), sub_nc(v3_.v, v1.v));
+    if (!normalize_nc(dir)) return false;
+    if (dot_nc(dir, v1.v) >= -MPR_EPS_LEN) hit = true;
+    v4 = mpr_support(g1, g2, dir);
+    const double reach = dot_nc(v4.v, dir);
+    if (!hit && reach < 0) return false;
+    const double progress = dot_nc(sub_nc(v4.v, v3_.v), dir);
+    if (progress <= MJS_MPR_TOLERANCE || it == MJS_MPR_MAX_ITER - 1) {
+      if (!hit) return false;
+      depth = dot_nc(v1.v, dir);
+      normal = dir;
+      const V3 c23 = cross_nc(v2.v, v3_.v), c13 = cross_nc(v1.v, v3_.v), c12 = cross_nc(v1.v, v2.v);
+      double b0 = dot_nc(v1.v, c23), b1 = -dot_nc(v0.v, c23), b2 = dot_nc(v0.v, c13), b3 = -dot_nc(v0.v, c12);
+      double sum = b0 + b1 + b2 + b3;
+      if (fabs(sum) < 1e-30) { b0 = 0; b1 = b2 = b3 = 1; sum = 3; }
+      const double pax = (b0 * v0.a.x + b1 * v1.a.x + b2 * v2.a.x + b3 * v3_.a.x) / sum, pbx = (b0 * v0.b.x + b1 * v1.b.x + b2 * v2.b.x + b3 * v3_.b.x) / sum;
+      const double pay = (b0 * v0.a.y + b1 * v1.a.y + b2 * v2.a.y + b3 * v3_.a.y) / sum, pby = (b0 * v0.b.y + b1 * v1.b.y + b2 * v2.b.y + b3 * v3_.b.y) / sum;
+      const double paz = (b0 * v0.a.z + b1 * v1.a.z + b2 * v2.a.z + b3 * v3_.a.z) / sum, pbz = (b0 * v0.b.z + b1 * v1.b.z + b2 * v2.b.z + b3 * v3_.b.z) / sum;
+      pos = v3(0.5 * (pax + pbx), 0.5 * (pay + pby), 0.5 * (paz + pbz));
+      return true;
+    }
+    const V3 t1 = cross_nc(v4.v, v0.v);
+    if (dot_nc(v1.v, t1) > MPR_EPS_VOL) {
+      if (dot_nc(v2.v, t1) > MPR_EPS_VOL) v1 = v4; else v3_ = v4;
+    } else {
+      if (dot_nc(v3_.v, t1) > MPR_EPS_VOL) v2 = v4; else v1 = v4;
+    }
+  }
+  return false;
+}
+MJS_DEV double rbound(const Geom& g) { return g.box ? sqrt(g.s.x * g.s.x + g.s.y * g.s.y + g.s.z * g.s.z) : sqrt(g.s.x * g.s.x + g.s.y * g.s.y); }
+MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, double tran, Contact& c) {
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return false;
+  double depth;
+  if (!mpr_penetration(g1, g2, depth, c.n, c.pos)) return false;
+  c.dist = -depth;
+  c.ba = ba; c.bb = bb;
+  c.tran = tran;
+  return true;
+}
+MJS_DEV Geom block_geom(const Block& b, const M3& R) {
+  Geom g;
+  g.R = R;
+  const double gz = MJS_BLOCK_GEOM_Z;  // geom_xpos = xpos + xmat * geom_pos
+  g.c = v3(b.p.x + R.cz.x * gz, b.p.y + R.cz.y * gz, b.p.z + R.cz.z * gz);
+  g.s = v3(MJS_BLOCK_HALF[0], MJS_BLOCK_HALF[1], MJS_BLOCK_HALF[2]);
+  g.box = true;
+  return g;
+}
+// mjc_PlaneBox against the floor z = 0: corners at or below the plane, at most 4, x index fastest
+MJS_DEV int floor_box(const Geom& g, int bb, Contact* out) {
+  int cnt = 0;
+  for (int i = 0; i < 8 && cnt < 4; i++) {
+    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+    const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
+                         g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
+    const double dist = corner.z;  // (corner - plane pos) . n with n = +z, plane through the origin
+    if (dist > 0.0) continue;
+    Contact& c = out[cnt++];
+    c.dist = dist;
+    c.n = v3(0, 0, 1);
+    c.pos = v3(corner.x, corner.y, corner.z - dist * 0.5);
+    c.ba = 0; c.bb = bb;
+    c.tran = 1.0 / MJS_BLOCK_MASS;  // world 0 + free block 1/m
+  }
+  return cnt;
+}
+#pragma clang fp contract(on)
+
+MJS_DEV Geom eef_geom(const rr::Chain& ch) {  // CylinderEEF: axis = flange z = wrist_3 y, centre at flange z = 0.051
+  Geom g;
+  const M3 R6 = ch.R[6];
+  g.R = M3{R6.cx, -R6.cz, R6.cy};  // flange frame (MJS_UR_FLANGE_QUAT): x = wrist_3 x, y = -wrist_3 z, z = wrist_3 y
+  g.c = madd(ch.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_POS_Z, R6.cy);
+  g.s = v3(MJS_CYL_RADIUS, MJS_CYL_HALFLEN, 0);
+  g.box = false;
+  return g;
+}
+MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collision proxy is a CYLINDER (MJS_UR_COL_* index 9):
+  Geom g;                                             // the only arm geom whose pair with a box is evaluated (convex-convex)
+  constexpr int G = MJS_UR_NCOLGEOM - 1;
+  const M3 R6 = ch.R[6];
+  g.R = M3{R6.cx, R6.cz, -R6.cy};  // geom quat (1,1,0,0): +90 deg about x of the body frame
+  g.c = madd(madd(madd(ch.p[6], MJS_UR_COL_POS[G][0], R6.cx), MJS_UR_COL_POS[G][1], R6.cy), MJS_UR_COL_POS[G][2], R6.cz);
+  g.s = v3(MJS_UR_COL_SIZE[G][0], MJS_UR_COL_SIZE[G][1], 0);
+  g.box = false;
+  return g;
+}
+MJS_DEV V3 eef_tcp_position(const rr::Chain& c) { return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_TCP_Z, c.R[6].cy); }
+
+// all contacts of the scene in MuJoCo's pair order (geom ids: floor, arm capsules, EEF cylinder, blocks): floor-block i
+// (<= 4 each), EEF-block i, block-block. Arm capsules vs floor and EEF vs floor are only COUNTED (D-8): `extra`.
+MJS_DEV int detect_contacts(const rr::Chain& ch, const World& s, const M3* Rb, int nb, Contact* con, int& extra, bool& eef_floor_active) {
+  int n = 0;
+  extra = rr::count_floor_contacts(ch);
+  const Geom eg = eef_geom(ch);
+  {  // mjc_PlaneCylinder first test: the deepest rim point of the EEF cylinder (active only if the arm sags by 19 mm)
+    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+    const double lowest = eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x;
+    eef_floor_active = lowest < 0.0;
+    if (!(lowest > 0.0)) extra += 1;
+  }
+  Geom bg[NB];
+  for (int b = 0; b < nb; b++) {
+    bg[b] = block_geom(s.b[b], Rb[b]);
+    n += floor_box(bg[b], 2 + b, con + n);
+  }
+  const Geom wg = wrist3_proxy_geom(ch);
+  for (int b = 0; b < nb; b++)
+    if (collide_convex(wg, bg[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS, con[n])) n++;
+  for (int b = 0; b < nb; b++)
+    if (collide_convex(eg, bg[b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS, con[n])) n++;
+  for (int a = 0; a < nb; a++)
+    for (int b = a + 1; b < nb; b++)
+      if (collide_convex(bg[a], bg[b], 2 + a, 2 + b, 2.0 / MJS_BLOCK_MASS, con[n])) n++;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ dynamics
+// Free block, generalised velocity (v_origin in the world, w in the body frame), COM at c_l = (0, 0, gz) in the body:
+//   M = [[m I, -m R C], [m C R^T, I_c - m C C]],  C = [c_l]x
+//   smooth force = -( m R (w x (w x c_l)) - m g ;  w x I_c w + m c_l x (w x (w x c_l)) - m c_l x R^T g )
+constexpr double BLK_IXX = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+constexpr double BLK_IYY = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+constexpr double BLK_IZZ = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1]) / 3;
+constexpr double BLK_INVW_TRAN = 1.0 / MJS_BLOCK_MASS, BLK_INVW_ROT = (1.0 / BLK_IXX + 1.0 / BLK_IYY + 1.0 / BLK_IZZ) / 3;
+MJS_DEV void block_mass_matrix(const M3& R, double (*M)[NV], int o) {  // writes the 6x6 block at offset o (both triangles)
+  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) M[o + i][o + j] = 0;
+  for (int k = 0; k < 3; k++) M[o + k][o + k] = m;
+  M[o + 3][o + 3] = BLK_IXX + m * g * g; M[o + 4][o + 4] = BLK_IYY + m * g * g; M[o + 5][o + 5] = BLK_IZZ;
+  // -m R C: column for w_x is -m g R.cy, for w_y is +m g R.cx, for w_z is 0
+  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
+  const double colx[3] = {cx.x, cx.y, cx.z}, coly[3] = {cy.x, cy.y, cy.z};
+  for (int k = 0; k < 3; k++) { M[o + k][o + 3] = M[o + 3][o + k] = colx[k]; M[o + k][o + 4] = M[o + 4][o + k] = coly[k]; }
+}
+MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
+  const double m = MJS_BLOCK_MASS;
+  const V3 c = v3(0, 0, MJS_BLOCK_GEOM_Z), grav = v3(0, 0, MJS_GRAVITY_Z);
+  const V3 wwc = cross(w, cross(w, c));
+  const V3 lin = m * rot(R, wwc) - m * grav;
+  const V3 Iw = v3(BLK_IXX * w.x, BLK_IYY * w.y, BLK_IZZ * w.z);
+  const V3 ang = cross(w, Iw) + m * cross(c, wwc) - m * cross(c, rot_t(R, grav));
+  f[0] = -lin.x; f[1] = -lin.y; f[2] = -lin.z; f[3] = -ang.x; f[4] = -ang.y; f[5] = -ang.z;
+}
+
+// dense symmetric positive definite solve helpers on [NV][NV] scratch arrays, n <= NV
+MJS_DEV bool chol_n(int n, double (*A)[NV]) {  // in place, lower triangle
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+      if (i == j) {
+        if (s < MJS_MINVAL) return false;
+        A[i][i] = sqrt(s);
+      } else
+        A[i][j] = s / A[j][j];
+    }
+  return true;
+}
+MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s / L[i][i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+
+struct Rows {
+  int n;
+  double J[MAXROW][NV], D[MAXROW], aref[MAXROW];
+};
+
+// mj_instantiateLimit + mj_instantiateContact (pyramidal, condim 4) + mj_makeImpedance + mj_referenceConstraint
+MJS_DEV void build_rows(const World& s, const rr::Chain& ch, const M3* Rb, int nb, const Contact* con, int ncon, const double* qvel, Rows& r) {
+  const int nv = NJ + 6 * nb;
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  r.n = 0;
+  for (int j = 0; j < NJ; j++)
+    for (int side = 0; side < 2; side++) {
+      const double sgn = side == 0 ? 1.0 : -1.0;
+      const double dist = side == 0 ? s.q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - s.q[j];
+      if (dist < 0.0) {
+        double* J = r.J[r.n];
+        for (int k = 0; k < nv; k++) J[k] = 0;
+        J[j] = sgn;
+        const double imp = impedance_default(dist);
+        r.D[r.n] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
+        r.aref[r.n] = -B * (sgn * s.v[j]) - K * imp * dist;
+        r.n++;
+      }
+    }
+  for (int c = 0; c < ncon; c++) {
+    const Contact& k = con[c];
+    if (!(k.dist < 0.0)) continue;  // detected, not active
+    V3 t1, t2;
+    {  // mju_makeFrame
+      V3 y = (k.n.y > -0.5 && k.n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
+      y = madd(y, -dot(k.n, y), k.n);
+      t1 = (1.0 / sqrt(dot(y, y))) * y;
+      t2 = cross(k.n, t1);
+    }
+    // contact-frame Jacobian (jac2 - jac1): rows normal, t1, t2 (translational) and torsion (rotational about the normal)
+    double Jc[4][NV];
+    for (int rr_ = 0; rr_ < 4; rr_++)
+      for (int d = 0; d < nv; d++) Jc[rr_][d] = 0;
+    for (int side = 0; side < 2; side++) {
+      const int body = side == 0 ? k.ba : k.bb;
+      const double sg = side == 0 ? -1.0 : 1.0;
+      if (body == 1) {
+        for (int j = 0; j < NJ; j++) {
+          const V3 ax = rr::joint_axis(ch, j), lin = cross(ax, k.pos - ch.p[j + 1]);
+          Jc[0][j] += sg * dot(k.n, lin); Jc[1][j] += sg * dot(t1, lin); Jc[2][j] += sg * dot(t2, lin); Jc[3][j] += sg * dot(k.n, ax);
+        }
+      } else if (body >= 2) {
+        const int b = body - 2, o = NJ + 6 * b;
+        const M3& R = Rb[b];
+        const V3 rvec = k.pos - s.b[b].p;
+        const V3 e[3] = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)}, axs[3] = {R.cx, R.cy, R.cz};
+        for (int d = 0; d < 3; d++) {
+          Jc[0][o + d] += sg * dot(k.n, e[d]); Jc[1][o + d] += sg * dot(t1, e[d]); Jc[2][o + d] += sg * dot(t2, e[d]);
+          const V3 lin = cross(axs[d], rvec);
+          Jc[0][o + 3 + d] += sg * dot(k.n, lin); Jc[1][o + 3 + d] += sg * dot(t1, lin); Jc[2][o + 3 + d] += sg * dot(t2, lin);
+          Jc[3][o + 3 + d] += sg * dot(k.n, axs[d]);
+        }
+      }
+    }
+    // friction: element-wise max of the pair; every pair of this scene involves a block (condim 4)
+    const bool blocks_only = k.ba >= 2 && k.bb >= 2;
+    const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
+    const double tran = k.tran;
+    const double imp = impedance_default(k.dist);
+    const double R0 = fmax(MJS_MINVAL, (1 - imp) * (tran + fri[0] * fri[0] * tran) / imp);
+    const double Dc = 1 / (2 * fri[0] * fri[0] * R0);
+    for (int kk = 0; kk < 3; kk++)
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        double* J = r.J[r.n];
+        double vel = 0;
+        for (int d = 0; d < nv; d++) { J[d] = Jc[0][d] + sgn * fri[kk] * Jc[1 + kk][d]; vel += J[d] * qvel[d]; }
+        r.D[r.n] = Dc;
+        r.aref[r.n] = -B * vel - K * imp * k.dist;
+        r.n++;
+      }
+  }
+}
+
+// mj_solPrimal (Newton), dense, cold start at qacc_smooth; returns qfrc_constraint = J^T force
+__device__ __noinline__ void solve_rows(int nv, const double (*M)[NV], const double* qfrc_smooth, const Rows& r, double meaninertia, double* qfrc_constraint) {
+  double H[NV][NV], a[NV], a_s[NV], Ma[NV], grad[NV], search[NV], Mv[NV], jar[MAXROW], jv[MAXROW], force[MAXROW];
+  bool active[MAXROW];
+  for (int i = 0; i < nv; i++) {
+    for (int j = 0; j <= i; j++) H[i][j] = M[i][j];
+    a_s[i] = qfrc_smooth[i];
+  }
+  chol_n(nv, H);
+  chol_solve_n(nv, H, a_s);
+  for (int i = 0; i < nv; i++) a[i] = a_s[i];
+  for (int i = 0; i < nv; i++) {
+    double m = 0;
+    for (int k = 0; k < nv; k++) m += M[i][k] * a[k];
+    Ma[i] = m;
+  }
+  for (int rw = 0; rw < r.n; rw++) {
+    double x = -r.aref[rw];
+    for (int k = 0; k < nv; k++) x += r.J[rw][k] * a[k];
+    jar[rw] = x;
+  }
+  auto update = [&]() {
+    double cost = 0;
+    for (int rw = 0; rw < r.n; rw++) {
+      const bool act = jar[rw] < 0;
+      active[rw] = act;
+      force[rw] = act ? -r.D[rw] * jar[rw] : 0.0;
+      if (act) cost += 0.5 * r.D[rw] * jar[rw] * jar[rw];
+    }
+    double gauss = 0;
+    for (int i = 0; i < nv; i++) gauss += (Ma[i] - qfrc_smooth[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv);
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    for (int i = 0; i < nv; i++) {
+      double g = Ma[i] - qfrc_smooth[i];
+      for (int rw = 0; rw < r.n; rw++) g -= r.J[rw][i] * force[rw];
+      grad[i] = g;
+      search[i] = -g;
+      for (int j = 0; j <= i; j++) H[i][j] = M[i][j];
+    }
+    for (int rw = 0; rw < r.n; rw++) {
+      if (!active[rw]) continue;
+      for (int i = 0; i < nv; i++) {
+        const double ji = r.J[rw][i] * r.D[rw];
+        if (ji == 0.0) continue;
+        for (int j = 0; j <= i; j++) H[i][j] += ji * r.J[rw][j];
+      }
+    }
+    if (!chol_n(nv, H)) break;
+    chol_solve_n(nv, H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+    for (int i = 0; i < nv; i++) {
+      double m = 0;
+      for (int k = 0; k < nv; k++) m += M[i][k] * search[k];
+      Mv[i] = m;
+    }
+    for (int i = 0; i < nv; i++) { g1 += search[i] * (Ma[i] - qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    for (int rw = 0; rw < r.n; rw++) {
+      double x = 0;
+      for (int k = 0; k < nv; k++) x += r.J[rw][k] * search[k];
+      jv[rw] = x;
+    }
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+      for (int rw = 0; rw < r.n; rw++) {
+        const double x = jar[rw] + alpha * jv[rw];
+        if (x < 0) { d1 += r.D[rw] * x * jv[rw]; d2 += r.D[rw] * jv[rw] * jv[rw]; }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+    for (int rw = 0; rw < r.n; rw++) jar[rw] += alpha * jv[rw];
+    const double oldcost = cost;
+    cost = update();
+    double gn = 0;
+    for (int i = 0; i < nv; i++) {
+      double g = Ma[i] - qfrc_smooth[i];
+      for (int rw = 0; rw < r.n; rw++) g -= r.J[rw][i] * force[rw];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  for (int i = 0; i < nv; i++) {
+    double f = 0;
+    for (int rw = 0; rw < r.n; rw++) f += r.J[rw][i] * force[rw];
+    qfrc_constraint[i] = f;
+  }
+}
+
+struct StepInfo {
+  bool bad, rows_active, unsupported;
+  int ncon;
+};
+
+// Decoupled case (the common one): no active arm-block or block-block contact and no joint limit. The constraint
+// problem is then separable: each block with its floor contacts is an independent 6-dof problem with at most 4
+// corner contacts x 6 pyramid edges. Static slots, everything unrolled (no indexed memory). The floor frame is
+// constant (n = +z, t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)), so a row is (F, (axis_d x r) . F) for the three
+// frame vectors F and (0, axis_d . n) for the torsional row. `Mb`: the block's 6x6 mass matrix (lower triangle used),
+// `f`: qfrc_smooth of the block in, qfrc_smooth + qfrc_constraint out.
+struct FloorSlots {
+  bool on[4];
+  double dist[4];
+  V3 r[4];  // contact point - body origin
+};
+__device__ __noinline__ void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
+                                               double* f) {
+  const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};  // max(block, floor) per component
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  // contact-frame Jacobians: rows normal, t1, t2, torsion over the block's 6 dofs
+  double Jc[4][4][6], D[4], aref[4][6];
+  const V3 axs[3] = {R.cx, R.cy, R.cz};
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const V3 lin = cross(axs[d], fs.r[c]);
+      Jc[c][0][d] = d == 2 ? 1.0 : 0.0; Jc[c][0][3 + d] = lin.z;    // n  = (0, 0, 1)
+      Jc[c][1][d] = d == 1 ? 1.0 : 0.0; Jc[c][1][3 + d] = lin.y;    // t1 = (0, 1, 0)
+      Jc[c][2][d] = d == 0 ? -1.0 : 0.0; Jc[c][2][3 + d] = -lin.x;  // t2 = (-1, 0, 0)
+      Jc[c][3][d] = 0.0; Jc[c][3][3 + d] = axs[d].z;                // torsion: rotation about n
+    }
+    const double imp = impedance_default(fs.dist[c]);
+    const double tran = 1.0 / MJS_BLOCK_MASS;
+    D[c] = 1 / (2 * mu[0] * mu[0] * fmax(MJS_MINVAL, (1 - imp) * (tran + mu[0] * mu[0] * tran) / imp));
+    double vel[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) vel[rw] += Jc[c][rw][d] * qvel[d];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) aref[c][e] = -B * (vel[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * vel[1 + (e >> 1)]) - K * imp * fs.dist[c];
+  }
+  auto edge_values = [&](const double* x, int c, double* out6) {
+    double u[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) u[rw] += Jc[c][rw][d] * x[d];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) out6[e] = u[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * u[1 + (e >> 1)];
+  };
+  double L[6][6], a[6], a_s[6], Ma[6], jar[4][6], force[4][6];
+  bool act[4][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = Mb[i][j];
+    a_s[i] = f[i];
+  }
+  rr::chol6(L);
+  rr::chol6_solve(L, a_s);
+#pragma unroll
+  for (int i = 0; i < 6; i++) a[i] = a_s[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double m = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * a[k];
+    Ma[i] = m;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    double ja[6];
+    edge_values(a, c, ja);
+#pragma unroll
+    for (int e = 0; e < 6; e++) jar[c][e] = ja[e] - aref[c][e];
+  }
+  auto update = [&]() {
+    double cost = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const bool on = fs.on[c] && jar[c][e] < 0;
+        act[c][e] = on;
+        force[c][e] = on ? -D[c] * jar[c][e] : 0.0;
+        if (on) cost += 0.5 * D[c] * jar[c][e] * jar[c][e];
+      }
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gauss += (Ma[i] - f[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+  auto constraint_force = [&](double* fc) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) fc[i] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const double fn = force[c][0] + force[c][1] + force[c][2] + force[c][3] + force[c][4] + force[c][5];
+      const double f1 = mu[0] * (force[c][0] - force[c][1]), f2 = mu[1] * (force[c][2] - force[c][3]), f3 = mu[2] * (force[c][4] - force[c][5]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) fc[i] += fn * Jc[c][0][i] + f1 * Jc[c][1][i] + f2 * Jc[c][2][i] + f3 * Jc[c][3][i];
+    }
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv_total);
+#pragma unroll 1
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[6], search[6], Mv[6], H[6][6], fc[6];
+    constraint_force(fc);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      grad[i] = Ma[i] - f[i] - fc[i];
+      search[i] = -grad[i];
+#pragma unroll
+      for (int j = 0; j <= i; j++) H[i][j] = Mb[i][j];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      // sum over active edges of D (Jn + s mu_k Jk)(Jn + s mu_k Jk)^T, k = t1, t2, torsion
+      double wn = 0, w[3], ww[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double np_ = act[c][2 * k], nm = act[c][2 * k + 1];
+        wn += np_ + nm;
+        w[k] = D[c] * mu[k] * (np_ - nm);
+        ww[k] = D[c] * mu[k] * mu[k] * (np_ + nm);
+      }
+      wn *= D[c];
+      if (wn != 0.0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const double jn = Jc[c][0][i];
+          const double rn = wn * jn + w[0] * Jc[c][1][i] + w[1] * Jc[c][2][i] + w[2] * Jc[c][3][i];
+          const double r1 = w[0] * jn + ww[0] * Jc[c][1][i], r2 = w[1] * jn + ww[1] * Jc[c][2][i], r3 = w[2] * jn + ww[2] * Jc[c][3][i];
+#pragma unroll
+          for (int j = 0; j <= i; j++) H[i][j] += rn * Jc[c][0][j] + r1 * Jc[c][1][j] + r2 * Jc[c][2][j] + r3 * Jc[c][3][j];
+        }
+      }
+    }
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * search[k];
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { g1 += search[i] * (Ma[i] - f[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    double jv[4][6];
+#pragma unroll
+    for (int c = 0; c < 4; c++) edge_values(search, c, jv[c]);
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+          const double x = jar[c][e] + alpha * jv[c][e];
+          if (fs.on[c] && x < 0) { d1 += D[c] * x * jv[c][e]; d2 += D[c] * jv[c][e] * jv[c][e]; }
+        }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int e = 0; e < 6; e++) jar[c][e] += alpha * jv[c][e];
+    }
+    const double oldcost = cost;
+    cost = update();
+    constraint_force(fc);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const double g = Ma[i] - f[i] - fc[i];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  double fc[6];
+  constraint_force(fc);
+#pragma unroll
+  for (int i = 0; i < 6; i++) f[i] += fc[i];
+}
+
+MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangle + the coupling block both ways
+  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) M[i][j] = 0;
+  }
+  M[0][0] = M[1][1] = M[2][2] = m;
+  M[3][3] = BLK_IXX + m * g * g; M[4][4] = BLK_IYY + m * g * g; M[5][5] = BLK_IZZ;
+  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
+  M[3][0] = M[0][3] = cx.x; M[3][1] = M[1][3] = cx.y; M[3][2] = M[2][3] = cx.z;
+  M[4][0] = M[0][4] = cy.x; M[4][1] = M[1][4] = cy.y; M[4][2] = M[2][4] = cy.z;
+}
+
+// The coupled case (an arm-block or block-block contact is active, or a joint is beyond its range): dense Newton over
+// all nv dofs with the rows in indexed per-lane arrays. Returns qfrc_smooth + qfrc_constraint in qacc.
+__device__ __noinline__ void coupled_forces(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb, double* qacc) {
+  const int nv = NJ + 6 * nb;
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  M3 Rb[NB];
+  for (int b = 0; b < nb; b++) {
+    double qn[4];
+    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    Rb[b] = quat_to_m3(qn);
+  }
+  Contact con[MAXCON];
+  int extra;
+  bool eef_floor;
+  const int ncon = detect_contacts(ch, s, Rb, nb, con, extra, eef_floor);
+  double M[NV][NV], qs[NV], qvel[NV];
+  for (int i = 0; i < nv; i++)
+    for (int j = 0; j < nv; j++) M[i][j] = 0;
+  for (int i = 0; i < NJ; i++) {
+    for (int j = 0; j <= i; j++) M[i][j] = M[j][i] = Marm[i * (i + 1) / 2 + j];
+    M[i][i] += MJS_UR_ARMATURE;
+    qs[i] = qs_arm[i];
+    qvel[i] = s.v[i];
+  }
+  for (int b = 0; b < nb; b++) {
+    const int o = NJ + 6 * b;
+    block_mass_matrix(Rb[b], M, o);
+    block_smooth_force(Rb[b], s.b[b].w, qs + o);
+    qvel[o] = s.b[b].v.x; qvel[o + 1] = s.b[b].v.y; qvel[o + 2] = s.b[b].v.z;
+    qvel[o + 3] = s.b[b].w.x; qvel[o + 4] = s.b[b].w.y; qvel[o + 5] = s.b[b].w.z;
+  }
+  for (int i = 0; i < nv; i++) qacc[i] = qs[i];
+  Rows rows;
+  build_rows(s, ch, Rb, nb, con, ncon, qvel, rows);
+  if (rows.n > 0) {
+    double fc[NV];
+    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+    solve_rows(nv, M, qs, rows, meaninertia, fc);
+    for (int i = 0; i < nv; i++) qacc[i] += fc[i];
+  }
+}
+
+// One Physics.step() (mj_step2 of the current state; the next mj_step1 is the start of the next call): smooth
+// dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
+__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info) {
+  const int nv = NJ + 6 * nb;
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  M3 Rb[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    double qn[4];
+    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    Rb[b] = quat_to_m3(qn);
+  }
+  Contact con[MAXCON];
+  int extra;
+  bool eef_floor;
+  const int ncon = detect_contacts(ch, s, Rb, nb, con, extra, eef_floor);
+  info.unsupported = info.unsupported || eef_floor;
+  // arm smooth dynamics
+  double Marm[21], bias[NJ], fact[NJ], qacc[NV];
+  ur5e_pp_M_gen(cs, sn, Marm);
+  ur5e_pp_bias_gen(cs, sn, s.v, bias);
+  const int clamped = rr::actuator_forces(s.q, s.v, ctrl, fact);
+#pragma unroll
+  for (int i = 0; i < NJ; i++) qacc[i] = fact[i] - bias[i];
+  // which constraint problem?
+  bool coupled = false, any_floor = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) coupled = coupled || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
+  for (int c = 0; c < ncon; c++) {
+    const bool active = con[c].dist < 0.0;
+    coupled = coupled || (active && con[c].ba != 0);
+    any_floor = any_floor || (active && con[c].ba == 0);
+  }
+  if (coupled) {
+    coupled_forces(s, cs, sn, Marm, qacc, nb, qacc);
+    info.rows_active = true;
+  } else {
+    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b >= nb) continue;
+      const int o = NJ + 6 * b;
+      block_smooth_force(Rb[b], s.b[b].w, qacc + o);
+      FloorSlots fs;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
+      int slot = 0;
+      for (int c = 0; c < ncon; c++)  // floor contacts of this block, in detection order
+        if (con[c].ba == 0 && con[c].bb == 2 + b) {
+          const bool on = con[c].dist < 0.0;
+          const V3 r = con[c].pos - s.b[b].p;
+          if (slot == 0) { fs.on[0] = on; fs.dist[0] = con[c].dist; fs.r[0] = r; }
+          if (slot == 1) { fs.on[1] = on; fs.dist[1] = con[c].dist; fs.r[1] = r; }
+          if (slot == 2) { fs.on[2] = on; fs.dist[2] = con[c].dist; fs.r[2] = r; }
+          if (slot == 3) { fs.on[3] = on; fs.dist[3] = con[c].dist; fs.r[3] = r; }
+          slot++;
+          any = any || on;
+        }
+      if (any) {
+        double Mb[6][6];
+        block_mass_matrix6(Rb[b], Mb);
+        const double qv[6] = {s.b[b].v.x, s.b[b].v.y, s.b[b].v.z, s.b[b].w.x, s.b[b].w.y, s.b[b].w.z};
+        solve_block_floor(Mb, Rb[b], fs, qv, meaninertia, nv, qacc + o);
+        info.rows_active = true;
+      }
+    }
+  }
+  // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
+  {
+    double A[NJ][NJ], rhs[NJ], Dinv[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = Marm[i * (i + 1) / 2 + j];
+      rhs[i] = qacc[i];
+    }
+    rr::factor_system(A, clamped, Dinv);
+    rr::udu_solve(A, Dinv, rhs);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) qacc[i] = rhs[i];
+  }
+  double acc2 = 0, dq2 = 0;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const int o = NJ + 6 * b;
+    double Lb[6][6], x[6];
+    block_mass_matrix6(Rb[b], Lb);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = qacc[o + i];
+    rr::chol6(Lb);
+    rr::chol6_solve(Lb, x);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { qacc[o + i] = x[i]; acc2 = fma(x[i], x[i], acc2); }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    acc2 = fma(qacc[j], qacc[j], acc2);
+    s.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+    const double dq = MJS_RR_PHYSICS_DT * s.v[j];
+    s.q[j] += dq;
+    dq2 = fma(dq, dq, dq2);
+    rr::rotate_small(cs[j], sn[j], dq);
+  }
+  if (!(dq2 <= 0.01)) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const int o = NJ + 6 * b;
+    Block& k = s.b[b];
+    k.v = madd(k.v, MJS_RR_PHYSICS_DT, v3(qacc[o], qacc[o + 1], qacc[o + 2]));
+    k.w = madd(k.w, MJS_RR_PHYSICS_DT, v3(qacc[o + 3], qacc[o + 4], qacc[o + 5]));
+    k.p = madd(k.p, MJS_RR_PHYSICS_DT, k.v);
+    // mju_quatIntegrate with the body-frame angular velocity
+    double nrm = sqrt(k.q[0] * k.q[0] + k.q[1] * k.q[1] + k.q[2] * k.q[2] + k.q[3] * k.q[3]);
+    const double ang = sqrt(dot(k.w, k.w));
+    if (ang >= MJS_MINVAL) {
+      const V3 ax = (1.0 / ang) * k.w;
+      double sh, chf;
+      sincos(0.5 * ang * MJS_RR_PHYSICS_DT, &sh, &chf);
+      const double q0 = k.q[0] / nrm, q1 = k.q[1] / nrm, q2 = k.q[2] / nrm, q3 = k.q[3] / nrm;
+      const double r0 = chf, r1 = ax.x * sh, r2 = ax.y * sh, r3 = ax.z * sh;
+      k.q[0] = q0 * r0 - q1 * r1 - q2 * r2 - q3 * r3;
+      k.q[1] = q0 * r1 + q1 * r0 + q2 * r3 - q3 * r2;
+      k.q[2] = q0 * r2 - q1 * r3 + q2 * r0 + q3 * r1;
+      k.q[3] = q0 * r3 + q1 * r2 - q2 * r1 + q3 * r0;
+      nrm = sqrt(k.q[0] * k.q[0] + k.q[1] * k.q[1] + k.q[2] * k.q[2] + k.q[3] * k.q[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.q[i] /= nrm;
+  }
+  info.bad = info.bad || !(acc2 <= 1e20);
+  s.time += MJS_RR_PHYSICS_DT;
+  info.ncon = ncon + extra;
+}
+
+// contacts of the current state as mj_forward / the trailing mj_step1 would report them (d->ncon)
+__device__ __noinline__ int count_contacts(const World& s, const double* cs, const double* sn, int nb) {
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  M3 Rb[NB];
+  for (int b = 0; b < nb; b++) {
+    double qn[4];
+    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    Rb[b] = quat_to_m3(qn);
+  }
+  Contact con[MAXCON];
+  int extra;
+  bool eef_floor;
+  return detect_contacts(ch, s, Rb, nb, con, extra, eef_floor) + extra;
+}
+
+MJS_DEV bool tcp_to_joints(const double* pos, const double* guess, double* q_out) { return rr::tcp_pose_to_joints_offset(pos, MJS_CYL_TCP_Z, guess, q_out); }
+
+MJS_DEV void make_obs(const World& s, const double* cs, const double* sn, int nb, double* obs) {
+  rr::Chain c;
+  rr::fk_cs(cs, sn, c);
+  const V3 tcp = eef_tcp_position(c);
+  obs[0] = tcp.x; obs[1] = tcp.y; obs[2] = tcp.z;            // ur5e/tcp_position
+  obs[3] = s.target[0]; obs[4] = s.target[1];                // target_position = site.pos[:2]
+  for (int b = 0; b < NB; b++) {                             // block_positions = body xpos[:2]
+    obs[5 + 2 * b] = b < nb ? s.b[b].p.x : 0.0;
+    obs[6 + 2 * b] = b < nb ? s.b[b].p.y : 0.0;
+  }
+}
+
+// initialize_episode (robot_planar_push.py:149-176, intended semantics)
+__device__ __noinline__ void episode_init(DevRng rng, int i, int nb, World& s, int& ncon, bool& bad) {
+  RngCursor c = rng_open(rng, i);
+  double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
+  const bool ok = tcp_to_joints(rp, zeros, q);
+  for (int j = 0; j < NJ; j++) { s.q[j] = ok ? q[j] : 0.0; s.v[j] = 0; }
+  for (int k = 0; k < 3; k++) s.target[k] = rng_uniform(rng, i, c, MJS_PP_TARGET_SPACE_LO[k], MJS_PP_TARGET_SPACE_HI[k]);
+  s.time = 0;
+  s.episode_step = 0;
+  double cs[NJ], sn[NJ];
+  for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  for (int b = 0; b < NB; b++) { s.b[b].p = v3(0, 0, 0); s.b[b].q[0] = 1; s.b[b].q[1] = s.b[b].q[2] = s.b[b].q[3] = 0; s.b[b].v = v3(0, 0, 0); s.b[b].w = v3(0, 0, 0); }
+  for (int attempt = 0; attempt < 1000; attempt++) {  // randomize_object_position: until mj_forward reports ncon == 0
+    for (int b = 0; b < nb; b++) {
+      double bp[3];
+      for (int k = 0; k < 3; k++) bp[k] = rng_uniform(rng, i, c, MJS_PP_OBJECT_SPACE_LO[k], MJS_PP_OBJECT_SPACE_HI[k]);
+      s.b[b].p = v3(bp[0], bp[1], bp[2]);
+    }
+    if (count_contacts(s, cs, sn, nb) == 0) break;
+  }
+  rng_close(rng, i, c);
+  StepInfo info{false, false, false, 0};
+  double ctrl0[NJ];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189); no trajectory yet
+  for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];
+  for (int k = 0; k < MJS_PP_SETTLE_STEPS; k++) physics_step(s, ctrl0, cs, sn, nb, info);
+  ncon = count_contacts(s, cs, sn, nb);
+  bad = info.bad;
+}
+
+template <bool IS_RESET>
+__global__ __launch_bounds__(64) void kernel(KernelParams p) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= p.N) return;
+  const int nb = p.n_objects;
+  uint8_t flags = p.flags[i];
+  double obs[OBS_DIM], cs[NJ], sn[NJ];
+  World s;
+  if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
+    int ncon;
+    bool bad;
+    episode_init(p.rng, i, nb, s, ncon, bad);
+    store_world(p, i, s);
+    p.flags[i] = 0;
+    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+    make_obs(s, cs, sn, nb, obs);
+    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
+    return;
+  }
+  s = load_world(p, i);
+  // before_step (base.py:31-32, robot_planar_push.py:185-201)
+  s.episode_step += 1.0;
+  double q0[NJ], q1[NJ], act[3] = {p.actions[(size_t)i * ACT_DIM], p.actions[(size_t)i * ACT_DIM + 1], MJS_PP_ACTION_Z};
+  for (int j = 0; j < NJ; j++) q0[j] = s.q[j];
+  if (!tcp_to_joints(act, q0, q1)) {
+    flags |= FLAG_IK_FAILED;
+    for (int j = 0; j < NJ; j++) q1[j] = q0[j];
+  }
+  const double t0 = s.time, t1 = s.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
+  for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  StepInfo info{false, false, false, 0};
+#pragma unroll 1
+  for (int sub = 0; sub < MJS_RR_NSUB; sub++) {
+    const double t = fmin(fmax(s.time, t0), t1);
+    double ctrl[NJ];
+    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    physics_step(s, ctrl, cs, sn, nb, info);
+  }
+  bool bad = info.bad;
+  for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
+  for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
+  make_obs(s, cs, sn, nb, obs);
+  // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
+  double sum = 0, nearest = INFINITY;
+  int inside = 0;
+  for (int b = 0; b < nb; b++) {
+    const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
+    const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
+    sum += dt;
+    inside += dt < MJS_PP_TARGET_RADIUS;
+    nearest = fmin(nearest, dr);
+  }
+  const bool success = inside == nb;
+  double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
+  double discount = success ? 0.0 : 1.0;
+  bool terminate = success || s.episode_step >= (double)p.max_episode_steps;
+  if (bad) { reward = 0; discount = 0; terminate = true; }
+  if (s.time >= p.time_limit) terminate = true;
+  const int ncon = count_contacts(s, cs, sn, nb);
+  const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+                    (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
+  const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+  store_world(p, i, s);
+  p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
+    if (p.out.terminal_obs)
+      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+    int ncon2;
+    bool bad2;
+    episode_init(p.rng, i, nb, s, ncon2, bad2);
+    store_world(p, i, s);
+    p.flags[i] = 0;
+    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+    make_obs(s, cs, sn, nb, obs);
+    if (p.out.obs)
+      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+    if (p.out.ncon) p.out.ncon[i] = ncon2;
+  }
+}
+
+}  // namespace pp

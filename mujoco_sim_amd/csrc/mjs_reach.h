@@ -716,7 +716,12 @@ MJS_DEV bool ik_closest(const Aff& T, const double* g, double* q_out) {
 }
 
 // TCP pose (position + scalar-LAST quaternion, type_aliases.py:6-10) -> joints (robot.py:113-121,138-151)
+MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const double* q_guess, double* q_out);
 MJS_DEV bool tcp_pose_to_joints(const double* pos, const double* q_guess, double* q_out) {
+  return tcp_pose_to_joints_offset(pos, MJS_G2F85_TCP_Z, q_guess, q_out);
+}
+// tcp_z = TCP offset of the attached end effector along the flange z axis (gripper 0.174, CylinderEEF 0.1)
+MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const double* q_guess, double* q_out) {
   double x = MJS_TOP_DOWN_QUAT_XYZW[0], y = MJS_TOP_DOWN_QUAT_XYZW[1], z = MJS_TOP_DOWN_QUAT_XYZW[2], w = MJS_TOP_DOWN_QUAT_XYZW[3];
   double n = sqrt(x * x + y * y + z * z + w * w);
   x /= n; y /= n; z /= n; w /= n;
@@ -724,9 +729,9 @@ MJS_DEV bool tcp_pose_to_joints(const double* pos, const double* q_guess, double
   T.r[0] = 1 - 2 * (y * y + z * z); T.r[1] = 2 * (x * y - z * w); T.r[2] = 2 * (x * z + y * w);
   T.r[3] = 2 * (x * y + z * w); T.r[4] = 1 - 2 * (x * x + z * z); T.r[5] = 2 * (y * z - x * w);
   T.r[6] = 2 * (x * z - y * w); T.r[7] = 2 * (y * z + x * w); T.r[8] = 1 - 2 * (x * x + y * y);
-  T.t[0] = pos[0] - T.r[2] * MJS_G2F85_TCP_Z;
-  T.t[1] = pos[1] - T.r[5] * MJS_G2F85_TCP_Z;
-  T.t[2] = pos[2] - T.r[8] * MJS_G2F85_TCP_Z;
+  T.t[0] = pos[0] - T.r[2] * tcp_z;
+  T.t[1] = pos[1] - T.r[5] * tcp_z;
+  T.t[2] = pos[2] - T.r[8] * tcp_z;
   return ik_closest(T, q_guess, q_out);
 }
 

@@ -11,6 +11,7 @@
 #include "mjs_pointmass.h"
 #include "mjs_reach.h"
 #include "mjs_button.h"
+#include "mjs_push.h"
 #include "mjs_render.h"
 #include <cmath>
 
@@ -48,6 +49,7 @@ int hip_fail(mjs_handle* h, hipError_t e, const char* what) {
 double default_time_limit(int task) {
   if (task == MJS_TASK_POINTMASS_REACH) return MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT;  // mujoco_sim/__init__.py:21,28
   if (task == MJS_TASK_BUTTON_PUSH) return MJS_BP_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      // mujoco_sim/__init__.py:45-49
+  if (task == MJS_TASK_PLANAR_PUSH) return 1e300;  // scripts/sb3/planar_push.py:72: no Environment time limit, the task counts steps
   return MJS_RR_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;                                       // BASELINE config 3
 }
 int default_reward(int task) { return task == MJS_TASK_POINTMASS_REACH ? MJS_REW_DENSE_BIASED_NEG_DISTANCE : MJS_REW_DENSE_NEG_DISTANCE; }
@@ -114,6 +116,8 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.terminate_on_success = h->cfg.terminate_on_success;
   p.action_type = h->cfg.action_type;
   p.button_disturbances = h->cfg.button_disturbances;
+  p.n_objects = h->cfg.n_objects;
+  p.max_episode_steps = h->cfg.max_episode_steps;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -131,6 +135,7 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH) pp::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
@@ -148,18 +153,18 @@ extern "C" {
 const char* mjs_version(void) { return "mjsim-hip 0.1 (gfx950, abi 1)"; }
 
 int mjs_obs_dim(int task) {
-  return task == MJS_TASK_POINTMASS_REACH ? pm::OBS_DIM : task == MJS_TASK_ROBOT_REACH ? rr::OBS_DIM : task == MJS_TASK_BUTTON_PUSH ? bp::OBS_DIM : -1;
+  return task == MJS_TASK_POINTMASS_REACH ? pm::OBS_DIM : task == MJS_TASK_ROBOT_REACH ? rr::OBS_DIM : task == MJS_TASK_BUTTON_PUSH ? bp::OBS_DIM : task == MJS_TASK_PLANAR_PUSH ? pp::OBS_DIM : -1;
 }
 int mjs_action_dim_for(int task, int action_type) {
   if (task == MJS_TASK_BUTTON_PUSH) return action_type == MJS_ACTION_ABS_EEF ? bp::ACT_DIM_EEF : action_type == MJS_ACTION_ABS_JOINT ? bp::ACT_DIM_JOINT : -1;
-  return task == MJS_TASK_POINTMASS_REACH ? pm::ACT_DIM : task == MJS_TASK_ROBOT_REACH ? rr::ACT_DIM : -1;
+  return task == MJS_TASK_POINTMASS_REACH ? pm::ACT_DIM : task == MJS_TASK_ROBOT_REACH ? rr::ACT_DIM : task == MJS_TASK_PLANAR_PUSH ? pp::ACT_DIM : -1;
 }
 int mjs_action_dim(int task) { return mjs_action_dim_for(task, MJS_ACTION_ABS_JOINT); }
 int mjs_state_dim(int task) {
-  return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : task == MJS_TASK_BUTTON_PUSH ? bp::STATE_DIM + 1 : -1;
+  return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : task == MJS_TASK_BUTTON_PUSH ? bp::STATE_DIM + 1 : task == MJS_TASK_PLANAR_PUSH ? pp::STATE_DIM + 1 : -1;
 }
 int mjs_substeps(int task) {
-  return task == MJS_TASK_POINTMASS_REACH ? MJS_PM_NSUB : (task == MJS_TASK_ROBOT_REACH || task == MJS_TASK_BUTTON_PUSH) ? MJS_RR_NSUB : -1;
+  return task == MJS_TASK_POINTMASS_REACH ? MJS_PM_NSUB : (task == MJS_TASK_ROBOT_REACH || task == MJS_TASK_BUTTON_PUSH || task == MJS_TASK_PLANAR_PUSH) ? MJS_RR_NSUB : -1;
 }
 
 int mjs_algorithmic_bytes_per_env_step(int task) {
@@ -169,6 +174,8 @@ int mjs_algorithmic_bytes_per_env_step(int task) {
     return 8 * pm::STATE_DIM /*R*/ + 8 * (pm::STATE_DIM - 2) /*W: target unchanged*/ + 2 + 8 * pm::ACT_DIM + 8 * pm::OBS_DIM + out_fixed;
   if (task == MJS_TASK_ROBOT_REACH)
     return 8 * rr::STATE_DIM /*R*/ + 8 * (rr::STATE_DIM - 3) /*W: target unchanged*/ + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;
+  if (task == MJS_TASK_PLANAR_PUSH)  // everything but the target is rewritten
+    return 8 * pp::STATE_DIM /*R*/ + 8 * (pp::STATE_DIM - 3) /*W*/ + 2 + 8 * pp::ACT_DIM + 8 * pp::OBS_DIM + out_fixed;
   if (task == MJS_TASK_BUTTON_PUSH)
     return 8 * bp::STATE_DIM /*R*/ + 8 * (bp::STATE_DIM - 3) /*W: switch pose unchanged*/ + 2 + 8 * bp::ACT_DIM_JOINT + 8 * bp::OBS_DIM + out_fixed;
   return -1;
@@ -179,10 +186,10 @@ const char* mjs_last_error(const mjs_handle* h) { return h ? h->err.c_str() : g_
 int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (!cfg || !out) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: null argument");
   *out = nullptr;
-  if (cfg->task == MJS_TASK_PLANAR_PUSH) return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: Planar-Push is not built yet (DESIGN.md, row a13)");
-  if (cfg->task != MJS_TASK_POINTMASS_REACH && cfg->task != MJS_TASK_ROBOT_REACH && cfg->task != MJS_TASK_BUTTON_PUSH)
+  if (cfg->task != MJS_TASK_POINTMASS_REACH && cfg->task != MJS_TASK_ROBOT_REACH && cfg->task != MJS_TASK_BUTTON_PUSH && cfg->task != MJS_TASK_PLANAR_PUSH)
     return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: unknown task id");
   if (mjs_action_dim_for(cfg->task, cfg->action_type) < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad action_type");
+  if (cfg->task == MJS_TASK_PLANAR_PUSH && cfg->n_objects > MJS_PP_MAX_OBJECTS) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: n_objects exceeds MJS_PP_MAX_OBJECTS");
   if (cfg->num_envs <= 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: num_envs must be positive");
   if (cfg->autoreset < MJS_AUTORESET_NEXT_STEP || cfg->autoreset > MJS_AUTORESET_DISABLED)
     return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad autoreset mode");
@@ -194,6 +201,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (!h) return fail(nullptr, MJS_ERR_ALLOC, "mjs_create: out of host memory");
   h->cfg = *cfg;
   if (h->cfg.reward_type < 0) h->cfg.reward_type = default_reward(cfg->task);
+  if (h->cfg.n_objects <= 0) h->cfg.n_objects = MJS_PP_MAX_OBJECTS;
+  if (h->cfg.max_episode_steps <= 0) h->cfg.max_episode_steps = MJS_PP_MAX_CONTROL_STEPS;
   if (!(h->cfg.time_limit > 0)) h->cfg.time_limit = default_time_limit(cfg->task);
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);

@@ -53,6 +53,9 @@ class HipEnvironment:
         kwargs = {}
         if hasattr(task, "config") and getattr(task.config, "terminate_on_success", False):
             kwargs["terminate_on_success"] = True
+        if task.task_name == "robot_planar_push":
+            kwargs["n_objects"] = task.config.n_objects
+            kwargs["max_episode_steps"] = task.config.max_control_steps_per_episode
         if hasattr(task, "action_type") and task.task_name == "robot_push_button":
             kwargs["action_type"] = task.action_type
             kwargs["button_disturbances"] = task.button_disturbances

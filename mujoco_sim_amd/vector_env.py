@@ -71,6 +71,14 @@ TASKS = {
     # robot_push_button.py:113-119 observables (which robot observable is enabled follows the action type, the
     # kernel always writes both), switch.py:86-108 (the Switch model is an unnamed mjcf root -> "unnamed_model/");
     # :176-203 action spec (ABS_JOINT default; ABS_EEF bounds are substituted in HipVectorEnv), :38-40 timing
+    # robot_planar_push.py:120-126,134-138 (STATE obs: tcp_position, target_position = site.pos[:2], block_positions = body
+    # xpos[:2] per block), :222-228 action spec ([-1, 1]^2, used directly as absolute TCP xy in metres, :197-201), :49-53 timing
+    "robot_planar_push": TaskSpec(
+        "robot_planar_push", nat.TASK_PLANAR_PUSH,
+        (("ur5e/tcp_position", 0, 3), ("target_position", 3, 2), ("block_positions", 5, 4)),
+        (-1.0, -1.0), (1.0, 1.0), np.float32,
+        (SPARSE_REWARD, DENSE_NEG_DISTANCE_REWARD),
+        0.1, 0.005, 500),
     "robot_push_button": TaskSpec(
         "robot_push_button", nat.TASK_BUTTON_PUSH,
         (("ur5e/joint_configuration", 0, 6), ("ur5e/tcp_position", 6, 3), ("unnamed_model/position", 9, 3), ("unnamed_model/active", 12, 1)),
@@ -92,7 +100,8 @@ class HipVectorEnv:
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
-                 button_disturbances: bool = False, use_wrist_camera: bool = True):
+                 button_disturbances: bool = False, use_wrist_camera: bool = True, n_objects: int | None = None,
+                 max_episode_steps: int | None = None):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -118,7 +127,8 @@ class HipVectorEnv:
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
                             time_limit=float(time_limit) if time_limit is not None else -1.0,
-                            action_type=_ACTION_IDS.get(action_type, 0), button_disturbances=int(bool(button_disturbances)))
+                            action_type=_ACTION_IDS.get(action_type, 0), button_disturbances=int(bool(button_disturbances)),
+                            n_objects=int(n_objects or 0), max_episode_steps=int(max_episode_steps or 0))
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h
@@ -144,6 +154,9 @@ class HipVectorEnv:
         # observable matching its action type (robot_push_button.py:113-117)
         self.action_low, self.action_high = self.spec.action_low, self.spec.action_high
         self._state_layout = self.spec.obs_layout
+        if task == "robot_planar_push":  # block_positions has 2 entries per configured block (robot_planar_push.py:178-179)
+            self.n_objects = int(n_objects or 2)
+            self._state_layout = self.spec.obs_layout[:2] + (("block_positions", 5, 2 * self.n_objects),)
         if task == "robot_push_button":
             drop = "ur5e/tcp_position" if action_type == ABS_JOINT_ACTION else "ur5e/joint_configuration"
             self._state_layout = tuple(e for e in self.spec.obs_layout if e[0] != drop)

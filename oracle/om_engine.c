@@ -487,6 +487,14 @@ static void collide_sphere_box(const om_model* m, om_data* d, int g1, int g2) {
  * position = midpoint of the two witness points (barycentric weights of the origin ray in the portal).
  * Plain + - * / sqrt arithmetic, compiled without FMA contraction: the HIP kernel repeats the same operations. */
 typedef struct { double v[3], a[3], b[3]; } mpr_vert; /* v = a - b, a on geom1, b on geom2 */
+/* Flat-on-flat and line contacts (a block lying on the floor pushed by a vertical cylinder, block on block) make many
+ * of the sign tests below exact ties in exact arithmetic; biased thresholds decide every such tie the same way
+ * whatever the rounding noise of the inputs, which keeps the contact point a deterministic function of the pose.
+ * MPR_EPS_DIR: components of unit directions; MPR_EPS_LEN: products with one length (~1e-2 m);
+ * MPR_EPS_VOL: triple products of Minkowski-difference points (~1e-5 m^3). */
+#define MPR_EPS_DIR 1e-10
+#define MPR_EPS_LEN 1e-13
+#define MPR_EPS_VOL 1e-16
 
 static void support_geom(const om_model* m, const om_data* d, int g, const double* dir, double* out) {
   const double* gp = d->geom_xpos[g];
@@ -495,11 +503,11 @@ static void support_geom(const om_model* m, const om_data* d, int g, const doubl
   double loc[3], res[3];
   for (int k = 0; k < 3; k++) loc[k] = gm[k] * dir[0] + gm[3 + k] * dir[1] + gm[6 + k] * dir[2]; /* R^T dir */
   if (m->geom_type[g] == OM_GEOM_BOX) {
-    for (int k = 0; k < 3; k++) res[k] = loc[k] >= 0 ? sz[k] : -sz[k];
+    for (int k = 0; k < 3; k++) res[k] = loc[k] >= -MPR_EPS_DIR ? sz[k] : -sz[k];
   } else { /* cylinder, axis = local z */
     double len = sqrt(loc[0] * loc[0] + loc[1] * loc[1]);
-    if (len > 1e-12) { res[0] = sz[0] * loc[0] / len; res[1] = sz[0] * loc[1] / len; } else { res[0] = 0; res[1] = 0; }
-    res[2] = loc[2] >= 0 ? sz[1] : -sz[1];
+    if (len > MPR_EPS_DIR) { res[0] = sz[0] * loc[0] / len; res[1] = sz[0] * loc[1] / len; } else { res[0] = 0; res[1] = 0; }
+    res[2] = loc[2] >= -MPR_EPS_DIR ? sz[1] : -sz[1];
   }
   mulMatVec3(out, gm, res);
   for (int k = 0; k < 3; k++) out[k] += gp[k];
@@ -539,7 +547,7 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
   for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
   cross3(dir, t1, t2);
   if (!normalize3(dir)) return 0;
-  if (dot3(dir, v0.v) > 0) { mpr_vert t = v1; v1 = v2; v2 = t; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
+  if (dot3(dir, v0.v) > MPR_EPS_LEN) { mpr_vert t = v1; v1 = v2; v2 = t; for (int k = 0; k < 3; k++) dir[k] = -dir[k]; }
   /* portal discovery */
   for (int it = 0;; it++) {
     if (it >= MJS_MPR_MAX_ITER) return 0;
@@ -547,10 +555,10 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
     if (dot3(v3.v, dir) <= 0) return 0;
     int cont = 0;
     cross3(t1, v1.v, v3.v);
-    if (dot3(t1, v0.v) < 0) { v2 = v3; cont = 1; }
+    if (dot3(t1, v0.v) < -MPR_EPS_VOL) { v2 = v3; cont = 1; }
     else {
       cross3(t1, v3.v, v2.v);
-      if (dot3(t1, v0.v) < 0) { v1 = v3; cont = 1; }
+      if (dot3(t1, v0.v) < -MPR_EPS_VOL) { v1 = v3; cont = 1; }
     }
     if (!cont) break;
     for (int k = 0; k < 3; k++) { t1[k] = v1.v[k] - v0.v[k]; t2[k] = v2.v[k] - v0.v[k]; }
@@ -563,7 +571,7 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
     for (int k = 0; k < 3; k++) { t1[k] = v2.v[k] - v1.v[k]; t2[k] = v3.v[k] - v1.v[k]; }
     cross3(dir, t1, t2);
     if (!normalize3(dir)) return 0;
-    if (dot3(dir, v1.v) >= 0) hit = 1; /* the origin is on the inner side of the portal: the shapes overlap */
+    if (dot3(dir, v1.v) >= -MPR_EPS_LEN) hit = 1; /* the origin is on the inner side of the portal: the shapes overlap */
     mpr_support(m, d, g1, g2, dir, &v4);
     double reach = dot3(v4.v, dir);
     if (!hit && reach < 0) return 0; /* the support plane separates the origin */
@@ -590,10 +598,10 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
     }
     /* expand the portal with v4: keep the face the ray origin->(-v0) passes through */
     cross3(t1, v4.v, v0.v);
-    if (dot3(v1.v, t1) > 0) {
-      if (dot3(v2.v, t1) > 0) v1 = v4; else v3 = v4;
+    if (dot3(v1.v, t1) > MPR_EPS_VOL) {
+      if (dot3(v2.v, t1) > MPR_EPS_VOL) v1 = v4; else v3 = v4;
     } else {
-      if (dot3(v3.v, t1) > 0) v2 = v4; else v1 = v4;
+      if (dot3(v3.v, t1) > MPR_EPS_VOL) v2 = v4; else v1 = v4;
     }
   }
   return 0;

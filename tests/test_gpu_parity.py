@@ -542,3 +542,139 @@ def test_registered_button_push_visual_env_id():
         done, n = term or trunc, n + 1
     assert done and n <= 100 and "is_success" in info
     env.close()
+
+
+# ------------------------------------------------------------------------------------------ Planar-Push
+def _push_state_to_gpu(venv, qpos, qvel, time):
+    """oracle layout (qpos [N, 6 + 7 n], qvel [N, 6 + 6 n]) -> mjs_set_state rows (q6 v6 time target3 step, 13 per block)"""
+    gs = venv.get_state().clone()
+    gs[0:6] = torch.from_numpy(qpos[:, :6].T)
+    gs[6:12] = torch.from_numpy(qvel[:, :6].T)
+    gs[12] = torch.from_numpy(time)
+    for b in range((qpos.shape[1] - 6) // 7):
+        gs[17 + 13 * b: 17 + 13 * b + 7] = torch.from_numpy(qpos[:, 6 + 7 * b: 13 + 7 * b].T)
+        gs[17 + 13 * b + 7: 17 + 13 * b + 13] = torch.from_numpy(qvel[:, 6 + 6 * b: 12 + 6 * b].T)
+    venv.set_state(gs)
+
+
+def _quat(axis, ang):
+    axis = np.asarray(axis, float) / np.linalg.norm(axis)
+    return np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * axis])
+
+
+def test_planar_push_controlled_scenarios(oracle_mod):
+    """Free bodies and every contact pair of the scene from identical hand-set states (mjs_set_state): free tumbling,
+    tilted drop on the floor (corner contacts), spinning on the floor (torsional friction rows), sliding, block
+    dropped on block (box-box MPR), EEF pushing one block and a block chain (cylinder-box MPR + arm Jacobian)."""
+    import mujoco_sim_amd as m
+
+    N = 7
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=1)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 1, nthreads=4)
+    venv.reset()
+    o = ob.reset()
+    qp, qv, tm = ob.get_state()
+    tcp = o["obs"][:, :3].copy()
+    qp[:, 6:13] = [0.14, -0.36, 0.0, 1, 0, 0, 0]
+    qp[:, 13:20] = [-0.14, -0.36, 0.0, 1, 0, 0, 0]
+    qv[:] = 0
+    qp[0, 6:13] = [0.1, -0.45, 0.6, *_quat([1, 2, 3], 0.7)]
+    qv[0, 6:12] = [0.1, -0.2, 0.3, 2.0, -3.0, 1.5]
+    qp[1, 6:13] = [0.1, -0.45, 0.03, *_quat([1, 1, 0], 0.4)]
+    qp[2, 6:13] = [0.1, -0.45, 0.02, 1, 0, 0, 0]
+    qv[2, 6:12] = [0, 0, 0, 0, 0, 6.0]
+    qp[3, 6:13] = [0.1, -0.45, 0.0, 1, 0, 0, 0]
+    qv[3, 6:12] = [0.5, 0.2, 0, 0, 0, 0]
+    qp[4, 6:13] = [0.0, -0.45, 0.0, 1, 0, 0, 0]
+    qp[4, 13:20] = [0.013, -0.442, 0.06, 1, 0, 0, 0]
+    qp[5, 6:13] = [tcp[5, 0] + 0.045, tcp[5, 1], 0.0, 1, 0, 0, 0]
+    qp[6, 6:13] = [tcp[6, 0] + 0.045, tcp[6, 1], 0.0, 1, 0, 0, 0]
+    qp[6, 13:20] = [tcp[6, 0] + 0.09, tcp[6, 1] + 0.01, 0.0, 1, 0, 0, 0]
+    ob.set_state(qp, qv)
+    _push_state_to_gpu(venv, qp, qv, tm)
+    act = tcp[:, :2].copy()
+    moved = False
+    for t in range(12):
+        act[5:, 0] += 0.01
+        venv.step(torch.from_numpy(act))
+        r = ob.step(act)
+        g = venv.get_state().cpu().numpy()
+        q2, v2, _ = ob.get_state()
+        for b in range(2):
+            np.testing.assert_allclose(g[17 + 13 * b: 24 + 13 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-10, err_msg=f"block {b} pose, step {t}")
+            np.testing.assert_allclose(g[24 + 13 * b: 30 + 13 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-8, err_msg=f"block {b} velocity, step {t}")
+        np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-10)
+        assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), t
+        np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-10)
+    assert q2[5, 6] - qp[5, 6] > 0.03 and q2[6, 13] - qp[6, 13] > 0.01  # the pushes really moved the blocks
+
+
+def test_planar_push_parity_with_oracle(oracle_mod):
+    """Seeded episodes with a noisy push-towards-the-block policy: device-side rejection-sampled resets + 150 settle
+    steps, pushes, step-limit truncation and auto-resets. Contact-rich rigid-body motion amplifies rounding noise in a
+    few envs (a block balancing on the arm, edge-on-edge impacts); the oracle measures its own conditioning: a second
+    oracle whose reset is perturbed by 1e-13 m marks the envs where it disagrees with itself by > 1e-10, and the GPU
+    must agree with the oracle to 1e-8 everywhere else (flags and contact counts exactly)."""
+    import ctypes as C
+
+    import mujoco_sim_amd as m
+
+    N, T, LIMIT = 128, 66, 30
+    knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2025, max_episode_steps=LIMIT)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
+    venv.reset()
+    o = ob.reset()
+    try:
+        knob.value = 1e-13
+        o2 = ob2.reset()
+    finally:
+        knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    g = _gpu_result(venv)
+    np.testing.assert_allclose(g["obs"][~sens], o["obs"][~sens], rtol=0, atol=1e-8)
+    assert np.array_equal(g["ncon"][~sens], o["ncon"][~sens])
+    rs = np.random.RandomState(5)
+    n_last = n_pushed = 0
+    for t in range(T):
+        tcp, blk = o["obs"][:, :2], o["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        try:
+            knob.value = 1e-13
+            o2 = ob2.step(a)
+        finally:
+            knob.value = 0.0
+        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        g = _gpu_result(venv)
+        ok = ~sens
+        np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(g["reward"][ok], o["reward"][ok], rtol=0, atol=1e-8, err_msg=f"reward step {t}")
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
+        n_last += int((o["step_type"] == 2).sum())
+        n_pushed += int((o["ncon"] > 8).sum())
+    assert sens.mean() < 0.15, sens.mean()   # the ill-conditioned envs are a small minority
+    assert n_last >= 2 * N - 4               # two step-limit truncations per env: device-side resets were exercised
+    assert n_pushed > 100                    # EEF-block / block-block contacts on top of the 8 floor corners
+
+
+def test_planar_push_env_id(oracle_mod):
+    import mujoco_sim_amd as m
+
+    env = m.make("mujoco_sim/robot_planar_push_state-v0", n_objects=1, max_control_steps_per_episode=5)
+    env.seed(3)
+    obs, _ = env.reset()
+    assert list(obs.keys()) == ["ur5e/tcp_position", "target_position", "block_positions"] and obs["block_positions"].shape == (2,)
+    assert env.action_space.shape == (2,)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, 3, n_objects=1, max_episode_steps=5)
+    o = ob.reset()
+    np.testing.assert_allclose(obs["block_positions"], o["obs"][0, 5:7], atol=1e-8)
+    for t in range(5):
+        a = obs["ur5e/tcp_position"][:2] + 0.01
+        obs, reward, term, trunc, info = env.step(a)
+        o = ob.step(a[None])
+        assert abs(reward - o["reward"][0]) < 1e-8 and (trunc == (t == 4)) and not term
+    env.close()

@@ -494,6 +494,7 @@ def emit_variant(prefix, links, uncomp, body_com_local, what):
     lm, cm = emit(out_M)
     nb, nm = sum(cb.values()), sum(cm.values())
     invw, meaninertia, tran, rot = model_constants(M, links, body_com_local)
+    _, _, w3tran, w3rot = model_constants(M, links, body_ipos[NJ])  # the wrist_3 body itself, at its own COM
     up = prefix.upper()
     text = f"""
 // ---- variant "{prefix}": {what}
@@ -501,6 +502,7 @@ def emit_variant(prefix, links, uncomp, body_com_local, what):
 constexpr double {up}_DOF_INVWEIGHT0[6] = {{{", ".join(repr(float(x)) for x in invw)}}};
 constexpr double {up}_MEANINERTIA = {meaninertia!r};
 constexpr double {up}_EEF_BODY_INVWEIGHT0[2] = {{{tran!r}, {rot!r}}};  // translation, rotation: contact rows of the EEF body
+constexpr double {up}_WRIST3_BODY_INVWEIGHT0[2] = {{{w3tran!r}, {w3rot!r}}};  // contact rows of geoms on the wrist_3 body
 
 MJS_DEV void {prefix}_M_gen(const double* c, const double* s, double* M) {{  // {nm} ops before FMA fusion
 """ + "\n".join(lm) + f"""
