@@ -266,6 +266,44 @@ MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collisi
 }
 MJS_DEV V3 eef_tcp_position(const rr::Chain& c) { return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_TCP_Z, c.R[6].cy); }
 
+// ---- hot-path detection: static slots only (no indexed memory)
+struct FloorSlots {
+  bool on[4];       // slot k = k-th corner at or below the floor in mjc_PlaneBox order (active when dist < 0)
+  double dist[4];
+  V3 r[4];          // contact point - body origin
+};
+#pragma clang fp contract(off)
+MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
+  FloorSlots fs;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
+  int rank = 0;  // number of detected corners so far
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+    const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
+                         g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
+    const double dist = corner.z;
+    const bool hit = !(dist > 0.0) && rank < 4;
+    const V3 r = v3(corner.x - origin.x, corner.y - origin.y, (corner.z - dist * 0.5) - origin.z);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (hit && rank == k) { fs.on[k] = dist < 0.0; fs.dist[k] = dist; fs.r[k] = r; }
+    rank += hit ? 1 : 0;
+  }
+  return fs;
+}
+MJS_DEV bool convex_penetrating(const Geom& g1, const Geom& g2) {  // an ACTIVE contact (dist < 0) between two convex geoms?
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return false;
+  double depth;
+  V3 n, pos;
+  if (!mpr_penetration(g1, g2, depth, n, pos)) return false;
+  return -depth < 0.0;
+}
+#pragma clang fp contract(on)
+
 // all contacts of the scene in MuJoCo's pair order (geom ids: floor, arm capsules, EEF cylinder, blocks): floor-block i
 // (<= 4 each), EEF-block i, block-block. Arm capsules vs floor and EEF vs floor are only COUNTED (D-8): `extra`.
 MJS_DEV int detect_contacts(const rr::Chain& ch, const World& s, const M3* Rb, int nb, Contact* con, int& extra, bool& eef_floor_active) {
@@ -350,204 +388,12 @@ MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
   }
 }
 
-struct Rows {
-  int n;
-  double J[MAXROW][NV], D[MAXROW], aref[MAXROW];
-};
-
-// mj_instantiateLimit + mj_instantiateContact (pyramidal, condim 4) + mj_makeImpedance + mj_referenceConstraint
-MJS_DEV void build_rows(const World& s, const rr::Chain& ch, const M3* Rb, int nb, const Contact* con, int ncon, const double* qvel, Rows& r) {
-  const int nv = NJ + 6 * nb;
-  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
-  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
-  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
-  r.n = 0;
-  for (int j = 0; j < NJ; j++)
-    for (int side = 0; side < 2; side++) {
-      const double sgn = side == 0 ? 1.0 : -1.0;
-      const double dist = side == 0 ? s.q[j] - MJS_UR_JNT_RANGE[j][0] : MJS_UR_JNT_RANGE[j][1] - s.q[j];
-      if (dist < 0.0) {
-        double* J = r.J[r.n];
-        for (int k = 0; k < nv; k++) J[k] = 0;
-        J[j] = sgn;
-        const double imp = impedance_default(dist);
-        r.D[r.n] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
-        r.aref[r.n] = -B * (sgn * s.v[j]) - K * imp * dist;
-        r.n++;
-      }
-    }
-  for (int c = 0; c < ncon; c++) {
-    const Contact& k = con[c];
-    if (!(k.dist < 0.0)) continue;  // detected, not active
-    V3 t1, t2;
-    {  // mju_makeFrame
-      V3 y = (k.n.y > -0.5 && k.n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
-      y = madd(y, -dot(k.n, y), k.n);
-      t1 = (1.0 / sqrt(dot(y, y))) * y;
-      t2 = cross(k.n, t1);
-    }
-    // contact-frame Jacobian (jac2 - jac1): rows normal, t1, t2 (translational) and torsion (rotational about the normal)
-    double Jc[4][NV];
-    for (int rr_ = 0; rr_ < 4; rr_++)
-      for (int d = 0; d < nv; d++) Jc[rr_][d] = 0;
-    for (int side = 0; side < 2; side++) {
-      const int body = side == 0 ? k.ba : k.bb;
-      const double sg = side == 0 ? -1.0 : 1.0;
-      if (body == 1) {
-        for (int j = 0; j < NJ; j++) {
-          const V3 ax = rr::joint_axis(ch, j), lin = cross(ax, k.pos - ch.p[j + 1]);
-          Jc[0][j] += sg * dot(k.n, lin); Jc[1][j] += sg * dot(t1, lin); Jc[2][j] += sg * dot(t2, lin); Jc[3][j] += sg * dot(k.n, ax);
-        }
-      } else if (body >= 2) {
-        const int b = body - 2, o = NJ + 6 * b;
-        const M3& R = Rb[b];
-        const V3 rvec = k.pos - s.b[b].p;
-        const V3 e[3] = {v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)}, axs[3] = {R.cx, R.cy, R.cz};
-        for (int d = 0; d < 3; d++) {
-          Jc[0][o + d] += sg * dot(k.n, e[d]); Jc[1][o + d] += sg * dot(t1, e[d]); Jc[2][o + d] += sg * dot(t2, e[d]);
-          const V3 lin = cross(axs[d], rvec);
-          Jc[0][o + 3 + d] += sg * dot(k.n, lin); Jc[1][o + 3 + d] += sg * dot(t1, lin); Jc[2][o + 3 + d] += sg * dot(t2, lin);
-          Jc[3][o + 3 + d] += sg * dot(k.n, axs[d]);
-        }
-      }
-    }
-    // friction: element-wise max of the pair; every pair of this scene involves a block (condim 4)
-    const bool blocks_only = k.ba >= 2 && k.bb >= 2;
-    const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
-    const double tran = k.tran;
-    const double imp = impedance_default(k.dist);
-    const double R0 = fmax(MJS_MINVAL, (1 - imp) * (tran + fri[0] * fri[0] * tran) / imp);
-    const double Dc = 1 / (2 * fri[0] * fri[0] * R0);
-    for (int kk = 0; kk < 3; kk++)
-      for (int sgn = 1; sgn >= -1; sgn -= 2) {
-        double* J = r.J[r.n];
-        double vel = 0;
-        for (int d = 0; d < nv; d++) { J[d] = Jc[0][d] + sgn * fri[kk] * Jc[1 + kk][d]; vel += J[d] * qvel[d]; }
-        r.D[r.n] = Dc;
-        r.aref[r.n] = -B * vel - K * imp * k.dist;
-        r.n++;
-      }
-  }
-}
-
-// mj_solPrimal (Newton), dense, cold start at qacc_smooth; returns qfrc_constraint = J^T force
-__device__ __noinline__ void solve_rows(int nv, const double (*M)[NV], const double* qfrc_smooth, const Rows& r, double meaninertia, double* qfrc_constraint) {
-  double H[NV][NV], a[NV], a_s[NV], Ma[NV], grad[NV], search[NV], Mv[NV], jar[MAXROW], jv[MAXROW], force[MAXROW];
-  bool active[MAXROW];
-  for (int i = 0; i < nv; i++) {
-    for (int j = 0; j <= i; j++) H[i][j] = M[i][j];
-    a_s[i] = qfrc_smooth[i];
-  }
-  chol_n(nv, H);
-  chol_solve_n(nv, H, a_s);
-  for (int i = 0; i < nv; i++) a[i] = a_s[i];
-  for (int i = 0; i < nv; i++) {
-    double m = 0;
-    for (int k = 0; k < nv; k++) m += M[i][k] * a[k];
-    Ma[i] = m;
-  }
-  for (int rw = 0; rw < r.n; rw++) {
-    double x = -r.aref[rw];
-    for (int k = 0; k < nv; k++) x += r.J[rw][k] * a[k];
-    jar[rw] = x;
-  }
-  auto update = [&]() {
-    double cost = 0;
-    for (int rw = 0; rw < r.n; rw++) {
-      const bool act = jar[rw] < 0;
-      active[rw] = act;
-      force[rw] = act ? -r.D[rw] * jar[rw] : 0.0;
-      if (act) cost += 0.5 * r.D[rw] * jar[rw] * jar[rw];
-    }
-    double gauss = 0;
-    for (int i = 0; i < nv; i++) gauss += (Ma[i] - qfrc_smooth[i]) * (a[i] - a_s[i]);
-    return cost + 0.5 * gauss;
-  };
-  double cost = update();
-  const double scale = 1 / (meaninertia * nv);
-  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
-    for (int i = 0; i < nv; i++) {
-      double g = Ma[i] - qfrc_smooth[i];
-      for (int rw = 0; rw < r.n; rw++) g -= r.J[rw][i] * force[rw];
-      grad[i] = g;
-      search[i] = -g;
-      for (int j = 0; j <= i; j++) H[i][j] = M[i][j];
-    }
-    for (int rw = 0; rw < r.n; rw++) {
-      if (!active[rw]) continue;
-      for (int i = 0; i < nv; i++) {
-        const double ji = r.J[rw][i] * r.D[rw];
-        if (ji == 0.0) continue;
-        for (int j = 0; j <= i; j++) H[i][j] += ji * r.J[rw][j];
-      }
-    }
-    if (!chol_n(nv, H)) break;
-    chol_solve_n(nv, H, search);
-    double g1 = 0, g2 = 0, snorm = 0;
-    for (int i = 0; i < nv; i++) {
-      double m = 0;
-      for (int k = 0; k < nv; k++) m += M[i][k] * search[k];
-      Mv[i] = m;
-    }
-    for (int i = 0; i < nv; i++) { g1 += search[i] * (Ma[i] - qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
-    if (sqrt(snorm) < MJS_MINVAL) break;
-    for (int rw = 0; rw < r.n; rw++) {
-      double x = 0;
-      for (int k = 0; k < nv; k++) x += r.J[rw][k] * search[k];
-      jv[rw] = x;
-    }
-    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
-    double alpha = 0, lo = 0, hi = INFINITY;
-    for (int it = 0; it < 50; it++) {
-      double d1 = g1 + alpha * g2, d2 = g2;
-      for (int rw = 0; rw < r.n; rw++) {
-        const double x = jar[rw] + alpha * jv[rw];
-        if (x < 0) { d1 += r.D[rw] * x * jv[rw]; d2 += r.D[rw] * jv[rw] * jv[rw]; }
-      }
-      if (fabs(d1) < gtol) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
-      if (d2 <= 0) break;
-      double next = alpha + (-d1 / d2);
-      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
-      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
-      alpha = next;
-    }
-    if (alpha == 0) break;
-    for (int i = 0; i < nv; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
-    for (int rw = 0; rw < r.n; rw++) jar[rw] += alpha * jv[rw];
-    const double oldcost = cost;
-    cost = update();
-    double gn = 0;
-    for (int i = 0; i < nv; i++) {
-      double g = Ma[i] - qfrc_smooth[i];
-      for (int rw = 0; rw < r.n; rw++) g -= r.J[rw][i] * force[rw];
-      gn += g * g;
-    }
-    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
-  }
-  for (int i = 0; i < nv; i++) {
-    double f = 0;
-    for (int rw = 0; rw < r.n; rw++) f += r.J[rw][i] * force[rw];
-    qfrc_constraint[i] = f;
-  }
-}
-
-struct StepInfo {
-  bool bad, rows_active, unsupported;
-  int ncon;
-};
-
 // Decoupled case (the common one): no active arm-block or block-block contact and no joint limit. The constraint
 // problem is then separable: each block with its floor contacts is an independent 6-dof problem with at most 4
 // corner contacts x 6 pyramid edges. Static slots, everything unrolled (no indexed memory). The floor frame is
 // constant (n = +z, t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)), so a row is (F, (axis_d x r) . F) for the three
 // frame vectors F and (0, axis_d . n) for the torsional row. `Mb`: the block's 6x6 mass matrix (lower triangle used),
 // `f`: qfrc_smooth of the block in, qfrc_smooth + qfrc_constraint out.
-struct FloorSlots {
-  bool on[4];
-  double dist[4];
-  V3 r[4];  // contact point - body origin
-};
 __device__ __noinline__ void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
                                                double* f) {
   const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};  // max(block, floor) per component
@@ -755,10 +601,203 @@ MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangl
   M[4][0] = M[0][4] = cy.x; M[4][1] = M[1][4] = cy.y; M[4][2] = M[2][4] = cy.z;
 }
 
-// The coupled case (an arm-block or block-block contact is active, or a joint is beyond its range): dense Newton over
-// all nv dofs with the rows in indexed per-lane arrays. Returns qfrc_smooth + qfrc_constraint in qacc.
-__device__ __noinline__ void coupled_forces(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb, double* qacc) {
-  const int nv = NJ + 6 * nb;
+struct StepInfo {
+  bool bad, rows_active, unsupported;
+  int ncon;
+#ifdef MJS_STAMPS
+  unsigned long long cyc[6];
+#endif
+};
+#ifdef MJS_STAMPS
+#define PP_TIC(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_ACC(info, k, t0) do { unsigned long long t1_; PP_TIC(t1_); (info).cyc[k] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define PP_TIC(t) do { } while (0)
+#define PP_ACC(info, k, t0) do { } while (0)
+#endif
+
+// The coupled case (an arm-block or block-block contact is active, or a joint is beyond its range): the constraint
+// problem couples all nv = 6 + 6 n dofs. It is solved by the WHOLE WAVEFRONT for one env at a time: the env's lane
+// publishes M, qfrc_smooth and its rows (<= 78 x 18) in LDS, then the 64 lanes share the dense Newton iteration of
+// mj_solPrimal: rows are dealt to lanes (residuals, forces, line-search sums with wave reductions), the Hessian
+// entries are dealt to lanes, the 18 x 18 Cholesky and the triangular solves run column by column in LDS.
+// The function must be called by all 64 lanes of the workgroup (uniform control flow).
+constexpr int LDP = NV + 1;  // padded leading dimension in LDS
+// The cooperating lanes are ONE wavefront (several wavefronts share a workgroup only to share the instruction
+// cache): LDS operations of a wavefront execute in order, so a release/acquire fence at wavefront scope is the
+// whole synchronisation.
+#define MJS_WAVE_SYNC()                                     \
+  do {                                                      \
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
+    __builtin_amdgcn_wave_barrier();                        \
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+  } while (0)
+struct CoopLds {
+  double J[MAXROW][LDP], D[MAXROW], aref[MAXROW], jar[MAXROW], jv[MAXROW], force[MAXROW];
+  double M[NV][LDP], H[NV][LDP];
+  double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
+  int active[MAXROW];
+  int nrow;
+  // problem description written by the owner lane; the rows are then built by all lanes
+  int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
+  double c_dist[MAXCON], c_tran[MAXCON], c_pos[MAXCON][3], c_n[MAXCON][3];
+  double ax[NJ][3], an[NJ][3];     // joint axes and anchors (world)
+  double bp[NB][3], bR[NB][9];     // block origins and rotation columns (cx, cy, cz)
+  double qvel[NV], q[NJ];
+};
+MJS_DEV double wave_sum(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+  return x;
+}
+// in-place Cholesky of sh.H (lower) and solve H x = b for x in `vec` (LDS), all lanes
+MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
+  bool ok = true;
+  for (int j = 0; j < nv; j++) {
+    const double d = sh.H[j][j];
+    if (d < MJS_MINVAL) ok = false;  // uniform: every lane reads the same value
+    const double sd = sqrt(fmax(d, MJS_MINVAL));
+    MJS_WAVE_SYNC();
+    if (lane == 0) sh.H[j][j] = sd;
+    if (lane > j && lane < nv) sh.H[lane][j] = sh.H[lane][j] / sd;
+    MJS_WAVE_SYNC();
+    // trailing update: pairs (i, k), j < k <= i < nv
+    const int m = nv - j - 1;
+    for (int e = lane; e < m * (m + 1) / 2; e += 64) {
+      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      while (i * (i + 1) / 2 > e) i--;
+      const int k = e - i * (i + 1) / 2;
+      sh.H[j + 1 + i][j + 1 + k] -= sh.H[j + 1 + i][j] * sh.H[j + 1 + k][j];
+    }
+    MJS_WAVE_SYNC();
+  }
+  for (int k = 0; k < nv; k++) {  // forward substitution, column oriented
+    if (lane == 0) vec[k] = vec[k] / sh.H[k][k];
+    MJS_WAVE_SYNC();
+    if (lane > k && lane < nv) vec[lane] -= sh.H[lane][k] * vec[k];
+    MJS_WAVE_SYNC();
+  }
+  for (int k = nv - 1; k >= 0; k--) {  // backward substitution with L^T
+    if (lane == 0) vec[k] = vec[k] / sh.H[k][k];
+    MJS_WAVE_SYNC();
+    if (lane < k) vec[lane] -= sh.H[k][lane] * vec[k];
+    MJS_WAVE_SYNC();
+  }
+  return ok;
+}
+// cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
+MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
+  const int nrow = sh.nrow;
+  // qacc_smooth = M^-1 qfrc_smooth
+  for (int e = lane; e < nv * nv; e += 64) sh.H[e / nv][e % nv] = sh.M[e / nv][e % nv];
+  if (lane < nv) sh.a_s[lane] = sh.qs[lane];
+  MJS_WAVE_SYNC();
+  coop_chol_solve(sh, nv, sh.a_s, lane);
+  if (lane < nv) sh.a[lane] = sh.a_s[lane];
+  MJS_WAVE_SYNC();
+  if (lane < nv) {
+    double m = 0;
+    for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.a[k];
+    sh.Ma[lane] = m;
+  }
+  for (int r = lane; r < nrow; r += 64) {
+    double x = -sh.aref[r];
+    for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.a[k];
+    sh.jar[r] = x;
+  }
+  MJS_WAVE_SYNC();
+  auto update = [&]() {  // forces / active set from jar; returns the total cost (all lanes)
+    double cost = 0;
+    for (int r = lane; r < nrow; r += 64) {
+      const double x = sh.jar[r];
+      const bool act = x < 0;
+      sh.active[r] = act;
+      sh.force[r] = act ? -sh.D[r] * x : 0.0;
+      if (act) cost += 0.5 * sh.D[r] * x * x;
+    }
+    if (lane < nv) cost += 0.5 * (sh.Ma[lane] - sh.qs[lane]) * (sh.a[lane] - sh.a_s[lane]);
+    MJS_WAVE_SYNC();
+    return wave_sum(cost);
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv);
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    // gradient -> search = -grad ; Hessian = M + J^T diag(D active) J
+    if (lane < nv) {
+      double g = sh.Ma[lane] - sh.qs[lane];
+      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
+      sh.search[lane] = -g;
+    }
+    for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
+      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+      while ((i + 1) * (i + 2) / 2 <= e) i++;
+      while (i * (i + 1) / 2 > e) i--;
+      const int j = e - i * (i + 1) / 2;
+      double h = sh.M[i][j];
+      for (int r = 0; r < nrow; r++)
+        if (sh.active[r]) h += sh.J[r][i] * sh.D[r] * sh.J[r][j];
+      sh.H[i][j] = h;
+    }
+    MJS_WAVE_SYNC();
+    if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
+    if (lane < nv) {
+      double m = 0;
+      for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
+      sh.Mv[lane] = m;
+    }
+    for (int r = lane; r < nrow; r += 64) {
+      double x = 0;
+      for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.search[k];
+      sh.jv[r] = x;
+    }
+    MJS_WAVE_SYNC();
+    double g1 = 0, g2 = 0, sn2 = 0;
+    if (lane < nv) { g1 = sh.search[lane] * (sh.Ma[lane] - sh.qs[lane]); g2 = sh.search[lane] * sh.Mv[lane]; sn2 = sh.search[lane] * sh.search[lane]; }
+    g1 = wave_sum(g1); g2 = wave_sum(g2); sn2 = wave_sum(sn2);
+    if (sqrt(sn2) < MJS_MINVAL) break;
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(sn2) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+    for (int it = 0; it < 50; it++) {  // exact 1-D Newton; every lane follows the same alpha sequence
+      double p1 = 0, p2 = 0;
+      for (int r = lane; r < nrow; r += 64) {
+        const double x = sh.jar[r] + alpha * sh.jv[r];
+        if (x < 0) { p1 += sh.D[r] * x * sh.jv[r]; p2 += sh.D[r] * sh.jv[r] * sh.jv[r]; }
+      }
+      const double d1 = g1 + alpha * g2 + wave_sum(p1), d2 = g2 + wave_sum(p2);
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+    if (lane < nv) { sh.a[lane] += alpha * sh.search[lane]; sh.Ma[lane] += alpha * sh.Mv[lane]; }
+    for (int r = lane; r < nrow; r += 64) sh.jar[r] += alpha * sh.jv[r];
+    MJS_WAVE_SYNC();
+    const double oldcost = cost;
+    cost = update();
+    double gn = 0;
+    if (lane < nv) {
+      double g = sh.Ma[lane] - sh.qs[lane];
+      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
+      gn = g * g;
+    }
+    gn = wave_sum(gn);
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  MJS_WAVE_SYNC();
+  if (lane < nv) {
+    double f = 0;
+    for (int r = 0; r < nrow; r++) f += sh.J[r][lane] * sh.force[r];
+    sh.fc[lane] = f;
+  }
+  MJS_WAVE_SYNC();
+}
+// the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
+__device__ __noinline__ void publish_problem(CoopLds& sh, const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb) {
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
   M3 Rb[NB];
@@ -772,40 +811,160 @@ __device__ __noinline__ void coupled_forces(const World& s, const double* cs, co
   int extra;
   bool eef_floor;
   const int ncon = detect_contacts(ch, s, Rb, nb, con, extra, eef_floor);
-  double M[NV][NV], qs[NV], qvel[NV];
-  for (int i = 0; i < nv; i++)
-    for (int j = 0; j < nv; j++) M[i][j] = 0;
-  for (int i = 0; i < NJ; i++) {
-    for (int j = 0; j <= i; j++) M[i][j] = M[j][i] = Marm[i * (i + 1) / 2 + j];
-    M[i][i] += MJS_UR_ARMATURE;
-    qs[i] = qs_arm[i];
-    qvel[i] = s.v[i];
+  sh.ncon = ncon;
+  for (int c = 0; c < ncon; c++) {
+    sh.c_ba[c] = con[c].ba; sh.c_bb[c] = con[c].bb; sh.c_act[c] = con[c].dist < 0.0;
+    sh.c_dist[c] = con[c].dist; sh.c_tran[c] = con[c].tran;
+    sh.c_pos[c][0] = con[c].pos.x; sh.c_pos[c][1] = con[c].pos.y; sh.c_pos[c][2] = con[c].pos.z;
+    sh.c_n[c][0] = con[c].n.x; sh.c_n[c][1] = con[c].n.y; sh.c_n[c][2] = con[c].n.z;
+  }
+  for (int j = 0; j < NJ; j++) {
+    const V3 a = rr::joint_axis(ch, j), p = ch.p[j + 1];
+    sh.ax[j][0] = a.x; sh.ax[j][1] = a.y; sh.ax[j][2] = a.z;
+    sh.an[j][0] = p.x; sh.an[j][1] = p.y; sh.an[j][2] = p.z;
+    sh.q[j] = s.q[j];
+    sh.qvel[j] = s.v[j];
+    sh.qs[j] = qs_arm[j];
+    sh.lim_act[2 * j] = s.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.0;
+    sh.lim_act[2 * j + 1] = MJS_UR_JNT_RANGE[j][1] - s.q[j] < 0.0;
+    for (int k = 0; k <= j; k++) sh.M[j][k] = sh.M[k][j] = Marm[j * (j + 1) / 2 + k];
+    sh.M[j][j] += MJS_UR_ARMATURE;
   }
   for (int b = 0; b < nb; b++) {
     const int o = NJ + 6 * b;
-    block_mass_matrix(Rb[b], M, o);
-    block_smooth_force(Rb[b], s.b[b].w, qs + o);
-    qvel[o] = s.b[b].v.x; qvel[o + 1] = s.b[b].v.y; qvel[o + 2] = s.b[b].v.z;
-    qvel[o + 3] = s.b[b].w.x; qvel[o + 4] = s.b[b].w.y; qvel[o + 5] = s.b[b].w.z;
+    double Mb[6][6], f[6];
+    block_mass_matrix6(Rb[b], Mb);
+    block_smooth_force(Rb[b], s.b[b].w, f);
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j < 6; j++) sh.M[o + i][o + j] = Mb[i][j];
+      sh.qs[o + i] = f[i];
+    }
+    sh.qvel[o] = s.b[b].v.x; sh.qvel[o + 1] = s.b[b].v.y; sh.qvel[o + 2] = s.b[b].v.z;
+    sh.qvel[o + 3] = s.b[b].w.x; sh.qvel[o + 4] = s.b[b].w.y; sh.qvel[o + 5] = s.b[b].w.z;
+    sh.bp[b][0] = s.b[b].p.x; sh.bp[b][1] = s.b[b].p.y; sh.bp[b][2] = s.b[b].p.z;
+    sh.bR[b][0] = Rb[b].cx.x; sh.bR[b][1] = Rb[b].cx.y; sh.bR[b][2] = Rb[b].cx.z;
+    sh.bR[b][3] = Rb[b].cy.x; sh.bR[b][4] = Rb[b].cy.y; sh.bR[b][5] = Rb[b].cy.z;
+    sh.bR[b][6] = Rb[b].cz.x; sh.bR[b][7] = Rb[b].cz.y; sh.bR[b][8] = Rb[b].cz.z;
   }
-  for (int i = 0; i < nv; i++) qacc[i] = qs[i];
-  Rows rows;
-  build_rows(s, ch, Rb, nb, con, ncon, qvel, rows);
-  if (rows.n > 0) {
-    double fc[NV];
-    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
-    solve_rows(nv, M, qs, rows, meaninertia, fc);
-    for (int i = 0; i < nv; i++) qacc[i] += fc[i];
+}
+// one frame row (F . translational or rotational Jacobian of (body b - body a)) of a published contact, all nv columns
+MJS_DEV void coop_frame_row(const CoopLds& sh, int c, V3 F, bool rotational, int nv, double* out) {
+  for (int d = 0; d < nv; d++) out[d] = 0;
+  const V3 pos = v3(sh.c_pos[c][0], sh.c_pos[c][1], sh.c_pos[c][2]);
+  for (int side = 0; side < 2; side++) {
+    const int body = side == 0 ? sh.c_ba[c] : sh.c_bb[c];
+    const double sg = side == 0 ? -1.0 : 1.0;
+    if (body == 1) {
+      for (int j = 0; j < NJ; j++) {
+        const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
+        const V3 col = rotational ? ax : cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
+        out[j] += sg * dot(F, col);
+      }
+    } else if (body >= 2) {
+      const int b = body - 2, o = NJ + 6 * b;
+      const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
+      for (int d = 0; d < 3; d++) {
+        const V3 axs = v3(sh.bR[b][3 * d], sh.bR[b][3 * d + 1], sh.bR[b][3 * d + 2]);
+        if (!rotational) out[o + d] += sg * (d == 0 ? F.x : d == 1 ? F.y : F.z);
+        out[o + 3 + d] += sg * dot(F, rotational ? axs : cross(axs, rvec));
+      }
+    }
+  }
+}
+// all lanes: limit rows + pyramid rows (6 per active contact, condim 4) in the oracle's order
+MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
+  const int nv = NJ + 6 * nb;
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  int nlim = 0;
+  for (int k = 0; k < 2 * NJ; k++) nlim += sh.lim_act[k];
+  if (lane < 2 * NJ && sh.lim_act[lane]) {
+    int row = 0;
+    for (int k = 0; k < lane; k++) row += sh.lim_act[k];
+    const int j = lane >> 1;
+    const double sgn = (lane & 1) ? -1.0 : 1.0;
+    const double dist = (lane & 1) ? MJS_UR_JNT_RANGE[j][1] - sh.q[j] : sh.q[j] - MJS_UR_JNT_RANGE[j][0];
+    for (int d = 0; d < nv; d++) sh.J[row][d] = d == j ? sgn : 0.0;
+    const double imp = impedance_default(dist);
+    sh.D[row] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
+    sh.aref[row] = -B * (sgn * sh.qvel[j]) - K * imp * dist;
+  }
+  int nact = 0;
+  for (int c = 0; c < sh.ncon; c++) nact += sh.c_act[c];
+  for (int t = lane; t < 6 * sh.ncon; t += 64) {  // task = (contact, pyramid edge)
+    const int c = t / 6, e = t - 6 * c;
+    if (!sh.c_act[c]) continue;
+    int rank = 0;
+    for (int k = 0; k < c; k++) rank += sh.c_act[k];
+    const int row = nlim + 6 * rank + e;
+    const V3 n = v3(sh.c_n[c][0], sh.c_n[c][1], sh.c_n[c][2]);
+    V3 t1, t2;
+    {  // mju_makeFrame
+      V3 y = (n.y > -0.5 && n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
+      y = madd(y, -dot(n, y), n);
+      t1 = (1.0 / sqrt(dot(y, y))) * y;
+      t2 = cross(n, t1);
+    }
+    const int kk = e >> 1;  // 0: t1, 1: t2, 2: torsion
+    const double sgn = (e & 1) ? -1.0 : 1.0;
+    const bool blocks_only = sh.c_ba[c] >= 2 && sh.c_bb[c] >= 2;
+    const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
+    double Jn[NV], Jk[NV];
+    coop_frame_row(sh, c, n, false, nv, Jn);
+    coop_frame_row(sh, c, kk == 0 ? t1 : kk == 1 ? t2 : n, kk == 2, nv, Jk);
+    double vel = 0;
+    for (int d = 0; d < nv; d++) {
+      const double j = Jn[d] + sgn * fri[kk] * Jk[d];
+      sh.J[row][d] = j;
+      vel += j * sh.qvel[d];
+    }
+    const double imp = impedance_default(sh.c_dist[c]);
+    const double R0 = fmax(MJS_MINVAL, (1 - imp) * (sh.c_tran[c] + fri[0] * fri[0] * sh.c_tran[c]) / imp);
+    sh.D[row] = 1 / (2 * fri[0] * fri[0] * R0);
+    sh.aref[row] = -B * vel - K * imp * sh.c_dist[c];
+  }
+  if (lane == 0) sh.nrow = nlim + 6 * nact;
+}
+MJS_DEV void coop_coupled(CoopLds& sh, bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info) {
+  const int lane = threadIdx.x & 63, nv = NJ + 6 * nb;
+  const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+  unsigned long long todo = __ballot(need);
+  while (todo) {  // wave-uniform loop over the lanes whose env needs the coupled solve
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    for (int e = lane; e < nv * nv; e += 64) sh.M[e / nv][e % nv] = 0;  // all lanes: clear M, the owner fills its diagonal blocks
+    MJS_WAVE_SYNC();
+    unsigned long long tp = 0;
+    PP_TIC(tp);
+    if (lane == owner) publish_problem(sh, s, cs, sn, Marm, qacc, nb);
+    MJS_WAVE_SYNC();
+    PP_ACC(info, 5, tp);
+    coop_build_rows(sh, nb, lane);
+    MJS_WAVE_SYNC();
+    if (sh.nrow > 0) coop_newton(sh, nv, meaninertia, lane);
+    if (lane == owner) {
+      for (int i = 0; i < nv; i++) qacc[i] = sh.qs[i] + (sh.nrow > 0 ? sh.fc[i] : 0.0);
+    }
+    MJS_WAVE_SYNC();
   }
 }
 
 // One Physics.step() (mj_step2 of the current state; the next mj_step1 is the start of the next call): smooth
 // dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
-__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info) {
+// `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
+// neighbours (all 64 lanes of the workgroup must call this function together).
+__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info, bool live, CoopLds& sh) {
   const int nv = NJ + 6 * nb;
+  double Marm[21], qacc[NV];
+  int clamped = 0;
+  bool coupled = false;
+  M3 Rb[NB];
+  unsigned long long tt = 0;
+  PP_TIC(tt);
+  if (live) {
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
-  M3 Rb[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     double qn[4];
@@ -814,29 +973,36 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
     Rb[b] = quat_to_m3(qn);
   }
-  Contact con[MAXCON];
-  int extra;
-  bool eef_floor;
-  const int ncon = detect_contacts(ch, s, Rb, nb, con, extra, eef_floor);
-  info.unsupported = info.unsupported || eef_floor;
+  // contacts (static slots): floor corners per block; is any arm-block / block-block pair penetrating?
+  Geom bg[NB];
+  FloorSlots fs[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    bg[b] = block_geom(s.b[b], Rb[b]);
+    fs[b] = floor_slots(bg[b], s.b[b].p);
+  }
+  {
+    const Geom eg = eef_geom(ch), wg = wrist3_proxy_geom(ch);
+    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+    info.unsupported = info.unsupported || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);  // EEF cylinder below the floor (D-8)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if (b < nb) coupled = coupled || convex_penetrating(wg, bg[b]) || convex_penetrating(eg, bg[b]);
+    if (nb > 1) coupled = coupled || convex_penetrating(bg[0], bg[1]);
+  }
+  PP_ACC(info, 0, tt);
   // arm smooth dynamics
-  double Marm[21], bias[NJ], fact[NJ], qacc[NV];
+  double bias[NJ], fact[NJ];
   ur5e_pp_M_gen(cs, sn, Marm);
   ur5e_pp_bias_gen(cs, sn, s.v, bias);
-  const int clamped = rr::actuator_forces(s.q, s.v, ctrl, fact);
+  clamped = rr::actuator_forces(s.q, s.v, ctrl, fact);
 #pragma unroll
   for (int i = 0; i < NJ; i++) qacc[i] = fact[i] - bias[i];
+  PP_ACC(info, 1, tt);
   // which constraint problem?
-  bool coupled = false, any_floor = false;
 #pragma unroll
   for (int j = 0; j < NJ; j++) coupled = coupled || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
-  for (int c = 0; c < ncon; c++) {
-    const bool active = con[c].dist < 0.0;
-    coupled = coupled || (active && con[c].ba != 0);
-    any_floor = any_floor || (active && con[c].ba == 0);
-  }
   if (coupled) {
-    coupled_forces(s, cs, sn, Marm, qacc, nb, qacc);
     info.rows_active = true;
   } else {
     const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
@@ -845,31 +1011,21 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
       if (b >= nb) continue;
       const int o = NJ + 6 * b;
       block_smooth_force(Rb[b], s.b[b].w, qacc + o);
-      FloorSlots fs;
-      bool any = false;
-#pragma unroll
-      for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
-      int slot = 0;
-      for (int c = 0; c < ncon; c++)  // floor contacts of this block, in detection order
-        if (con[c].ba == 0 && con[c].bb == 2 + b) {
-          const bool on = con[c].dist < 0.0;
-          const V3 r = con[c].pos - s.b[b].p;
-          if (slot == 0) { fs.on[0] = on; fs.dist[0] = con[c].dist; fs.r[0] = r; }
-          if (slot == 1) { fs.on[1] = on; fs.dist[1] = con[c].dist; fs.r[1] = r; }
-          if (slot == 2) { fs.on[2] = on; fs.dist[2] = con[c].dist; fs.r[2] = r; }
-          if (slot == 3) { fs.on[3] = on; fs.dist[3] = con[c].dist; fs.r[3] = r; }
-          slot++;
-          any = any || on;
-        }
+      const bool any = fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3];
       if (any) {
         double Mb[6][6];
         block_mass_matrix6(Rb[b], Mb);
         const double qv[6] = {s.b[b].v.x, s.b[b].v.y, s.b[b].v.z, s.b[b].w.x, s.b[b].w.y, s.b[b].w.z};
-        solve_block_floor(Mb, Rb[b], fs, qv, meaninertia, nv, qacc + o);
+        solve_block_floor(Mb, Rb[b], fs[b], qv, meaninertia, nv, qacc + o);
         info.rows_active = true;
       }
     }
   }
+  }  // live
+  PP_ACC(info, 2, tt);
+  coop_coupled(sh, live && coupled, s, cs, sn, Marm, nb, qacc, info);  // all lanes
+  PP_ACC(info, 3, tt);
+  if (!live) return;
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
   {
     double A[NJ][NJ], rhs[NJ], Dinv[NJ];
@@ -939,7 +1095,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   }
   info.bad = info.bad || !(acc2 <= 1e20);
   s.time += MJS_RR_PHYSICS_DT;
-  info.ncon = ncon + extra;
+  PP_ACC(info, 4, tt);
 }
 
 // contacts of the current state as mj_forward / the trailing mj_step1 would report them (d->ncon)
@@ -973,8 +1129,9 @@ MJS_DEV void make_obs(const World& s, const double* cs, const double* sn, int nb
   }
 }
 
-// initialize_episode (robot_planar_push.py:149-176, intended semantics)
-__device__ __noinline__ void episode_init(DevRng rng, int i, int nb, World& s, int& ncon, bool& bad) {
+// initialize_episode (robot_planar_push.py:149-176, intended semantics), first part: the draws. The 150 settle steps
+// run in the kernel's uniform substep loop. `commit` = false leaves the env's RNG stream untouched (padding lanes).
+__device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, bool commit) {
   RngCursor c = rng_open(rng, i);
   double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
   for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
@@ -994,94 +1151,146 @@ __device__ __noinline__ void episode_init(DevRng rng, int i, int nb, World& s, i
     }
     if (count_contacts(s, cs, sn, nb) == 0) break;
   }
-  rng_close(rng, i, c);
-  StepInfo info{false, false, false, 0};
-  double ctrl0[NJ];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189); no trajectory yet
-  for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];
-  for (int k = 0; k < MJS_PP_SETTLE_STEPS; k++) physics_step(s, ctrl0, cs, sn, nb, info);
-  ncon = count_contacts(s, cs, sn, nb);
-  bad = info.bad;
+  if (commit) rng_close(rng, i, c);
 }
 
+// One workgroup = one wavefront = 64 envs, lane per env. Control flow is UNIFORM across the wavefront (the coupled
+// constraint problems are solved cooperatively): every lane runs the same substep loop, with `live` masking lanes
+// that have nothing to do in an iteration (padding lanes of the last workgroup, lanes that step while their neighbours
+// run the 150 settle steps of a reset).
+constexpr int WAVES = 4;  // wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines
+// Envs per wavefront. The coupled constraint problems of a wavefront's envs are solved one after the other by the
+// whole wavefront, so the critical path of a launch is set by the wavefront with the most coupled envs; at 4096 envs
+// the chip has 16x more SIMDs than 64-env wavefronts would use, so fewer envs per wavefront (the other lanes only
+// help in the cooperative solves) shorten that path.
+#ifndef MJS_PP_ENVS_PER_WAVE
+#define MJS_PP_ENVS_PER_WAVE 4
+#endif
+constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
 template <bool IS_RESET>
-__global__ __launch_bounds__(64) void kernel(KernelParams p) {
-  const int i = blockIdx.x * 64 + threadIdx.x;
-  if (i >= p.N) return;
+__global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
+  __shared__ CoopLds sh_all[WAVES];
+  CoopLds& sh = sh_all[threadIdx.x >> 6];
+  const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
+  const bool valid = (threadIdx.x & 63) < EPW && gi < p.N;
+  const int i = valid ? gi : 0;  // helper / padding lanes shadow env 0 and never write
   const int nb = p.n_objects;
   uint8_t flags = p.flags[i];
-  double obs[OBS_DIM], cs[NJ], sn[NJ];
+  double obs[OBS_DIM], cs[NJ], sn[NJ], ctrl0[NJ], q0[NJ], q1[NJ];
   World s;
-  if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
-    if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    int ncon;
-    bool bad;
-    episode_init(p.rng, i, nb, s, ncon, bad);
-    store_world(p, i, s);
-    p.flags[i] = 0;
-    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
-    make_obs(s, cs, sn, nb, obs);
-    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
-    return;
+  const bool masked_out = IS_RESET && p.reset_mask && !p.reset_mask[i];
+  const bool resetting = valid && !masked_out && (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP));
+  const bool stepping = valid && !IS_RESET && !resetting;
+  double t0 = 0, t1 = 1, inv_span = 1;
+  int nsub = 0;
+  if (resetting) {
+    episode_draws(p.rng, i, nb, s, valid);
+    nsub = MJS_PP_SETTLE_STEPS;
+    for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189)
+  } else if (stepping) {
+    s = load_world(p, i);
+    // before_step (base.py:31-32, robot_planar_push.py:185-201)
+    s.episode_step += 1.0;
+    double act[3] = {p.actions[(size_t)i * ACT_DIM], p.actions[(size_t)i * ACT_DIM + 1], MJS_PP_ACTION_Z};
+    for (int j = 0; j < NJ; j++) q0[j] = s.q[j];
+    if (!tcp_to_joints(act, q0, q1)) {
+      flags |= FLAG_IK_FAILED;
+      for (int j = 0; j < NJ; j++) q1[j] = q0[j];
+    }
+    t0 = s.time; t1 = s.time + MJS_RR_CONTROL_DT; inv_span = 1.0 / (t1 - t0);
+    nsub = MJS_RR_NSUB;
+  } else {
+    s = load_world(p, i);
   }
-  s = load_world(p, i);
-  // before_step (base.py:31-32, robot_planar_push.py:185-201)
-  s.episode_step += 1.0;
-  double q0[NJ], q1[NJ], act[3] = {p.actions[(size_t)i * ACT_DIM], p.actions[(size_t)i * ACT_DIM + 1], MJS_PP_ACTION_Z};
-  for (int j = 0; j < NJ; j++) q0[j] = s.q[j];
-  if (!tcp_to_joints(act, q0, q1)) {
-    flags |= FLAG_IK_FAILED;
-    for (int j = 0; j < NJ; j++) q1[j] = q0[j];
-  }
-  const double t0 = s.time, t1 = s.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
   for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  if (!valid) nsub = 0;  // helper lanes only take part in the cooperative solves
   StepInfo info{false, false, false, 0};
+#ifdef MJS_STAMPS
+  for (int k = 0; k < 6; k++) info.cyc[k] = 0;
+#endif
+  int nmax = nsub;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
 #pragma unroll 1
-  for (int sub = 0; sub < MJS_RR_NSUB; sub++) {
-    const double t = fmin(fmax(s.time, t0), t1);
+  for (int sub = 0; sub < nmax; sub++) {
     double ctrl[NJ];
-    for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    physics_step(s, ctrl, cs, sn, nb, info);
+    if (stepping) {
+      const double t = fmin(fmax(s.time, t0), t1);
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    } else {
+      for (int j = 0; j < NJ; j++) ctrl[j] = ctrl0[j];
+    }
+    physics_step(s, ctrl, cs, sn, nb, info, sub < nsub, sh);
   }
-  bool bad = info.bad;
-  for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
-  for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
-  make_obs(s, cs, sn, nb, obs);
-  // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
-  double sum = 0, nearest = INFINITY;
-  int inside = 0;
-  for (int b = 0; b < nb; b++) {
-    const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
-    const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
-    sum += dt;
-    inside += dt < MJS_PP_TARGET_RADIUS;
-    nearest = fmin(nearest, dr);
-  }
-  const bool success = inside == nb;
-  double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
-  double discount = success ? 0.0 : 1.0;
-  bool terminate = success || s.episode_step >= (double)p.max_episode_steps;
-  if (bad) { reward = 0; discount = 0; terminate = true; }
-  if (s.time >= p.time_limit) terminate = true;
-  const int ncon = count_contacts(s, cs, sn, nb);
-  const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-                    (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
-  const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  store_world(p, i, s);
-  p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
-  write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
-  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
-    if (p.out.terminal_obs)
-      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
-    int ncon2;
-    bool bad2;
-    episode_init(p.rng, i, nb, s, ncon2, bad2);
-    store_world(p, i, s);
-    p.flags[i] = 0;
-    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+#ifdef MJS_STAMPS
+  if (p.stamps && threadIdx.x == 0 && !IS_RESET)
+    for (int k = 0; k < 6; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
+#endif
+  bool bad = info.bad, terminate = false;
+  if (resetting) {
+    const int ncon = count_contacts(s, cs, sn, nb);
+    if (valid) {
+      store_world(p, i, s);
+      p.flags[i] = 0;
+      make_obs(s, cs, sn, nb, obs);
+      write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
+    }
+  } else if (stepping) {
+    for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
+    for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
     make_obs(s, cs, sn, nb, obs);
-    if (p.out.obs)
-      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-    if (p.out.ncon) p.out.ncon[i] = ncon2;
+    // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
+    double sum = 0, nearest = INFINITY;
+    int inside = 0;
+    for (int b = 0; b < nb; b++) {
+      const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
+      const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
+      sum += dt;
+      inside += dt < MJS_PP_TARGET_RADIUS;
+      nearest = fmin(nearest, dr);
+    }
+    const bool success = inside == nb;
+    double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
+    double discount = success ? 0.0 : 1.0;
+    terminate = success || s.episode_step >= (double)p.max_episode_steps;
+    if (bad) { reward = 0; discount = 0; terminate = true; }
+    if (s.time >= p.time_limit) terminate = true;
+    const int ncon = count_contacts(s, cs, sn, nb);
+    const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+                      (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
+    const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+    if (valid) {
+      store_world(p, i, s);
+      p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+      write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+    }
+  }
+  // same-step auto-reset (SB3 VecEnv convention): the lanes whose episode just ended run a reset, the others idle
+  if (!IS_RESET && p.autoreset == MJS_AUTORESET_SAME_STEP && __any(stepping && terminate)) {
+    const bool again = stepping && terminate;
+    if (again) {
+      if (valid && p.out.terminal_obs)
+        for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+      episode_draws(p.rng, i, nb, s, valid);
+      for (int j = 0; j < NJ; j++) { ctrl0[j] = s.q[j]; sincos(s.q[j], &sn[j], &cs[j]); }
+    }
+    StepInfo info2{false, false, false, 0};
+#ifdef MJS_STAMPS
+    for (int k = 0; k < 6; k++) info2.cyc[k] = 0;
+#endif
+#pragma unroll 1
+    for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid, sh);
+    if (again) {
+      const int ncon2 = count_contacts(s, cs, sn, nb);
+      if (valid) {
+        store_world(p, i, s);
+        p.flags[i] = 0;
+        make_obs(s, cs, sn, nb, obs);
+        if (p.out.obs)
+          for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+        if (p.out.ncon) p.out.ncon[i] = ncon2;
+      }
+    }
   }
 }
 

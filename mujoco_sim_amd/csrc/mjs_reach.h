@@ -364,7 +364,16 @@ MJS_DEV bool build_limit_rows(const double* q, const double* v, LimitRows& r) {
   }
   return any;
 }
-// in-place Cholesky of a symmetric positive definite 6x6 (lower triangle used) and solve
+// reciprocal square root from v_rsq_f64 + two Newton steps (full double precision to ~1 ulp): the 6x6 Cholesky below
+// is called several times per substep by the constraint stages and IEEE sqrt + division sequences dominated it
+MJS_DEV double rsqrt_fast(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
+// in-place Cholesky of a symmetric positive definite 6x6 (lower triangle used). The DIAGONAL of the factor is
+// stored as its RECIPROCAL (chol6_solve multiplies instead of dividing).
 MJS_DEV bool chol6(double H[NJ][NJ]) {
 #pragma unroll
   for (int i = 0; i < NJ; i++) {
@@ -375,9 +384,9 @@ MJS_DEV bool chol6(double H[NJ][NJ]) {
       for (int k = 0; k < j; k++) s -= H[i][k] * H[j][k];
       if (i == j) {
         if (s < MJS_MINVAL) return false;
-        H[i][i] = sqrt(s);
+        H[i][i] = rsqrt_fast(s);
       } else
-        H[i][j] = s / H[j][j];
+        H[i][j] = s * H[j][j];
     }
   }
   return true;
@@ -388,14 +397,14 @@ MJS_DEV void chol6_solve(const double L[NJ][NJ], double* x) {
     double s = x[i];
 #pragma unroll
     for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
-    x[i] = s / L[i][i];
+    x[i] = s * L[i][i];
   }
 #pragma unroll
   for (int i = NJ - 1; i >= 0; i--) {
     double s = x[i];
 #pragma unroll
     for (int k = i + 1; k < NJ; k++) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
+    x[i] = s * L[i][i];
   }
 }
 // constraint force in joint space for the active limit rows; Mf = full symmetric M incl. armature

@@ -135,7 +135,8 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH) pp::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)
+    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
@@ -220,8 +221,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
 #ifdef MJS_STAMPS
-  if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
-  if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 16 * ((N + 63) / 64));
+  if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * N);  // one slot block per workgroup, at most N workgroups
+  if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 16 * N);
 #endif
   if (e != hipSuccess) {
     int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
@@ -245,13 +246,19 @@ void mjs_destroy(mjs_handle* h) {
 #ifdef MJS_STAMPS
   if (h->stamps) {  // diagnostic build: mean phase lengths (shader cycles) of the LAST step launch
     const int W = (h->cfg.num_envs + 63) / 64;
-    unsigned long long* host = new unsigned long long[16 * W];
+    unsigned long long* host = new unsigned long long[16 * (size_t)h->cfg.num_envs];
     (void)hipDeviceSynchronize();
-    (void)hipMemcpy(host, h->stamps, sizeof(unsigned long long) * 16 * W, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host, h->stamps, sizeof(unsigned long long) * 16 * (size_t)h->cfg.num_envs, hipMemcpyDeviceToHost);
     double d[5] = {0, 0, 0, 0, 0}, e[5] = {0, 0, 0, 0, 0};
     for (int w = 0; w < W; w++) {
       for (int k = 0; k < 5; k++) d[k] += (double)(host[16 * w + k + 1] - host[16 * w + k]) / W;
       for (int k = 0; k < 5; k++) e[k] += (double)(host[16 * w + 8 + k + 1] - host[16 * w + 8 + k]) / W;
+    }
+    if (h->cfg.task == MJS_TASK_PLANAR_PUSH) {
+      double c[6] = {0, 0, 0, 0, 0, 0};
+      const int WG = (h->cfg.num_envs + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES);
+      for (int w = 0; w < WG; w++) for (int k = 0; k < 6; k++) c[k] += (double)host[16 * w + k] / WG;
+      std::fprintf(stderr, "[MJS_STAMPS] planar-push, wave 0 of each workgroup, cycles per control step: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (of which the owner lane's publish %.0f) | integrate %.0f\n", c[0], c[1], c[2], c[3], c[5], c[4]);
     }
     std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
     std::fprintf(stderr, "[MJS_STAMPS] role-0 substep 10: CRBA+factor+invert %.0f | barrier %.0f | apply inverse+publish+barrier %.0f | integrate %.0f\n", e[0], e[1], e[2], e[3]);

@@ -531,7 +531,9 @@ static void any_perpendicular(double* out, const double* v) {
   cross3(out, v, ax);
 }
 /* returns 1 and fills (depth >= 0, normal geom1->geom2, pos) when the geoms overlap */
+long om_dbg_mpr_calls = 0, om_dbg_mpr_iters = 0, om_dbg_mpr_max = 0, om_dbg_mpr_hits = 0;
 static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, double* depth, double* normal, double* pos) {
+  om_dbg_mpr_calls++;
   mpr_vert v0, v1, v2, v3, v4;
   double dir[3], t1[3], t2[3];
   for (int k = 0; k < 3; k++) { v0.a[k] = d->geom_xpos[g1][k]; v0.b[k] = d->geom_xpos[g2][k]; v0.v[k] = v0.a[k] - v0.b[k]; }
@@ -568,6 +570,7 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
   /* portal refinement */
   int hit = 0;
   for (int it = 0; it < MJS_MPR_MAX_ITER; it++) {
+    om_dbg_mpr_iters++; if (it + 1 > om_dbg_mpr_max) om_dbg_mpr_max = it + 1;
     for (int k = 0; k < 3; k++) { t1[k] = v2.v[k] - v1.v[k]; t2[k] = v3.v[k] - v1.v[k]; }
     cross3(dir, t1, t2);
     if (!normalize3(dir)) return 0;
