@@ -97,10 +97,12 @@ const char* mjs_version(void);
 /* flat observation width: Pointmass {pointmass/position(2), goal_position(2)} (point_reach.py:115-118);
  * Robot-Reach {ur5e/tcp_position(3), ur5e/joint_configuration(6), target_position(3)}
  * (robot_reach.py:134-137, robot.py:292-298); Button-Push {ur5e/joint_configuration(6),
- * ur5e/tcp_position(3), switch/position(3), switch/active(1)} (robot_push_button.py:113-119, switch.py:99-108) */
+ * ur5e/tcp_position(3), switch/position(3), switch/active(1)} (robot_push_button.py:113-119, switch.py:99-108);
+ * Planar-Push {ur5e/tcp_position(3), target_position(2), block_positions(2 per block, 2 slots)}
+ * (robot_planar_push.py:120-126,134-138,178-179) */
 int mjs_obs_dim(int task);
 /* action width: 2 (point_reach.py:204-209) / 3 (robot_reach.py:187-201) / Button-Push default 7
- * (robot_push_button.py:181-203) */
+ * (robot_push_button.py:181-203) / Planar-Push 2 (absolute TCP xy, robot_planar_push.py:197-201,222-228) */
 int mjs_action_dim(int task);
 /* action width for a task + MJS_ACTION_* pair (Button-Push: 7 or 4); equals mjs_action_dim otherwise */
 int mjs_action_dim_for(int task, int action_type);
@@ -108,7 +110,8 @@ int mjs_action_dim_for(int task, int action_type);
 int mjs_state_dim(int task);
 /* algorithmic HBM bytes one env-step moves (state R+W, action, outputs), from the real layout */
 int mjs_algorithmic_bytes_per_env_step(int task);
-/* physics substeps per control step: 5 (point_reach.py:24-25) / 20 (robot_reach.py:62-63) */
+/* physics substeps per control step: 5 (point_reach.py:24-25) / 20 (robot_reach.py:62-63, robot_planar_push.py:51-52,
+ * robot_push_button.py:38-39) */
 int mjs_substeps(int task);
 
 /* Replaces task + composer.Environment + DMCEnvironmentAdapter construction
