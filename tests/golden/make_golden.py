@@ -76,7 +76,49 @@ def run_button(N, T, base_seed):
     return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
 
 
+def run_push(N, T, base_seed, limit):
+    """Planar-Push: noisy push-towards-block-0 policy, closed loop on the oracle, step limit `limit` so that
+    truncations + device-side resets (rejection-sampled draws, 150 settle steps) are inside the fixture. Returns None
+    when some env of the batch is ill-conditioned (a second oracle perturbed by 1e-13 m at every reset disagrees by
+    more than 1e-10): rigid-body contact amplifies rounding noise there and no fixed tolerance would be meaningful."""
+    import ctypes as C
+
+    knob = C.c_double.in_dll(oracle.lib(), "om_dbg_perturb")
+    b = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit)
+    b2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit)
+    r = b.reset()
+    knob.value = 1e-13
+    r2 = b2.reset()
+    knob.value = 0.0
+    keys = ["obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon"]
+    traj = {k: [] for k in keys}
+    acts = []
+    reset_obs = r["obs"]
+    rs = np.random.RandomState(99)
+    worst = np.abs(r["obs"] - r2["obs"]).max()
+    for t in range(T):
+        tcp, blk = r["obs"][:, :2], r["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        acts.append(a)
+        r = b.step(a)
+        knob.value = 1e-13
+        r2 = b2.step(a)
+        knob.value = 0.0
+        worst = max(worst, np.abs(r["obs"] - r2["obs"]).max())
+        for k in keys:
+            traj[k].append(r[k])
+    if worst > 1e-10:
+        return None
+    return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
+
+
 if __name__ == "__main__":
+    for seed in range(2025, 2125):  # first batch of seeds whose 8 envs are all well-conditioned
+        fx = run_push(8, 70, seed, 25)
+        if fx is not None:
+            np.savez_compressed(OUT / "planar_push_n8_t70.npz", base_seed=seed, **fx)
+            print("planar push fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 8).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
+            break
     np.savez_compressed(OUT / "button_push_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025))
     np.savez_compressed(OUT / "pointmass_n8_t70_seed2025.npz", **run(oracle.TASK_POINTMASS, 8, 70, 2025, oracle.AUTORESET_NEXT_STEP))
     np.savez_compressed(OUT / "robot_reach_n8_t110_seed2025.npz", **run(oracle.TASK_ROBOT_REACH, 8, 110, 2025, oracle.AUTORESET_NEXT_STEP))

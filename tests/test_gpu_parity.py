@@ -87,18 +87,20 @@ def test_pointmass_wall_contacts_parity(oracle_mod):
 
 
 @pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", "point_mass_reach"), ("robot_reach_n8_t110_seed2025", "robot_reach"),
-                                       ("button_push_eef_n8_t80_seed2025", "robot_push_button")])
+                                       ("button_push_eef_n8_t80_seed2025", "robot_push_button"), ("planar_push_n8_t70", "robot_planar_push")])
 def test_gpu_matches_committed_golden(name, task):
     import mujoco_sim_amd as m
 
     g = np.load(GOLDEN / f"{name}.npz")
     T, N = g["actions"].shape[:2]
-    venv = m.HipVectorEnv(task, N, seed=2025, **({"action_type": "absolute_eef_action"} if task == "robot_push_button" else {}))
+    kw = {"action_type": "absolute_eef_action"} if task == "robot_push_button" else {"max_episode_steps": 25} if task == "robot_planar_push" else {}
+    venv = m.HipVectorEnv(task, N, seed=int(g["base_seed"]) if "base_seed" in g else 2025, **kw)
     venv.reset()
-    np.testing.assert_allclose(venv.flat_obs.cpu().numpy(), g["reset_obs"], rtol=0, atol=ATOL)
+    atol = 1e-8 if task == "robot_planar_push" else ATOL  # contact-rich free bodies (fixture envs are well-conditioned, see make_golden.py)
+    np.testing.assert_allclose(venv.flat_obs.cpu().numpy(), g["reset_obs"], rtol=0, atol=atol)
     out = venv.rollout(torch.from_numpy(g["actions"]))  # T launches through mjs_rollout
-    np.testing.assert_allclose(out["obs"].cpu().numpy(), g["obs"], rtol=0, atol=ATOL)
-    np.testing.assert_allclose(out["reward"].cpu().numpy(), g["reward"], rtol=0, atol=ATOL)
+    np.testing.assert_allclose(out["obs"].cpu().numpy(), g["obs"], rtol=0, atol=atol)
+    np.testing.assert_allclose(out["reward"].cpu().numpy(), g["reward"], rtol=0, atol=atol)
     for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
         assert np.array_equal(out[k].cpu().numpy().astype(np.int64), g[k].astype(np.int64)), k
 
@@ -678,3 +680,47 @@ def test_planar_push_env_id(oracle_mod):
         o = ob.step(a[None])
         assert abs(reward - o["reward"][0]) < 1e-8 and (trunc == (t == 4)) and not term
     env.close()
+
+
+@pytest.mark.parametrize("n_objects,reward_type,autoreset", [(1, "sparse_reward", "same_step"), (2, "dense_negative_distance_reward", "same_step")])
+def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
+    # one block / sparse reward / SB3-style same-step auto-reset (terminal_obs + fresh observation in the same call)
+    import ctypes as C
+
+    import mujoco_sim_amd as m
+
+    N, T, LIMIT = 32, 26, 12
+    knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
+    rid = {"sparse_reward": 0, "dense_negative_distance_reward": 2}[reward_type]
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=40, autoreset=autoreset, reward_type=reward_type, n_objects=n_objects, max_episode_steps=LIMIT)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    venv.reset()
+    o = ob.reset()
+    knob.value = 1e-13
+    o2 = ob2.reset()
+    knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    rs = np.random.RandomState(8)
+    n_last = 0
+    for t in range(T):
+        tcp, blk = o["obs"][:, :2], o["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        knob.value = 1e-13
+        o2 = ob2.step(a)
+        knob.value = 0.0
+        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        g = _gpu_result(venv)
+        ok = ~sens
+        np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(g["reward"][ok], o["reward"][ok], rtol=0, atol=1e-8)
+        ended = (o["step_type"] == 2) & ok
+        np.testing.assert_allclose(g["terminal_obs"][ended], o["terminal_obs"][ended], rtol=0, atol=1e-8)
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
+        n_last += int(ended.sum())
+        if n_objects == 1:
+            assert (g["obs"][:, 7:9] == 0).all()  # the unused block slot of the flat layout
+    assert sens.mean() < 0.2 and n_last >= N
