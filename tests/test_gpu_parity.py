@@ -724,3 +724,32 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
         if n_objects == 1:
             assert (g["obs"][:, 7:9] == 0).all()  # the unused block slot of the flat layout
     assert sens.mean() < 0.2 and n_last >= N
+
+
+@pytest.mark.parametrize("task,kw", [("robot_push_button", {"action_type": "absolute_eef_action"}), ("robot_planar_push", {"max_episode_steps": 9})])
+def test_contact_tasks_shard_invariance(task, kw):
+    """Multi-GPU sharding for the contact tasks: env i of one 64-env handle is bit-identical to env i of
+    two 32-env handles with env_index_offset 0 / 32 (global seeds, no cross-env state, lane placement irrelevant)."""
+    import mujoco_sim_amd as m
+
+    N, T = 64, 14
+    whole = m.HipVectorEnv(task, N, seed=321, **kw)
+    parts = [m.HipVectorEnv(task, N // 2, seed=321, env_index_offset=o, **kw) for o in (0, N // 2)]
+    whole.reset()
+    for p_ in parts:
+        p_.reset()
+    rs = np.random.RandomState(3)
+    for t in range(T):
+        obs = whole.flat_obs.cpu().numpy()
+        if task == "robot_push_button":
+            a = np.concatenate([obs[:, 9:12] + rs.uniform(-0.03, 0.05, (N, 3)), np.zeros((N, 1))], axis=1)  # aim at the switch
+        else:
+            a = obs[:, :2] + np.clip(obs[:, 5:7] - obs[:, :2], -0.02, 0.02)                               # push block 0
+        whole.step(torch.from_numpy(a))
+        for k, p_ in enumerate(parts):
+            p_.step(torch.from_numpy(a[k * N // 2:(k + 1) * N // 2]))
+        for key in ("obs", "reward", "step_type", "ncon"):
+            w = whole._buf[key].cpu().numpy()
+            sh = np.concatenate([p_._buf[key].cpu().numpy() for p_ in parts])
+            assert np.array_equal(w, sh), (key, t)
+    assert (whole._buf["ncon"].cpu().numpy() > 0).any()

@@ -33,12 +33,38 @@ def test_task_descriptions_mirror_reference_defaults():
         RobotReachTask(RobotReachConfig(action_type=RobotReachConfig.ABS_JOIN_ACTION))
 
 
+def test_contact_task_descriptions_mirror_reference_defaults():
+    from mujoco_sim_amd.environments.tasks.robot_planar_push import RobotPushConfig, RobotPushTask
+    from mujoco_sim_amd.environments.tasks.robot_push_button import RobotPushButtonTask
+
+    t = RobotPushButtonTask()  # robot_push_button.py:20-58
+    assert (t.reward_type, t.observation_type, t.action_type, t.image_resolution) == ("sparse_reward", "visual_observations", "absolute_joint_action", 96)
+    assert (t.PHYSICS_TIMESTEP, t.CONTROL_TIMESTEP, t.MAX_CONTROL_STEPS_PER_EPISODE, t.GOAL_DISTANCE_THRESHOLD) == (0.005, 0.1, 100, 0.05)
+    assert t.use_wrist_camera and not t.button_disturbances and np.allclose(t.robot_end_position, [-0.3, -0.2, 0.3])
+    spec = t.action_spec()
+    assert spec.shape == (7,) and spec.dtype == np.float64 and np.allclose(spec.maximum, [3.14] * 6 + [0.085]) and np.allclose(spec.minimum, [-3.14] * 6 + [0.0])
+    spec = RobotPushButtonTask(action_type="absolute_eef_action").action_spec()
+    assert spec.shape == (4,) and np.allclose(spec.minimum, [-0.2, -0.6, 0.02, 0.0]) and np.allclose(spec.maximum, [0.2, -0.3, 0.3, 0.085])
+    with pytest.raises(AssertionError):
+        RobotPushButtonTask(action_type="relative_eef_action")
+    c = RobotPushConfig()  # robot_planar_push.py:28-73
+    assert (c.reward_type, c.observation_type) == ("dense_negative_distance_reward", "state_observations")
+    assert (c.physics_timestep, c.control_timestep, c.max_control_steps_per_episode, c.target_radius, c.nearest_object_reward_coefficient) == (0.005, 0.1, 500, 0.05, 0.1)
+    spec = RobotPushTask(c).action_spec()
+    assert spec.shape == (2,) and spec.dtype == np.float32 and np.allclose(spec.maximum, 1.0)
+    with pytest.raises(NotImplementedError):
+        RobotPushConfig(n_objects=5)  # the reference default; this build is limited to 2 blocks
+    with pytest.raises(AssertionError):
+        RobotPushConfig(reward_type="nope")
+
+
 def test_spaces_and_registry():
     import mujoco_sim_amd as m
     from mujoco_sim_amd.environments.dmc2gym import _convert_specs_to_flattened_box, _flatten_obs, convert_spec_to_box
     from mujoco_sim_amd.environments.tasks.point_reach import ArraySpec, BoundedArraySpec
 
     assert "mujoco_sim/point_mass_reach-v0" in m.registry  # reference id (mujoco_sim/__init__.py:26-30)
+    assert "mujoco_sim/robot_push_button_visual-v0" in m.registry  # reference id (mujoco_sim/__init__.py:31-39)
     box = _convert_specs_to_flattened_box([BoundedArraySpec((2,), np.float32, [-1, -2], [1, 2]), ArraySpec((2, 2), np.float64)], np.float64)
     assert box.shape == (6,) and box.dtype == np.float32 and np.isinf(box.high[2:]).all()
     b = convert_spec_to_box(BoundedArraySpec((3,), np.float64, -1, 1))
