@@ -179,6 +179,15 @@ def main():
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }
+        if args.task == "robot_reach":
+            # informational: the bound that actually applies. FP64 operation count per env-step:
+            # 20 substeps x (generated M + bias code 725 ops + servo/actuators/U D U^T/inverse/integration ~330) + IK ~3000
+            # + FK/observables ~500; peak = 1024 SIMDs x 16 FP64 FMA lanes x 2 x ~2.4 GHz (public spec 78.6 TFLOP/s;
+            # measured here: 4 cycles per wave64 FP64 instruction per SIMD). 4096 envs occupy 128 of the 1024 SIMDs.
+            flops = 20 * (725 + 330) + 3000 + 500
+            tf = flops * value / 1e12
+            line["roofline"]["valu_fp64"] = {"flops_per_env_step": flops, "achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
+                                             "simds_occupied_frac": min(1.0, 2 * (n_local / 64) / 1024)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds)
         print(json.dumps(line))
