@@ -301,6 +301,13 @@ MJS_K float MJS_SW_BOX_RGB[3] = {1.0f, 1.0f, 1.0f};
 MJS_K float MJS_SW_BUTTON_RGB_OFF[3] = {1.0f, 0.0f, 0.0f};
 MJS_K float MJS_SW_BUTTON_RGB_ON[3] = {0.0f, 1.0f, 0.0f};
 MJS_K float MJS_CAM_BODY_RGB[3] = {0.0f, 0.0f, 0.0f};
+/* Planar-Push scene [REF]: cylinder.py:30 (EEF rgba), robot_planar_push.py:91-98 (target site: white cylinder r 0.05,
+ * half-height 0.001), google_block.py:11-18 (block colours; the reference draws one at random from the unseeded
+ * global `random`: here block i takes COLORS[i], deviation D-9) */
+MJS_K float MJS_CYL_RGB[3] = {0.2f, 0.2f, 0.2f};
+MJS_K float MJS_PP_TARGET_RGB[3] = {1.0f, 1.0f, 1.0f};
+MJS_K float MJS_PP_TARGET_HALF_HEIGHT = 0.001f;
+MJS_K float MJS_BLOCK_RGB[2][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};
 /* [REF] empty_robot_arena.py:24-26: six positional lights at (x, +-x, 3), x in {-3, 3, 0.5} */
 MJS_K float MJS_RR_LIGHT_POS[6][3] = {{-3.0f, -3.0f, 3.0f}, {-3.0f, 3.0f, 3.0f}, {3.0f, 3.0f, 3.0f},
                                       {3.0f, -3.0f, 3.0f},  {0.5f, 0.5f, 3.0f},  {0.5f, -0.5f, 3.0f}};

@@ -15,6 +15,7 @@
 #include "mjs_pointmass.h"
 #include "mjs_reach.h"
 #include "mjs_button.h"
+#include "mjs_push.h"
 
 namespace rend {
 
@@ -332,6 +333,58 @@ __global__ __launch_bounds__(64) void button_prims_kernel(const double* state, c
     pr[13] = (float)MJS_SW_BUTTON_RADIUS;
     pr[17] = bound_radius((float)(MJS_SW_BUTTON_RADIUS + MJS_SW_BUTTON_HALF));
     put_rgb(pr + 14, (flags[i] & bp::FLAG_SWITCH_ACTIVE) ? MJS_SW_BUTTON_RGB_ON : MJS_SW_BUTTON_RGB_OFF);
+  }
+}
+
+// Planar-Push scene (robot_planar_push.py:81-117): arm proxies + base stand-in, CylinderEEF, target site disc, blocks
+constexpr int PP_NPRIM = ARM_NREC + 1 + pp::NB;
+static_assert(PP_NPRIM <= MAX_NPRIM, "one candidate bit per primitive");
+__global__ __launch_bounds__(64) void push_prims_kernel(const double* state, float* prims, int N, int nb) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= N) return;
+  double q[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) q[j] = state[(size_t)(pp::S_Q + j) * N + i];
+  rr::Chain c;
+  rr::fk(q, c);
+  float* out = prims + (size_t)i * PP_NPRIM * PRIM_FLOATS;
+  arm_prims(c, out);
+  {  // CylinderEEF replaces the gripper stand-in record: axis = flange z = wrist_3 y
+    float* pr = out + (ARM_NREC - 1) * PRIM_FLOATS;
+    const V3 centre = madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_POS_Z, c.R[6].cy);
+    pr[0] = (float)PRIM_CYLINDER;
+    put3(pr + 1, madd(centre, -MJS_CYL_HALFLEN, c.R[6].cy));
+    put3(pr + 4, madd(centre, MJS_CYL_HALFLEN, c.R[6].cy));
+    pr[13] = (float)MJS_CYL_RADIUS;
+    pr[17] = bound_radius((float)(MJS_CYL_RADIUS + MJS_CYL_HALFLEN));
+    put_rgb(pr + 14, MJS_CYL_RGB);
+  }
+  {  // target site: a thin white disc on the floor
+    float* pr = out + ARM_NREC * PRIM_FLOATS;
+    const double tx = state[(size_t)(pp::S_TARGET + 0) * N + i], ty = state[(size_t)(pp::S_TARGET + 1) * N + i], tz = state[(size_t)(pp::S_TARGET + 2) * N + i];
+    pr[0] = (float)PRIM_CYLINDER;
+    put3(pr + 1, v3(tx, ty, tz - (double)MJS_PP_TARGET_HALF_HEIGHT));
+    put3(pr + 4, v3(tx, ty, tz + (double)MJS_PP_TARGET_HALF_HEIGHT));
+    pr[13] = (float)MJS_PP_TARGET_RADIUS;
+    pr[17] = bound_radius((float)MJS_PP_TARGET_RADIUS + MJS_PP_TARGET_HALF_HEIGHT);
+    put_rgb(pr + 14, MJS_PP_TARGET_RGB);
+  }
+#pragma unroll
+  for (int b = 0; b < pp::NB; b++) {
+    float* pr = out + (ARM_NREC + 1 + b) * PRIM_FLOATS;
+    const double* bs = state + (size_t)(pp::S_BLOCK + pp::BLOCK_DIM * b) * N + i;
+    double qn[4] = {bs[3 * (size_t)N], bs[4 * (size_t)N], bs[5 * (size_t)N], bs[6 * (size_t)N]};
+    const double nrm = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qn[k] = qn[k] / nrm;
+    const M3 R = pp::quat_to_m3(qn);
+    const V3 origin = v3(bs[0], bs[(size_t)N], bs[2 * (size_t)N]);
+    pr[0] = (float)PRIM_BOX;
+    put3(pr + 1, b < nb ? madd(origin, MJS_BLOCK_GEOM_Z, R.cz) : v3(0, 0, -10.0));  // unused slot: out of sight
+    put3(pr + 4, R.cx); put3(pr + 7, R.cy);
+    pr[10] = (float)MJS_BLOCK_HALF[0]; pr[11] = (float)MJS_BLOCK_HALF[1]; pr[12] = (float)MJS_BLOCK_HALF[2];
+    pr[17] = bound_radius((float)(MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2]));
+    put_rgb(pr + 14, MJS_BLOCK_RGB[b]);
   }
 }
 

@@ -219,6 +219,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess && cfg->task == MJS_TASK_ROBOT_REACH)  // render primitive list (no allocation in launch paths)
     e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::RR_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
+  if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::PP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
 #ifdef MJS_STAMPS
   if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * N);  // one slot block per workgroup, at most N workgroups
@@ -358,6 +359,10 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
     rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
     p.nprim = rend::BP_NPRIM;
     if (wrist) p.env_cams = h->cams;
+    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+  } else if (task == MJS_TASK_PLANAR_PUSH) {  // robot_planar_push.py:45,66: the FRONT_TILTED camera of Robot-Reach
+    rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects);
+    p.nprim = rend::PP_NPRIM;
     rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   } else {
     rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);

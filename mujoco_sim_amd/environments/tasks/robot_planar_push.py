@@ -41,8 +41,6 @@ class RobotPushConfig:
         self.observation_type = self.observation_type or RobotPushConfig.STATE_OBS
         assert self.observation_type in RobotPushConfig.OBSERVATION_TYPES
         assert self.reward_type in RobotPushConfig.REWARD_TYPES
-        if self.observation_type != RobotPushConfig.STATE_OBS:
-            raise NotImplementedError("Planar-Push cameras are not built (state observations only)")
         if not 1 <= self.n_objects <= 2:
             raise NotImplementedError("n_objects must be 1 or 2 (MJS_PP_MAX_OBJECTS)")
         if self.nearest_object_reward_coefficient != 0.1 or self.physics_timestep != 0.005 or self.control_timestep != 0.1:

@@ -246,7 +246,7 @@ static void quat_to_mat(const double* q, double* R) {
 static void render_robot_scene(const om_env* e, int camera, int H, int W, uint8_t* out) {
   const om_model* m = &e->m;
   const om_data* dd = &e->d;
-  const int button = e->cfg.task == OM_TASK_BUTTON_PUSH;
+  const int button = e->cfg.task == OM_TASK_BUTTON_PUSH, push = e->cfg.task == OM_TASK_PLANAR_PUSH;
   /* flange frame (site 0) */
   const double* sp = dd->site_xpos[0];
   const double* sm = dd->site_xmat[0];
@@ -318,8 +318,28 @@ static void render_robot_scene(const om_env* e, int camera, int H, int W, uint8_
         if (MJS_UR_COL_TYPE[g] == 3) capsule(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
         else cylinder(eye, d, cap_a[g], cap_b[g], (float)MJS_UR_COL_SIZE[g][0], V(c[0], c[1], c[2]), &s);
       }
+      if (push) {
+        /* CylinderEEF (geom after the arm proxies), target site disc, blocks (box geoms of the free bodies) */
+        const int ge = 1 + MJS_UR_NCOLGEOM;
+        const double* gp = dd->geom_xpos[ge];
+        const double* gm = dd->geom_xmat[ge];
+        double a[3], b[3], ta[3], tb[3];
+        for (int k = 0; k < 3; k++) { a[k] = gp[k] + -MJS_CYL_HALFLEN * gm[3 * k + 2]; b[k] = gp[k] + MJS_CYL_HALFLEN * gm[3 * k + 2]; }
+        cylinder(eye, d, Vd(a), Vd(b), (float)MJS_CYL_RADIUS, V(MJS_CYL_RGB[0], MJS_CYL_RGB[1], MJS_CYL_RGB[2]), &s);
+        for (int k = 0; k < 3; k++) { ta[k] = e->target_pos[k]; tb[k] = e->target_pos[k]; }
+        ta[2] = e->target_pos[2] - (double)MJS_PP_TARGET_HALF_HEIGHT; tb[2] = e->target_pos[2] + (double)MJS_PP_TARGET_HALF_HEIGHT;
+        cylinder(eye, d, Vd(ta), Vd(tb), (float)MJS_PP_TARGET_RADIUS, V(MJS_PP_TARGET_RGB[0], MJS_PP_TARGET_RGB[1], MJS_PP_TARGET_RGB[2]), &s);
+        for (int i = 0; i < e->cfg.n_objects; i++) {
+          const double* bp = dd->geom_xpos[ge + 1 + i];
+          const double* bm = dd->geom_xmat[ge + 1 + i];
+          double u[3] = {bm[0], bm[3], bm[6]}, w[3] = {bm[1], bm[4], bm[7]};
+          obb(eye, d, Vd(bp), Vd(u), Vd(w), V((float)MJS_BLOCK_HALF[0], (float)MJS_BLOCK_HALF[1], (float)MJS_BLOCK_HALF[2]),
+              V(MJS_BLOCK_RGB[i][0], MJS_BLOCK_RGB[i][1], MJS_BLOCK_RGB[i][2]), &s);
+        }
+      } else
       obb(eye, d, box_c, box_u, box_v, V(MJS_G2F85_STANDIN_HALF[0], MJS_G2F85_STANDIN_HALF[1], MJS_G2F85_STANDIN_HALF[2]), V(MJS_UR_BLACK[0], MJS_UR_BLACK[1], MJS_UR_BLACK[2]), &s);
-      if (!button) {
+      if (push) {
+      } else if (!button) {
         sphere(eye, d, tgt, MJS_RR_TARGET_RADIUS, V(MJS_RR_TARGET_RGB[0], MJS_RR_TARGET_RGB[1], MJS_RR_TARGET_RGB[2]), &s);
       } else {
         obb(eye, d, Vd(wpos), Vd(wright), Vd(wup), cam_half, cam_rgb, &s);

@@ -753,3 +753,33 @@ def test_contact_tasks_shard_invariance(task, kw):
             sh = np.concatenate([p_._buf[key].cpu().numpy() for p_ in parts])
             assert np.array_equal(w, sh), (key, t)
     assert (whole._buf["ncon"].cpu().numpy() > 0).any()
+
+
+def test_planar_push_camera_matches_oracle(oracle_mod):
+    """Planar-Push scene camera (robot_planar_push.py:45,111-116: the FRONT_TILTED camera): arm, CylinderEEF, target
+    disc, blocks; same bar as the other robot scenes. Also the VISUAL_OBS observation dict (:140-142)."""
+    import mujoco_sim_amd as m
+
+    N = 12
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2032)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2032, nthreads=4)
+    venv.reset()
+    o = ob.reset()
+    for t in range(4):
+        a = o["obs"][:, :2] + np.clip(o["obs"][:, 5:7] - o["obs"][:, :2], -0.02, 0.02)
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+    same = np.abs(venv.flat_obs.cpu().numpy() - o["obs"]).max(axis=1) < 1e-8  # compare images of envs whose states agree
+    assert same.sum() >= N - 2
+    for res in (64, 128):
+        gpu = venv.render(res, res).cpu().numpy().astype(np.int16)[same]
+        cpu = ob.render(res, res).astype(np.int16)[same]
+        diff = np.abs(gpu - cpu)
+        assert (diff > 0).mean() < 2e-4 and diff.max() <= 2, (res, (diff > 0).mean(), diff.max())
+        assert gpu.std() > 10
+    venv.close()
+    vis = m.HipVectorEnv("robot_planar_push", 4, seed=1, observation_type="visual_observations", image_resolution=64)
+    obs, _ = vis.reset()
+    assert list(obs) == ["ur5e/tcp_position", "Camera/rgb_image"] and obs["Camera/rgb_image"].shape == (4, 64, 64, 3)
+    assert obs["Camera/rgb_image"].float().std() > 10
+    vis.close()
