@@ -17,6 +17,7 @@ from .environments.tasks.point_reach import PointMassReachTask
 from .environments.tasks.robot_reach import RobotReachConfig, RobotReachTask
 from .environments.tasks.robot_push_button import RobotPushButtonTask
 from .environments.tasks.robot_planar_push import RobotPushConfig, RobotPushTask
+from .recording import LeRobotDatasetRecorder  # noqa: F401
 from .vector_env import TASKS, HipVectorEnv  # noqa: F401
 
 __version__ = "0.1.0"

@@ -134,3 +134,54 @@ def test_gloo_world2_gather_matches_single_process():
     ref = np.stack([b.step(acts[t])["obs"] for t in range(T)])
     assert full.shape == (T, N, 4) and np.array_equal(full, ref)
     assert tmax == 2.0
+
+
+def test_lerobot_recorder_schema_and_round_trip(tmp_path):
+    """Recorder with the reference collector's conventions (scripts/demonstration_collection.py:39-167): feature names,
+    '/' -> '_' key mapping, observation.images.* for image keys, observation.state = concatenated state keys; LeRobot
+    v2 directory layout read back with pyarrow."""
+    import json
+    from collections import OrderedDict
+
+    import pyarrow.parquet as pq
+
+    from mujoco_sim_amd.recording import LeRobotDatasetRecorder
+    from mujoco_sim_amd.spaces import Box, Dict
+
+    class FakeEnv:  # the spaces of mujoco_sim/robot_push_button_visual-v0 at 8x8 resolution
+        single_observation_space = Dict(OrderedDict([("ur5e/joint_configuration", Box(-np.inf, np.inf, shape=(6,), dtype=np.float64)),
+                                                     ("ur5e/Camera/rgb_image", Box(0, 255, shape=(8, 8, 3), dtype=np.uint8)),
+                                                     ("Camera/rgb_image", Box(0, 255, shape=(8, 8, 3), dtype=np.uint8))]))
+        single_action_space = Box(-3.14, 3.14, shape=(7,), dtype=np.float32)
+
+    rec = LeRobotDatasetRecorder(FakeEnv(), tmp_path / "ds", "test/push_button", fps=10, task="push the button")
+    assert set(rec.features) == {"next.reward", "next.success", "seed", "timestamp", "observation.images.ur5e_Camera_rgb_image", "observation.images.Camera_rgb_image",
+                                 "ur5e_joint_configuration", "observation.state", "action"}
+    assert rec.features["observation.state"]["shape"] == (6,) and rec.features["action"]["shape"] == (7,)
+    rs = np.random.RandomState(0)
+    N, lengths = 3, [4, 2, 3]
+    t = 0
+    while rec.n_recorded_episodes < 3:
+        obs = {"ur5e/joint_configuration": rs.normal(size=(N, 6)), "ur5e/Camera/rgb_image": rs.randint(0, 255, (N, 8, 8, 3)).astype(np.uint8),
+               "Camera/rgb_image": rs.randint(0, 255, (N, 8, 8, 3)).astype(np.uint8)}
+        last = np.array([t + 1 == lengths[i] for i in range(N)])
+        rec.record_batch(obs, rs.normal(size=(N, 7)), np.arange(N, dtype=float), last, last, seeds=[5, 6, 7])
+        t += 1
+        if t >= 4:
+            break
+    rec.finish_recording()
+    info = json.loads((tmp_path / "ds" / "meta" / "info.json").read_text())
+    assert info["total_episodes"] == 3 and info["total_frames"] == 9 and info["fps"] == 10
+    episodes = [json.loads(l) for l in (tmp_path / "ds" / "meta" / "episodes.jsonl").read_text().splitlines()]
+    assert sorted(e["length"] for e in episodes) == [2, 3, 4]
+    tab = pq.read_table(tmp_path / "ds" / "data" / "chunk-000" / "episode_000000.parquet").to_pydict()
+    assert len(tab["action"]) == 2 and len(tab["action"][0]) == 7 and len(tab["observation.images.Camera_rgb_image"][0]) == 8 * 8 * 3  # env 1 ended first
+    assert tab["next.success"][-1] == [True] and tab["seed"][0] == [6] and abs(tab["timestamp"][1][0] - 0.1) < 1e-6
+    # single-env API of the reference
+    rec2 = LeRobotDatasetRecorder(FakeEnv(), tmp_path / "ds2", "test/single", fps=10)
+    rec2.start_episode()
+    for k in range(3):
+        rec2.record({"ur5e/joint_configuration": np.zeros(6), "ur5e/Camera/rgb_image": np.zeros((8, 8, 3), np.uint8), "Camera/rgb_image": np.zeros((8, 8, 3), np.uint8)},
+                    np.zeros(7, np.float32), 0.0, k == 2, {})
+    rec2.save_episode()
+    assert rec2.n_recorded_episodes == 1
