@@ -645,6 +645,11 @@ struct CoopLds {
   double bp[NB][3], bR[NB][9];     // block origins and rotation columns (cx, cy, cz)
   double qvel[NV], q[NJ];
 };
+// The cooperative workspace lives in dynamic LDS declared at namespace scope so that every device function reaches it
+// as an LDS (address space 3) object: passing it by reference through a non-inlined call would degrade every access
+// to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
+extern __shared__ double pp_lds_raw[];
+MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
 MJS_DEV double wave_sum(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
@@ -797,7 +802,8 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
   MJS_WAVE_SYNC();
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
-__device__ __noinline__ void publish_problem(CoopLds& sh, const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb) {
+__device__ __noinline__ void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb) {
+  CoopLds& sh = coop_lds();
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
   M3 Rb[NB];
@@ -926,7 +932,8 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
   }
   if (lane == 0) sh.nrow = nlim + 6 * nact;
 }
-MJS_DEV void coop_coupled(CoopLds& sh, bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info) {
+MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info) {
+  CoopLds& sh = coop_lds();
   const int lane = threadIdx.x & 63, nv = NJ + 6 * nb;
   const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
   unsigned long long todo = __ballot(need);
@@ -937,7 +944,7 @@ MJS_DEV void coop_coupled(CoopLds& sh, bool need, const World& s, const double* 
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
-    if (lane == owner) publish_problem(sh, s, cs, sn, Marm, qacc, nb);
+    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb);
     MJS_WAVE_SYNC();
     PP_ACC(info, 5, tp);
     coop_build_rows(sh, nb, lane);
@@ -954,7 +961,7 @@ MJS_DEV void coop_coupled(CoopLds& sh, bool need, const World& s, const double* 
 // dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
 // `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
 // neighbours (all 64 lanes of the workgroup must call this function together).
-__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info, bool live, CoopLds& sh) {
+__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info, bool live) {
   const int nv = NJ + 6 * nb;
   double Marm[21], qacc[NV];
   int clamped = 0;
@@ -1023,7 +1030,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   }
   }  // live
   PP_ACC(info, 2, tt);
-  coop_coupled(sh, live && coupled, s, cs, sn, Marm, nb, qacc, info);  // all lanes
+  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
@@ -1169,8 +1176,6 @@ constexpr int WAVES = 4;  // wavefronts per workgroup: same-CU wavefronts walk t
 constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
 template <bool IS_RESET>
 __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
-  __shared__ CoopLds sh_all[WAVES];
-  CoopLds& sh = sh_all[threadIdx.x >> 6];
   const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
   const bool valid = (threadIdx.x & 63) < EPW && gi < p.N;
   const int i = valid ? gi : 0;  // helper / padding lanes shadow env 0 and never write
@@ -1220,7 +1225,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     } else {
       for (int j = 0; j < NJ; j++) ctrl[j] = ctrl0[j];
     }
-    physics_step(s, ctrl, cs, sn, nb, info, sub < nsub, sh);
+    physics_step(s, ctrl, cs, sn, nb, info, sub < nsub);
   }
 #ifdef MJS_STAMPS
   if (p.stamps && threadIdx.x == 0 && !IS_RESET)
@@ -1279,7 +1284,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     for (int k = 0; k < 6; k++) info2.cyc[k] = 0;
 #endif
 #pragma unroll 1
-    for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid, sh);
+    for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid);
     if (again) {
       const int ncon2 = count_contacts(s, cs, sn, nb);
       if (valid) {

@@ -136,7 +136,7 @@ template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)
-    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, 0, s>>>(p);
+    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, sizeof(pp::CoopLds) * pp::WAVES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
@@ -256,10 +256,16 @@ void mjs_destroy(mjs_handle* h) {
       for (int k = 0; k < 5; k++) e[k] += (double)(host[16 * w + 8 + k + 1] - host[16 * w + 8 + k]) / W;
     }
     if (h->cfg.task == MJS_TASK_PLANAR_PUSH) {
-      double c[6] = {0, 0, 0, 0, 0, 0};
+      double c[6] = {0, 0, 0, 0, 0, 0}, worst[6] = {0, 0, 0, 0, 0, 0}, worst_total = 0;
       const int WG = (h->cfg.num_envs + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES);
-      for (int w = 0; w < WG; w++) for (int k = 0; k < 6; k++) c[k] += (double)host[16 * w + k] / WG;
-      std::fprintf(stderr, "[MJS_STAMPS] planar-push, wave 0 of each workgroup, cycles per control step: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (of which the owner lane's publish %.0f) | integrate %.0f\n", c[0], c[1], c[2], c[3], c[5], c[4]);
+      for (int w = 0; w < WG; w++) {
+        double tot = 0;
+        for (int k = 0; k < 5; k++) tot += (double)host[16 * w + k];
+        for (int k = 0; k < 6; k++) c[k] += (double)host[16 * w + k] / WG;
+        if (tot > worst_total) { worst_total = tot; for (int k = 0; k < 6; k++) worst[k] = (double)host[16 * w + k]; }
+      }
+      std::fprintf(stderr, "[MJS_STAMPS] planar-push, wave 0 of each workgroup, cycles per control step, MEAN: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (of which the owner lane's publish %.0f) | integrate %.0f\n", c[0], c[1], c[2], c[3], c[5], c[4]);
+      std::fprintf(stderr, "[MJS_STAMPS] SLOWEST workgroup: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (publish %.0f) | integrate %.0f\n", worst[0], worst[1], worst[2], worst[3], worst[5], worst[4]);
     }
     std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
     std::fprintf(stderr, "[MJS_STAMPS] role-0 substep 10: CRBA+factor+invert %.0f | barrier %.0f | apply inverse+publish+barrier %.0f | integrate %.0f\n", e[0], e[1], e[2], e[3]);
