@@ -655,18 +655,19 @@ MJS_DEV double wave_sum(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
   return x;
 }
-// in-place Cholesky of sh.H (lower) and solve H x = b for x in `vec` (LDS), all lanes
+// in-place Cholesky of sh.H (lower; the diagonal ends up holding RECIPROCALS) fused with the forward substitution,
+// then the backward substitution: H x = b for x in `vec` (LDS), all lanes. A wavefront's LDS instructions execute in
+// program order, so the syncs only have to stop the COMPILER from moving one lane's load above another lane's store.
 MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
   bool ok = true;
   for (int j = 0; j < nv; j++) {
-    const double d = sh.H[j][j];
-    if (d < MJS_MINVAL) ok = false;  // uniform: every lane reads the same value
-    const double sd = sqrt(fmax(d, MJS_MINVAL));
+    const double d = sh.H[j][j];  // every lane reads the same value
+    if (d < MJS_MINVAL) ok = false;
+    const double inv = rr::rsqrt_fast(fmax(d, MJS_MINVAL));
+    if (lane > j && lane < nv) sh.H[lane][j] = sh.H[lane][j] * inv;
+    if (lane == 0) { sh.H[j][j] = inv; vec[j] = vec[j] * inv; }  // y_j
     MJS_WAVE_SYNC();
-    if (lane == 0) sh.H[j][j] = sd;
-    if (lane > j && lane < nv) sh.H[lane][j] = sh.H[lane][j] / sd;
-    MJS_WAVE_SYNC();
-    // trailing update: pairs (i, k), j < k <= i < nv
+    // trailing update (pairs (i, k), j < k <= i < nv) and forward elimination of the right-hand side
     const int m = nv - j - 1;
     for (int e = lane; e < m * (m + 1) / 2; e += 64) {
       int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
@@ -675,18 +676,14 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
       const int k = e - i * (i + 1) / 2;
       sh.H[j + 1 + i][j + 1 + k] -= sh.H[j + 1 + i][j] * sh.H[j + 1 + k][j];
     }
-    MJS_WAVE_SYNC();
+    if (lane > j && lane < nv) vec[lane] -= sh.H[lane][j] * vec[j];
+    MJS_WAVE_SYNC();  // the next column reads what other lanes just updated
   }
-  for (int k = 0; k < nv; k++) {  // forward substitution, column oriented
-    if (lane == 0) vec[k] = vec[k] / sh.H[k][k];
+  for (int k = nv - 1; k >= 0; k--) {  // backward substitution with L^T: one sync per step
+    const double xk = vec[k] * sh.H[k][k];  // same value on every lane
     MJS_WAVE_SYNC();
-    if (lane > k && lane < nv) vec[lane] -= sh.H[lane][k] * vec[k];
-    MJS_WAVE_SYNC();
-  }
-  for (int k = nv - 1; k >= 0; k--) {  // backward substitution with L^T
-    if (lane == 0) vec[k] = vec[k] / sh.H[k][k];
-    MJS_WAVE_SYNC();
-    if (lane < k) vec[lane] -= sh.H[k][lane] * vec[k];
+    if (lane == k) vec[k] = xk;
+    if (lane < k) vec[lane] -= sh.H[k][lane] * xk;
     MJS_WAVE_SYNC();
   }
   return ok;
@@ -694,12 +691,21 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
 // cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
 MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
   const int nrow = sh.nrow;
-  // qacc_smooth = M^-1 qfrc_smooth
-  for (int e = lane; e < nv * nv; e += 64) sh.H[e / nv][e % nv] = sh.M[e / nv][e % nv];
-  if (lane < nv) sh.a_s[lane] = sh.qs[lane];
-  MJS_WAVE_SYNC();
-  coop_chol_solve(sh, nv, sh.a_s, lane);
-  if (lane < nv) sh.a[lane] = sh.a_s[lane];
+  // qacc_smooth = M^-1 qfrc_smooth: M is block diagonal (arm, block 0, block 1), one lane per 6x6 block
+  if (lane < nv / 6) {
+    double L[6][6], x[6];
+    const int o = 6 * lane;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i][j] = sh.M[o + i][o + j];
+      x[i] = sh.qs[o + i];
+    }
+    rr::chol6(L);
+    rr::chol6_solve(L, x);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sh.a_s[o + i] = x[i]; sh.a[o + i] = x[i]; }
+  }
   MJS_WAVE_SYNC();
   if (lane < nv) {
     double m = 0;
@@ -727,6 +733,19 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
   };
   double cost = update();
   const double scale = 1 / (meaninertia * nv);
+  // this lane's (up to 3) entries of the lower triangle of the Hessian
+  int hi[3], hj[3];
+  bool he[3];
+#pragma unroll
+  for (int q = 0; q < 3; q++) {
+    const int e = lane + 64 * q;
+    he[q] = e < nv * (nv + 1) / 2;
+    int i = (int)((sqrt(8.0 * (he[q] ? e : 0) + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= (he[q] ? e : 0)) i++;
+    while (i * (i + 1) / 2 > (he[q] ? e : 0)) i--;
+    hi[q] = i;
+    hj[q] = (he[q] ? e : 0) - i * (i + 1) / 2;
+  }
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     // gradient -> search = -grad ; Hessian = M + J^T diag(D active) J
     if (lane < nv) {
@@ -734,15 +753,19 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
       for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
       sh.search[lane] = -g;
     }
-    for (int e = lane; e < nv * (nv + 1) / 2; e += 64) {
-      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= e) i++;
-      while (i * (i + 1) / 2 > e) i--;
-      const int j = e - i * (i + 1) / 2;
-      double h = sh.M[i][j];
-      for (int r = 0; r < nrow; r++)
-        if (sh.active[r]) h += sh.J[r][i] * sh.D[r] * sh.J[r][j];
-      sh.H[i][j] = h;
+    {
+      double h[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) h[q] = he[q] ? sh.M[hi[q]][hj[q]] : 0.0;
+      for (int r = 0; r < nrow; r++) {
+        if (!sh.active[r]) continue;  // wave-uniform
+        const double d = sh.D[r];
+#pragma unroll
+        for (int q = 0; q < 3; q++) h[q] += sh.J[r][hi[q]] * d * sh.J[r][hj[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
     }
     MJS_WAVE_SYNC();
     if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
