@@ -146,15 +146,19 @@ def main():
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device=device)
 
-    # per-launch kernel time with HIP events on the launch stream (torch's current stream)
-    n_ev = min(200, max(20, args.steps))
+    # per-launch kernel time with HIP events on the launch stream (torch's current stream). Each event pair brackets a
+    # short train of back-to-back launches so that the ~4 us cost of the event records themselves is amortised and the
+    # figure is the kernel's own duration (it then agrees with rocprofv3's per-kernel average, profiles/).
+    train = 10 if not cams else 1
+    n_ev = min(40, max(4, args.steps // train))
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for i, (a, b) in enumerate(evs):
+    for g, (a, b) in enumerate(evs):
         a.record()
-        venv.step_flat(acts[i % chunk])
+        for k in range(train):
+            venv.step_flat(acts[(g * train + k) % chunk])
         b.record()
     torch.cuda.synchronize(device)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) / train
     faults = int(venv._buf["fault"].max().item())
 
     if rank == 0:
