@@ -75,6 +75,12 @@ __device__ __forceinline__ void set_contact(Rows& r, double dist, double vx, dou
 
 // value of the constraint+Gauss cost, forces and active set (mj_constraintUpdate), nv = 2,
 // M = m*I, qfrc_smooth = qacc_smooth = 0
+__device__ __forceinline__ double rsqrt_newton(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  y = y * fma(-0.5 * x * y, y, 1.5);
+  return y;
+}
 template <int NS>
 __device__ __forceinline__ double cost_update(const Rows& r, const double* jar, double ax, double ay, double Max, double May, bool* active, double* force) {
   double cost = 0;
@@ -150,13 +156,14 @@ __device__ __forceinline__ void solve(const Rows& r, double wx, double wy, doubl
         }
       }
     }
-    // Cholesky of the 2x2 Hessian, search = -H^-1 grad
+    // Cholesky of the 2x2 Hessian, search = -H^-1 grad; reciprocal square roots (v_rsq_f64 + 2 Newton steps) instead
+    // of the IEEE sqrt and five divisions, which were a quarter of the substep's instructions
     if (hxx < MJS_MINVAL) break;
-    double l00 = sqrt(hxx), l10 = hxy / l00, s = hyy - l10 * l10;
+    const double i00 = rsqrt_newton(hxx), l10 = hxy * i00, s = hyy - l10 * l10;
     if (s < MJS_MINVAL) break;
-    double l11 = sqrt(s);
-    double y0 = -gx / l00, y1 = (-gy - l10 * y0) / l11;
-    double sy = y1 / l11, sx = (y0 - l10 * sy) / l00;
+    const double i11 = rsqrt_newton(s);
+    const double y0 = -gx * i00, y1 = (-gy - l10 * y0) * i11;
+    const double sy = y1 * i11, sx = (y0 - l10 * sy) * i00;
     double Mvx = mass * sx, Mvy = mass * sy;
     double g1 = sx * Max + sy * May, g2 = sx * Mvx + sy * Mvy, snorm = sx * sx + sy * sy;
     if (sqrt(snorm) < MJS_MINVAL) break;
@@ -201,17 +208,22 @@ __device__ __forceinline__ void physics_step(State& st, double mx, double my, bo
     r.D[1] = D; r.on[1] = true; r.aref[1] = -B * (-st.vy) - K * imp * ey;
   }
   // walls: rows are active when dist < 0
-  set_contact<2>(r, (st.qx - MJS_PM_ARENA_LO) - radius, st.vx, st.vy, K, B, tran);
-  set_contact<6>(r, (st.qy - MJS_PM_ARENA_LO) - radius, st.vx, st.vy, K, B, tran);
-  set_contact<10>(r, -(st.qx - MJS_PM_ARENA_HI) - radius, st.vx, st.vy, K, B, tran);
-  set_contact<14>(r, -(st.qy - MJS_PM_ARENA_HI) - radius, st.vx, st.vy, K, B, tran);
+  const double d0 = (st.qx - MJS_PM_ARENA_LO) - radius, d1 = (st.qy - MJS_PM_ARENA_LO) - radius;
+  const double d2 = -(st.qx - MJS_PM_ARENA_HI) - radius, d3 = -(st.qy - MJS_PM_ARENA_HI) - radius;
   // Wave-uniform fast path: when no lane of this wavefront has an active wall contact, only the two
-  // weld rows exist. Row order and arithmetic are identical to the 18-slot path (inactive slots
+  // weld rows exist and the wall rows are not even instantiated (their impedance / regularisation costs three
+  // divisions per wall). Row order and arithmetic are identical to the 18-slot path (inactive slots
   // contribute nothing there), so a lane gets the same bits whichever path its wavefront takes.
-  const bool any_contact = r.on[2] || r.on[6] || r.on[10] || r.on[14];
+  const bool any_contact = d0 < 0 || d1 < 0 || d2 < 0 || d3 < 0;
   double ax, ay;
-  if (__any(any_contact)) solve<NSLOT>(r, st.wx, st.wy, mass, ax, ay);
-  else solve<2>(r, st.wx, st.wy, mass, ax, ay);
+  if (__any(any_contact)) {
+    set_contact<2>(r, d0, st.vx, st.vy, K, B, tran);
+    set_contact<6>(r, d1, st.vx, st.vy, K, B, tran);
+    set_contact<10>(r, d2, st.vx, st.vy, K, B, tran);
+    set_contact<14>(r, d3, st.vx, st.vy, K, B, tran);
+    solve<NSLOT>(r, st.wx, st.wy, mass, ax, ay);
+  } else
+    solve<2>(r, st.wx, st.wy, mass, ax, ay);
   bad = bad || bad_value(ax) || bad_value(ay) || bad_value(st.qx) || bad_value(st.qy) || bad_value(st.vx) || bad_value(st.vy);
   st.wx = ax; st.wy = ay;
   st.vx += dt * ax; st.vy += dt * ay;
