@@ -31,6 +31,9 @@ def test_static_queries(native):
     assert L.mjs_version().startswith(b"mjsim-hip")
     assert (L.mjs_obs_dim(0), L.mjs_action_dim(0), L.mjs_substeps(0)) == (4, 2, 5)
     assert (L.mjs_obs_dim(1), L.mjs_action_dim(1), L.mjs_substeps(1)) == (12, 3, 20)
+    assert (L.mjs_obs_dim(2), L.mjs_action_dim(2), L.mjs_substeps(2), L.mjs_state_dim(2)) == (9, 2, 20, 44)   # Planar-Push, 2 block slots
+    assert (L.mjs_obs_dim(3), L.mjs_action_dim(3), L.mjs_substeps(3)) == (13, 7, 20)                            # Button-Push
+    assert (L.mjs_action_dim_for(3, 0), L.mjs_action_dim_for(3, 1), L.mjs_action_dim_for(3, 2), L.mjs_action_dim_for(1, 5)) == (7, 4, -1, 3)
     assert L.mjs_obs_dim(99) == -1
     # algorithmic bytes per env-step, recomputed from the SoA layout
     assert L.mjs_algorithmic_bytes_per_env_step(0) == 8 * 13 + 8 * 11 + 2 + 16 + 32 + 25
@@ -45,7 +48,12 @@ def test_create_rejects_bad_arguments(native):
     cfg = native.MjsConfig(task=0, num_envs=0, device=0, reward_type=-1, autoreset=0)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1  # MJS_ERR_INVALID_ARG
     assert L.mjs_create(None, C.byref(h)) == -1
-    assert b"num_envs" in L.mjs_last_error(None) or b"null" in L.mjs_last_error(None)
+    cfg = native.MjsConfig(task=3, num_envs=4, device=0, reward_type=-1, autoreset=0, action_type=9)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1  # bad action_type
+    cfg = native.MjsConfig(task=2, num_envs=4, device=0, reward_type=-1, autoreset=0, n_objects=5)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"n_objects" in L.mjs_last_error(None)
+    cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=7)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"autoreset" in L.mjs_last_error(None)
 
 
 def test_no_cpu_fallback_without_gpu(native):
