@@ -624,13 +624,14 @@ struct StepInfo {
 // The function must be called by all 64 lanes of the workgroup (uniform control flow).
 constexpr int LDP = NV + 1;  // padded leading dimension in LDS
 // The cooperating lanes are ONE wavefront (several wavefronts share a workgroup only to share the instruction
-// cache): LDS operations of a wavefront execute in order, so a release/acquire fence at wavefront scope is the
-// whole synchronisation.
-#define MJS_WAVE_SYNC()                                     \
-  do {                                                      \
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  \
-    __builtin_amdgcn_wave_barrier();                        \
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  \
+// cache). A wavefront's LDS instructions execute in program order, so the only things a "sync" has to do are (1) keep
+// the COMPILER from moving one lane's LDS load above another lane's earlier store and (2) drain the LDS queue. A
+// release/acquire fence pair also waited for every outstanding scratch/global access (s_waitcnt vmcnt(0)) at each of
+// the ~60 syncs of a solve; an explicit lgkmcnt wait with a compiler memory barrier does not.
+#define MJS_WAVE_SYNC()                                          \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_wave_barrier();                             \
   } while (0)
 struct CoopLds {
   double J[MAXROW][LDP], D[MAXROW], aref[MAXROW], jar[MAXROW], jv[MAXROW], force[MAXROW];
@@ -658,7 +659,7 @@ MJS_DEV double wave_sum(double x) {
 // in-place Cholesky of sh.H (lower; the diagonal ends up holding RECIPROCALS) fused with the forward substitution,
 // then the backward substitution: H x = b for x in `vec` (LDS), all lanes. A wavefront's LDS instructions execute in
 // program order, so the syncs only have to stop the COMPILER from moving one lane's load above another lane's store.
-MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
+MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane, const int* hi, const int* hj, const bool* he) {
   bool ok = true;
   for (int j = 0; j < nv; j++) {
     const double d = sh.H[j][j];  // every lane reads the same value
@@ -667,15 +668,11 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
     if (lane > j && lane < nv) sh.H[lane][j] = sh.H[lane][j] * inv;
     if (lane == 0) { sh.H[j][j] = inv; vec[j] = vec[j] * inv; }  // y_j
     MJS_WAVE_SYNC();
-    // trailing update (pairs (i, k), j < k <= i < nv) and forward elimination of the right-hand side
-    const int m = nv - j - 1;
-    for (int e = lane; e < m * (m + 1) / 2; e += 64) {
-      int i = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
-      while ((i + 1) * (i + 2) / 2 <= e) i++;
-      while (i * (i + 1) / 2 > e) i--;
-      const int k = e - i * (i + 1) / 2;
-      sh.H[j + 1 + i][j + 1 + k] -= sh.H[j + 1 + i][j] * sh.H[j + 1 + k][j];
-    }
+    // trailing update of this lane's own entries (r, c) of the lower triangle with c > j, and forward elimination
+    // of the right-hand side
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+      if (he[q] && hj[q] > j) sh.H[hi[q]][hj[q]] -= sh.H[hi[q]][j] * sh.H[hj[q]][j];
     if (lane > j && lane < nv) vec[lane] -= sh.H[lane][j] * vec[j];
     MJS_WAVE_SYNC();  // the next column reads what other lanes just updated
   }
@@ -768,7 +765,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
         if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
     }
     MJS_WAVE_SYNC();
-    if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
+    if (!coop_chol_solve(sh, nv, sh.search, lane, hi, hj, he)) break;
     if (lane < nv) {
       double m = 0;
       for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
