@@ -29,12 +29,12 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def measured_traffic(task, n_local):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic.json: rocprofv3 --pmc
-    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, FETCH corrected x2 per the gfx950
-    calibration). Only valid for the configuration it was measured on; otherwise None."""
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic_all_tasks.json: rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate runs of this very command, FETCH corrected per the gfx950 calibration of
+    profiles/r01_traffic.json). Only valid for the configuration it was measured on; otherwise None."""
     try:
-        d = json.load(open(ROOT / "profiles" / "r01_traffic.json"))
-        if task == "robot_reach" and n_local == 4096:
+        d = json.load(open(ROOT / "profiles" / "r01_traffic_all_tasks.json"))["tasks"][task]
+        if n_local == d["envs"]:
             return d["corrected_bytes_per_launch"]["total"]
     except Exception:  # noqa: BLE001
         pass
