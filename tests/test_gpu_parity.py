@@ -783,3 +783,32 @@ def test_planar_push_camera_matches_oracle(oracle_mod):
     assert list(obs) == ["ur5e/tcp_position", "Camera/rgb_image"] and obs["Camera/rgb_image"].shape == (4, 64, 64, 3)
     assert obs["Camera/rgb_image"].float().std() > 10
     vis.close()
+
+
+def test_every_registered_env_runs_a_random_policy_to_the_end():
+    """test/test_gym_envs.py:7-18 (test_env_w_random_policy) and :21-36 (test_determinism_of_env) over every registered id:
+    an episode under the task's own random policy ends (terminated or truncated) within the step limit; seeded resets
+    repeat and differ between seeds."""
+    import mujoco_sim_amd as m
+
+    limits = {"point_mass": 51, "robot_reach": 100, "robot_push_button": 100, "robot_planar_push": 500}
+    for env_id in sorted(m.registry):
+        kwargs = {"max_control_steps_per_episode": 40} if "planar_push" in env_id else {}
+        env = m.make(env_id, **kwargs)
+        env.seed(2025)
+        obs, _ = env.reset()
+        env.seed(2025)
+        obs2, _ = env.reset()
+        env.seed(2024)
+        obs3, _ = env.reset()
+        state_keys = [k for k in obs if "image" not in k]
+        assert all(np.allclose(obs[k], obs2[k], atol=1e-6) for k in obs)
+        assert not all(np.allclose(obs[k], obs3[k], atol=1e-6) for k in state_keys if "active" not in k)
+        policy = env.dmc_env.task.create_random_policy()
+        limit = 40 if "planar_push" in env_id else next(v for k, v in limits.items() if k in env_id)
+        done, n = False, 0
+        while not done and n <= limit:
+            obs, reward, term, trunc, info = env.step(policy(None))
+            done, n = bool(term or trunc), n + 1
+        assert done and n <= limit, (env_id, n)
+        env.close()

@@ -469,3 +469,17 @@ def test_planar_push_step_limit_truncates(oracle_mod):
         r = b.step(hold)
         assert (r["step_type"][0] == 2) == (t == 6)
     assert r["truncated"][0] and not r["terminated"][0] and r["discount"][0] == 1.0
+
+
+def test_joint_space_move_converges_like_reference_test(oracle_mod):
+    """test/test_ur_control_api.py:7-28 (test_moveJ) re-expressed on the path the tasks use: a joint-space target
+    (the reference's home pose, robot.py:307) commanded through servoJ control step after control step is reached within
+    the reference's own tolerance 1e-2 rad (position servos + gripper payload sag)."""
+    target = np.array([0.0, -0.5, 0.5, -0.5, -0.5, -0.5]) * np.pi
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, 3, 12, action_type=0)
+    r = b.reset()
+    a = np.tile(np.concatenate([target, [0.0]]), (3, 1))
+    for _ in range(40):
+        r = b.step(a)
+    assert np.abs(r["obs"][:, :6] - target).max() < 1e-2
+    assert not r["fault"].any()
