@@ -293,6 +293,23 @@ MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
   }
   return fs;
 }
+// convex pairs of the scene in MuJoCo's pair order: wrist proxy - block b (2 slots), EEF - block b (2), block 0 - block 1
+constexpr int NCVX = 2 * NB + 1;
+struct ConvexHits {
+  bool hit[NCVX];
+  double dist[NCVX];
+  V3 pos[NCVX], n[NCVX];
+};
+MJS_DEV void convex_slot(const Geom& g1, const Geom& g2, ConvexHits& h, int k) {  // k is a compile-time constant at every call site
+  h.hit[k] = false; h.dist[k] = 0; h.pos[k] = v3(0, 0, 0); h.n[k] = v3(0, 0, 1);
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return;
+  double depth;
+  V3 nn, pp_;
+  if (!mpr_penetration(g1, g2, depth, nn, pp_)) return;
+  h.hit[k] = true; h.dist[k] = -depth; h.pos[k] = pp_; h.n[k] = nn;
+}
 MJS_DEV bool convex_penetrating(const Geom& g1, const Geom& g2) {  // an ACTIVE contact (dist < 0) between two convex geoms?
   const V3 diff = sub_nc(g2.c, g1.c);
   const double bound = rbound(g1) + rbound(g2);
@@ -656,33 +673,53 @@ MJS_DEV double wave_sum(double x) {
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
   return x;
 }
-// in-place Cholesky of sh.H (lower; the diagonal ends up holding RECIPROCALS) fused with the forward substitution,
-// then the backward substitution: H x = b for x in `vec` (LDS), all lanes. A wavefront's LDS instructions execute in
-// program order, so the syncs only have to stop the COMPILER from moving one lane's load above another lane's store.
-MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane, const int* hi, const int* hj, const bool* he) {
+// wave broadcast of a double from a compile-time lane
+MJS_DEV double bcast(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+// Solve H x = b (H = sh.H, lower triangle, SPD; b and x in `vec`, LDS) with the factorisation in REGISTERS: lane i owns
+// row i of H; the pivot, the column-j entries of the other rows and the right-hand side travel by v_readlane
+// broadcasts (all lane indices are compile-time constants of the unrolled loops), so the 153 trailing updates and
+// the forward substitution touch no memory. The rows of L then go to LDS once and every lane fetches its column of
+// L for the backward substitution. Rows >= nv are identity padding (one block instead of two).
+MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
+  double row[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) row[j] = (lane < nv && j <= lane) ? sh.H[lane < NV ? lane : 0][j] : (j == lane ? 1.0 : 0.0);
+  double b = lane < nv ? vec[lane < NV ? lane : 0] : 0.0;
   bool ok = true;
-  for (int j = 0; j < nv; j++) {
-    const double d = sh.H[j][j];  // every lane reads the same value
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const double d = bcast(row[j], j);
     if (d < MJS_MINVAL) ok = false;
     const double inv = rr::rsqrt_fast(fmax(d, MJS_MINVAL));
-    if (lane > j && lane < nv) sh.H[lane][j] = sh.H[lane][j] * inv;
-    if (lane == 0) { sh.H[j][j] = inv; vec[j] = vec[j] * inv; }  // y_j
-    MJS_WAVE_SYNC();
-    // trailing update of this lane's own entries (r, c) of the lower triangle with c > j, and forward elimination
-    // of the right-hand side
+    row[j] = lane == j ? inv : row[j] * inv;  // L_ij for the rows below; the pivot row keeps 1 / L_jj
+    const double yj = bcast(b, j) * inv;      // forward substitution fused in
+    b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
 #pragma unroll
-    for (int q = 0; q < 3; q++)
-      if (he[q] && hj[q] > j) sh.H[hi[q]][hj[q]] -= sh.H[hi[q]][j] * sh.H[hj[q]][j];
-    if (lane > j && lane < nv) vec[lane] -= sh.H[lane][j] * vec[j];
-    MJS_WAVE_SYNC();  // the next column reads what other lanes just updated
+    for (int k = j + 1; k < NV; k++) {
+      const double lkj = bcast(row[j], k);
+      if (lane >= k) row[k] -= row[j] * lkj;
+    }
   }
-  for (int k = nv - 1; k >= 0; k--) {  // backward substitution with L^T: one sync per step
-    const double xk = vec[k] * sh.H[k][k];  // same value on every lane
-    MJS_WAVE_SYNC();
-    if (lane == k) vec[k] = xk;
-    if (lane < k) vec[lane] -= sh.H[k][lane] * xk;
-    MJS_WAVE_SYNC();
+  // rows of L to LDS, then each lane reads its column: L[k][lane], k > lane
+  if (lane < NV) {
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (j <= lane) sh.H[lane][j] = row[j];
   }
+  MJS_WAVE_SYNC();
+  double col[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) col[k] = (lane < NV && k > lane) ? sh.H[k][lane < NV ? lane : 0] : 0.0;
+#pragma unroll
+  for (int k = NV - 1; k >= 0; k--) {
+    const double xk = bcast(b, k) * bcast(row[k], k);  // y_k / L_kk
+    b = lane == k ? xk : (lane < k ? b - col[k] * xk : b);
+  }
+  if (lane < nv) vec[lane] = b;
+  MJS_WAVE_SYNC();
   return ok;
 }
 // cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
@@ -765,7 +802,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
         if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
     }
     MJS_WAVE_SYNC();
-    if (!coop_chol_solve(sh, nv, sh.search, lane, hi, hj, he)) break;
+    if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
     if (lane < nv) {
       double m = 0;
       for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
@@ -822,28 +859,32 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
   MJS_WAVE_SYNC();
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
-__device__ __noinline__ void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb) {
+__device__ __noinline__ void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
+                                             const FloorSlots fs0, const FloorSlots fs1, const ConvexHits cvx, const M3 R0, const M3 R1) {
   CoopLds& sh = coop_lds();
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
-  M3 Rb[NB];
+  const M3 Rb[NB] = {R0, R1};
+  // contact list in MuJoCo's pair order from the hot path's static slots (no second collision pass)
+  int ncon = 0;
+  auto put = [&](double dist, V3 pos, V3 n, int ba, int bb, double tran) {
+    sh.c_ba[ncon] = ba; sh.c_bb[ncon] = bb; sh.c_act[ncon] = dist < 0.0;
+    sh.c_dist[ncon] = dist; sh.c_tran[ncon] = tran;
+    sh.c_pos[ncon][0] = pos.x; sh.c_pos[ncon][1] = pos.y; sh.c_pos[ncon][2] = pos.z;
+    sh.c_n[ncon][0] = n.x; sh.c_n[ncon][1] = n.y; sh.c_n[ncon][2] = n.z;
+    ncon++;
+  };
   for (int b = 0; b < nb; b++) {
-    double qn[4];
-    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
-    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
-    Rb[b] = quat_to_m3(qn);
+    const FloorSlots& f = b == 0 ? fs0 : fs1;
+    for (int k = 0; k < 4; k++)  // only ACTIVE corners make rows (a corner exactly on the floor is detected but inactive)
+      if (f.on[k]) put(f.dist[k], f.r[k] + s.b[b].p, v3(0, 0, 1), 0, 2 + b, 1.0 / MJS_BLOCK_MASS);
   }
-  Contact con[MAXCON];
-  int extra;
-  bool eef_floor;
-  const int ncon = detect_contacts(ch, s, Rb, nb, con, extra, eef_floor);
+  for (int b = 0; b < nb; b++)
+    if (cvx.hit[b]) put(cvx.dist[b], cvx.pos[b], cvx.n[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+  for (int b = 0; b < nb; b++)
+    if (cvx.hit[NB + b]) put(cvx.dist[NB + b], cvx.pos[NB + b], cvx.n[NB + b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+  if (nb > 1 && cvx.hit[2 * NB]) put(cvx.dist[2 * NB], cvx.pos[2 * NB], cvx.n[2 * NB], 2, 3, 2.0 / MJS_BLOCK_MASS);
   sh.ncon = ncon;
-  for (int c = 0; c < ncon; c++) {
-    sh.c_ba[c] = con[c].ba; sh.c_bb[c] = con[c].bb; sh.c_act[c] = con[c].dist < 0.0;
-    sh.c_dist[c] = con[c].dist; sh.c_tran[c] = con[c].tran;
-    sh.c_pos[c][0] = con[c].pos.x; sh.c_pos[c][1] = con[c].pos.y; sh.c_pos[c][2] = con[c].pos.z;
-    sh.c_n[c][0] = con[c].n.x; sh.c_n[c][1] = con[c].n.y; sh.c_n[c][2] = con[c].n.z;
-  }
   for (int j = 0; j < NJ; j++) {
     const V3 a = rr::joint_axis(ch, j), p = ch.p[j + 1];
     sh.ax[j][0] = a.x; sh.ax[j][1] = a.y; sh.ax[j][2] = a.z;
@@ -952,7 +993,8 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
   }
   if (lane == 0) sh.nrow = nlim + 6 * nact;
 }
-MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info) {
+MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
+                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
   CoopLds& sh = coop_lds();
   const int lane = threadIdx.x & 63, nv = NJ + 6 * nb;
   const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
@@ -964,7 +1006,7 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
-    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb);
+    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs[0], fs[1], cvx, Rb[0], Rb[1]);
     MJS_WAVE_SYNC();
     PP_ACC(info, 5, tp);
     coop_build_rows(sh, nb, lane);
@@ -986,6 +1028,8 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   double Marm[21], qacc[NV];
   int clamped = 0;
   bool coupled = false;
+  ConvexHits cvx;
+  FloorSlots fs[NB];
   M3 Rb[NB];
   unsigned long long tt = 0;
   PP_TIC(tt);
@@ -1002,7 +1046,6 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   }
   // contacts (static slots): floor corners per block; is any arm-block / block-block pair penetrating?
   Geom bg[NB];
-  FloorSlots fs[NB];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     bg[b] = block_geom(s.b[b], Rb[b]);
@@ -1013,9 +1056,13 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
     info.unsupported = info.unsupported || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);  // EEF cylinder below the floor (D-8)
 #pragma unroll
+    for (int k = 0; k < NCVX; k++) { cvx.hit[k] = false; cvx.dist[k] = 0; cvx.pos[k] = v3(0, 0, 0); cvx.n[k] = v3(0, 0, 1); }
+#pragma unroll
     for (int b = 0; b < NB; b++)
-      if (b < nb) coupled = coupled || convex_penetrating(wg, bg[b]) || convex_penetrating(eg, bg[b]);
-    if (nb > 1) coupled = coupled || convex_penetrating(bg[0], bg[1]);
+      if (b < nb) { convex_slot(wg, bg[b], cvx, b); convex_slot(eg, bg[b], cvx, NB + b); }
+    if (nb > 1) convex_slot(bg[0], bg[1], cvx, 2 * NB);
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) coupled = coupled || (cvx.hit[k] && cvx.dist[k] < 0.0);
   }
   PP_ACC(info, 0, tt);
   // arm smooth dynamics
@@ -1050,7 +1097,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   }
   }  // live
   PP_ACC(info, 2, tt);
-  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info);  // all lanes
+  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
