@@ -859,8 +859,8 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
   MJS_WAVE_SYNC();
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
-__device__ __noinline__ void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
-                                             const FloorSlots fs0, const FloorSlots fs1, const ConvexHits cvx, const M3 R0, const M3 R1) {
+MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
+                             const FloorSlots& fs0, const FloorSlots& fs1, const ConvexHits& cvx, const M3& R0, const M3& R1) {
   CoopLds& sh = coop_lds();
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
