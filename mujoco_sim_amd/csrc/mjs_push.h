@@ -411,7 +411,7 @@ MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
 // constant (n = +z, t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)), so a row is (F, (axis_d x r) . F) for the three
 // frame vectors F and (0, axis_d . n) for the torsional row. `Mb`: the block's 6x6 mass matrix (lower triangle used),
 // `f`: qfrc_smooth of the block in, qfrc_smooth + qfrc_constraint out.
-__device__ __noinline__ void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
+MJS_DEV void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
                                                double* f) {
   const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};  // max(block, floor) per component
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
