@@ -49,6 +49,28 @@ class PointMassReachTask:
 
         return random_policy
 
+    # point_reach.py:227-240 (the reference spells it `create_demonstation_policy`; both names are provided)
+    def demonstration_actions(self, venv, noise: float = 0.0):
+        """Batched form for a HipVectorEnv of this task: the step towards the goal, rescaled so that its largest
+        component is MAX_STEP_SIZE (optionally multiplied by 1 + N(0, noise) first, as the reference does)."""
+        import torch
+
+        obs = venv.flat_obs  # [N, 4] = pointmass position (2), goal position (2)
+        action = obs[:, 2:4] - obs[:, 0:2]
+        if noise > 0:
+            action = action * (1 + noise * torch.randn_like(action))
+        return action * (MAX_STEP_SIZE / action.abs().amax(dim=1, keepdim=True).clamp_min(1e-300))
+
+    def create_demonstration_policy(self, environment, noise: float = 0.0):
+        venv = environment._venv if hasattr(environment, "_venv") else environment
+
+        def policy(time_step=None):
+            return self.demonstration_actions(venv, noise)[0].cpu().numpy().astype(np.float32)
+
+        return policy
+
+    create_demonstation_policy = create_demonstration_policy
+
 
 class BoundedArraySpec:
     """Stand-in for dm_env.specs.BoundedArray (shape, dtype, minimum, maximum)."""
