@@ -42,6 +42,9 @@ class HipSB3VecEnv(_Base):
             self.num_envs, self.observation_space, self.action_space = num_envs, obs_space, act_space
         self.render_mode = None
         self._actions = None
+        # VecMonitor-equivalent episode statistics (what SB3's Monitor wrapper of scripts/sb3/reach_sac.py:77 reports)
+        self._ep_return = np.zeros(num_envs, dtype=np.float64)
+        self._ep_length = np.zeros(num_envs, dtype=np.int64)
         self._lo = torch.as_tensor(np.asarray(self.venv.action_low), dtype=torch.float64, device=self.venv.device)
         self._hi = torch.as_tensor(np.asarray(self.venv.action_high), dtype=torch.float64, device=self.venv.device)
 
@@ -58,6 +61,8 @@ class HipSB3VecEnv(_Base):
 
     def reset(self):
         self.venv.reset()
+        self._ep_return[:] = 0
+        self._ep_length[:] = 0
         return self._obs_numpy(self.venv.flat_obs)
 
     def step_async(self, actions):
@@ -73,11 +78,16 @@ class HipSB3VecEnv(_Base):
         success = b["is_success"].cpu().numpy()
         dones = terminated | truncated
         infos = [{"is_success": float(success[i])} for i in range(self.num_envs)]
+        self._ep_return += reward
+        self._ep_length += 1
         if dones.any():
             term_obs = b["terminal_obs"].cpu().numpy()
             for i in np.nonzero(dones)[0]:
                 infos[i]["terminal_observation"] = OrderedDict((k, term_obs[i, s:s + n].copy()) for k, s, n in self.venv._state_layout)
                 infos[i]["TimeLimit.truncated"] = bool(truncated[i] and not terminated[i])
+                infos[i]["episode"] = {"r": float(self._ep_return[i]), "l": int(self._ep_length[i])}  # Monitor's keys
+                self._ep_return[i] = 0
+                self._ep_length[i] = 0
         return obs, reward, dones, infos
 
     def step(self, actions):

@@ -215,10 +215,12 @@ def test_sb3_vec_env_surface(oracle_mod):
     assert np.allclose(np.concatenate([obs[k] for k in obs], axis=1), o["obs"], atol=ATOL)
     rs = np.random.RandomState(0)
     n_done = 0
+    returns = np.zeros(N)
     for t in range(12):
         a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N, 3))
         obs, rew, dones, infos = env.step(a)
         o = ob.step(a)
+        returns += o["reward"]
         assert obs["ur5e/tcp_position"].dtype == np.float64 and rew.dtype == np.float32 and dones.dtype == bool
         assert np.allclose(np.concatenate([obs[k] for k in obs], axis=1), o["obs"], atol=ATOL)
         assert np.array_equal(dones, o["truncated"] | o["terminated"])
@@ -226,6 +228,8 @@ def test_sb3_vec_env_surface(oracle_mod):
             if dones[i]:
                 n_done += 1
                 assert infos[i]["TimeLimit.truncated"] is True
+                assert infos[i]["episode"]["l"] == 5 and abs(infos[i]["episode"]["r"] - returns[i]) < 1e-5  # Monitor-style stats
+                returns[i] = 0
                 term = np.concatenate([infos[i]["terminal_observation"][k] for k in obs])
                 assert np.allclose(term, o["terminal_obs"][i], atol=ATOL)
             else:
