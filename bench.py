@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button", "robot_planar_push"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--n-objects", type=int, default=2, help="Planar-Push blocks: 2 = BASELINE config 4, 5 = the reference's dataclass default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
     ap.add_argument("--visual", type=int, default=0, metavar="RES",
@@ -87,13 +88,13 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MJS_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(task, n_envs, seconds):
+def cpu_baseline(task, n_envs, seconds, n_objects=2):
     import oracle
 
     tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH,
            "robot_planar_push": oracle.TASK_PLANAR_PUSH}[task]
     cores = host_cores()
-    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores)
+    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores, **({"n_objects": n_objects} if task == "robot_planar_push" else {}))
     b.reset()
     acts = make_actions(task, 8, n_envs, "cpu", 12345).numpy()
     b.step(acts[0])  # warm
@@ -122,7 +123,8 @@ def main():
 
     n_local = args.envs_per_gpu
     n_global = n_local * world
-    venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant)
+    extra = {"n_objects": args.n_objects} if args.task == "robot_planar_push" else {}
+    venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant, **extra)
     venv.reset()
     chunk = 64  # distinct action slabs resident in HBM, cycled
     acts = make_actions(args.task, chunk, n_local, device, 12345 + rank)
@@ -170,7 +172,7 @@ def main():
         line = {
             "metric": {"robot_reach": "env-steps/sec at N_envs=4096, Robot-Reach", "point_mass_reach": "env-steps/sec, Pointmass-Reach",
                        "robot_push_button": "env-steps/sec, Button-Push (state obs)",
-                       "robot_planar_push": "env-steps/sec, Planar-Push, 2 objects (state obs)"}[args.task],
+                       "robot_planar_push": f"env-steps/sec, Planar-Push, {args.n_objects} objects (state obs)"}[args.task],
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
@@ -179,7 +181,7 @@ def main():
                                    + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "traffic": None if (args.task == "robot_planar_push" and args.n_objects != 2) else measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }
@@ -193,7 +195,7 @@ def main():
             line["roofline"]["valu_fp64"] = {"flops_per_env_step": flops, "achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
                                              "simds_occupied_frac": min(1.0, 2 * (n_local / 64) / 1024)}
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds)
+            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects)
         print(json.dumps(line))
     venv.close()
     if torch.distributed.is_initialized():

@@ -219,7 +219,10 @@ MJS_K double MJS_BP_CAM_FOVY = 70.0;
  * mjcf/google_language_table_blocks/cube.{xml,obj}. The block is a bevelled-cube MESH in the reference (bounding box
  * x,z in +-0.019826, y in [0, 0.0381], geom quat (1,1,0,0): mesh y -> body z, body origin = centre of the bottom face);
  * here it is a BOX of that bounding box (deviation D-9). */
-MJS_K int    MJS_PP_MAX_OBJECTS = 2;              /* BASELINE config 4: 2 objects (reference default n_objects = 5) */
+MJS_K int    MJS_PP_MAX_OBJECTS = 5;              /* :61 reference default n_objects = 5 */
+MJS_K int    MJS_PP_FAST_OBJECTS = 2;             /* :315 registered env / BASELINE config 4: 2 objects. Engines keep two
+                                                   * layouts: block slots = 2 for n_objects <= 2, 5 otherwise */
+#define MJS_PP_OBJECT_SLOTS(n) ((n) <= MJS_PP_FAST_OBJECTS ? MJS_PP_FAST_OBJECTS : MJS_PP_MAX_OBJECTS)
 MJS_K int    MJS_PP_MAX_CONTROL_STEPS = 500;      /* :53 */
 MJS_K double MJS_PP_TARGET_RADIUS = 0.05;         /* :60 */
 MJS_K double MJS_PP_NEAREST_COEF = 0.1;           /* :59 */
@@ -307,7 +310,7 @@ MJS_K float MJS_CAM_BODY_RGB[3] = {0.0f, 0.0f, 0.0f};
 MJS_K float MJS_CYL_RGB[3] = {0.2f, 0.2f, 0.2f};
 MJS_K float MJS_PP_TARGET_RGB[3] = {1.0f, 1.0f, 1.0f};
 MJS_K float MJS_PP_TARGET_HALF_HEIGHT = 0.001f;
-MJS_K float MJS_BLOCK_RGB[2][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}};
+MJS_K float MJS_BLOCK_RGB[5][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.5f, 0.0f}};
 /* [REF] empty_robot_arena.py:24-26: six positional lights at (x, +-x, 3), x in {-3, 3, 0.5} */
 MJS_K float MJS_RR_LIGHT_POS[6][3] = {{-3.0f, -3.0f, 3.0f}, {-3.0f, 3.0f, 3.0f}, {3.0f, 3.0f, 3.0f},
                                       {3.0f, -3.0f, 3.0f},  {0.5f, 0.5f, 3.0f},  {0.5f, -0.5f, 3.0f}};

@@ -71,7 +71,8 @@ typedef struct {
   int32_t action_type;          /* MJS_ACTION_* (Button-Push only) */
   int32_t button_disturbances;  /* Button-Push only: after each control step an active, released switch is
                                  * deactivated with probability 0.01 from the env's stream (robot_push_button.py:159-165) */
-  int32_t n_objects;            /* Planar-Push only: number of blocks, 1..2 (<= 0: 2, BASELINE config 4) */
+  int32_t n_objects;            /* Planar-Push only: number of blocks, 1..5 (robot_planar_push.py:61; <= 0: 2 = the registered env, :315,
+                                 * and BASELINE config 4). 1..2 run the 2-slot kernel, 3..5 the 5-slot kernel */
   int32_t max_episode_steps;    /* Planar-Push only: RobotTask step limit (tasks/base.py:47-51); <= 0: 500 */
 } mjs_config;
 
@@ -108,6 +109,10 @@ int mjs_action_dim(int task);
 int mjs_action_dim_for(int task, int action_type);
 /* number of float64 per env in mjs_get_state / mjs_set_state */
 int mjs_state_dim(int task);
+/* the same two widths for a created handle: Planar-Push with n_objects 3..5 uses 5 block slots
+ * (obs 5 + 2*5 = 15, state 1 + 17 + 13*5 = 83); the per-task queries above describe the 2-slot layout */
+int mjs_env_obs_dim(const mjs_handle* h);
+int mjs_env_state_dim(const mjs_handle* h);
 /* algorithmic HBM bytes one env-step moves (state R+W, action, outputs), from the real layout */
 int mjs_algorithmic_bytes_per_env_step(int task);
 /* physics substeps per control step: 5 (point_reach.py:24-25) / 20 (robot_reach.py:62-63, robot_planar_push.py:51-52,

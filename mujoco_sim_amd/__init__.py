@@ -56,7 +56,7 @@ registry = {
     "mujoco_sim/robot_push_button_visual-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
                                                {"observation_type": RobotPushButtonTask.VISUAL_OBS, "image_resolution": 96,
                                                 "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
-    "mujoco_sim/robot_planar_push_state-v0": (_make_robot_planar_push_env, {}),
+    "mujoco_sim/robot_planar_push_state-v0": (_make_robot_planar_push_env, {"n_objects": 2}),  # robot_planar_push.py:315 / BASELINE config 4
     "mujoco_sim/robot_push_button_state-v0": (partial(make_point_mass_reach_env, RobotPushButtonTask, max_steps=100),
                                               {"observation_type": RobotPushButtonTask.STATE_OBS, "action_type": RobotPushButtonTask.ABS_JOINT_ACTION}),
 }

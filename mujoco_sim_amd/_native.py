@@ -24,7 +24,7 @@ AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
 
 EXPORTED_SYMBOLS = [
-    "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_action_dim_for", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
+    "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_action_dim_for", "mjs_state_dim", "mjs_env_obs_dim", "mjs_env_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
     "mjs_create", "mjs_destroy", "mjs_last_error", "mjs_seed", "mjs_reset", "mjs_step", "mjs_rollout",
     "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik", "mjs_ur5e_tcp_to_joints",
 ]
@@ -85,6 +85,9 @@ def lib() -> C.CDLL:
     L.mjs_version.restype = C.c_char_p
     for name in ("mjs_obs_dim", "mjs_action_dim", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps"):
         getattr(L, name).argtypes = [C.c_int]
+        getattr(L, name).restype = C.c_int
+    for name in ("mjs_env_obs_dim", "mjs_env_state_dim"):
+        getattr(L, name).argtypes = [C.c_void_p]
         getattr(L, name).restype = C.c_int
     L.mjs_action_dim_for.argtypes = [C.c_int, C.c_int]
     L.mjs_action_dim_for.restype = C.c_int

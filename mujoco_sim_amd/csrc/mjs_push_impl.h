@@ -1,0 +1,1394 @@
+// mjs_push_impl.h — Robot Planar-Push fused control-step kernel (BASELINE config 4: the contact-solver path).
+// Included by mjs_push.h once per block-slot count (MJS_PP_NS = namespace, MJS_PP_NB = slots): `pp` with 2 slots
+// (n_objects <= 2, the registered env and BASELINE config 4) and `pp5` with 5 (the reference's dataclass default).
+//
+// Path replaced (reference, paths under /root/reference/mujoco_sim/; INTENDED semantics where the reference is
+// broken at HEAD):
+//   environments/tasks/robot_planar_push.py:185-201 before_step (episode_step += 1, servoL to (ax, ay, 0.02)),
+//   per substep robot.py:261-263 servo interpolation + Physics.step() on the scene of :81-117 (UR5e + CylinderEEF +
+//   n free blocks on the floor), :203-241 + tasks/base.py:47-57 reward / accomplished / step limit / discount,
+//   :149-176 initialize_episode (robot, target, blocks re-drawn until nothing touches, 150 settle steps).
+// Deviation D-9: the blocks are BOXES of the cube mesh's bounding box (google_block.py loads a bevelled-cube mesh);
+// convex pairs (cylinder-box, box-box) go through an own MPR (role of mjc_Convex -> libccd), one contact per pair;
+// box-floor gives up to 4 corner contacts. Contacts are condim 4 (block) pyramids: 6 rows each.
+//
+// First correct version: lane per env, one wavefront per 64 envs, generic dense in-lane Newton over nv = 6 + 6 n
+// dofs with the rows in per-lane scratch arrays. The arm's M and bias come from the generated code (ur5e_pp_*),
+// the free blocks' from closed forms. Collision arithmetic is + - * / sqrt without FMA contraction so that contact
+// sets match the CPU restatement bit for bit.
+namespace MJS_PP_NS {
+
+using rr::NJ;
+constexpr int NB = MJS_PP_NB, NV = NJ + 6 * NB;
+constexpr int OBS_DIM = 5 + 2 * NB, ACT_DIM = 2;
+// state rows (float64 SoA): arm q, v, time, target xyz, episode_step, then per block pos3 quat4 vel6
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK = 17, BLOCK_DIM = 13;
+constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
+constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
+constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
+
+struct Block {
+  V3 p;          // body origin = centre of the bottom face (free joint qpos[0:3])
+  double q[4];   // orientation (w, x, y, z)
+  V3 v, w;       // linear velocity of the origin (world), angular velocity (body frame)
+};
+struct World {
+  double q[NJ], v[NJ], time, target[3], episode_step;
+  Block b[NB];
+};
+
+MJS_DEV World load_world(const KernelParams& p, int i) {
+  World s;
+  const size_t N = p.N;
+  const double* st = p.state + i;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { s.q[j] = st[(S_Q + j) * N]; s.v[j] = st[(S_V + j) * N]; }
+  s.time = st[S_TIME * N];
+#pragma unroll
+  for (int k = 0; k < 3; k++) s.target[k] = st[(S_TARGET + k) * N];
+  s.episode_step = st[S_STEP * N];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const double* bs = st + (size_t)(S_BLOCK + BLOCK_DIM * b) * N;
+    s.b[b].p = v3(bs[0], bs[N], bs[2 * N]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) s.b[b].q[k] = bs[(3 + k) * N];
+    s.b[b].v = v3(bs[7 * N], bs[8 * N], bs[9 * N]);
+    s.b[b].w = v3(bs[10 * N], bs[11 * N], bs[12 * N]);
+  }
+  return s;
+}
+MJS_DEV void store_world(const KernelParams& p, int i, const World& s) {
+  const size_t N = p.N;
+  double* st = p.state + i;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st[(S_Q + j) * N] = s.q[j]; st[(S_V + j) * N] = s.v[j]; }
+  st[S_TIME * N] = s.time;
+#pragma unroll
+  for (int k = 0; k < 3; k++) st[(S_TARGET + k) * N] = s.target[k];
+  st[S_STEP * N] = s.episode_step;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    double* bs = st + (size_t)(S_BLOCK + BLOCK_DIM * b) * N;
+    bs[0] = s.b[b].p.x; bs[N] = s.b[b].p.y; bs[2 * N] = s.b[b].p.z;
+#pragma unroll
+    for (int k = 0; k < 4; k++) bs[(3 + k) * N] = s.b[b].q[k];
+    bs[7 * N] = s.b[b].v.x; bs[8 * N] = s.b[b].v.y; bs[9 * N] = s.b[b].v.z;
+    bs[10 * N] = s.b[b].w.x; bs[11 * N] = s.b[b].w.y; bs[12 * N] = s.b[b].w.z;
+  }
+}
+
+MJS_DEV M3 quat_to_m3(const double* q) {  // unit quaternion -> rotation (columns = body axes in the world)
+  const double w = q[0], x = q[1], y = q[2], z = q[3];
+  return M3{v3(1 - 2 * (y * y + z * z), 2 * (x * y + z * w), 2 * (x * z - y * w)), v3(2 * (x * y - z * w), 1 - 2 * (x * x + z * z), 2 * (y * z + x * w)),
+            v3(2 * (x * z + y * w), 2 * (y * z - x * w), 1 - 2 * (x * x + y * y))};
+}
+MJS_DEV V3 rot(const M3& R, V3 a) { return madd(madd(a.x * R.cx, a.y, R.cy), a.z, R.cz); }
+MJS_DEV V3 rot_t(const M3& R, V3 a) { return v3(dot(R.cx, a), dot(R.cy, a), dot(R.cz, a)); }
+
+// ------------------------------------------------------------------------------------------------ collision
+// Same operations, in the same order, as oracle/om_engine.c (collide_plane box branch, mpr_penetration): the two
+// sides are written independently but must take the same branches, hence no FMA contraction here.
+#pragma clang fp contract(off)
+
+// biased tie-break thresholds, identical to oracle/om_engine.c (see the comment there)
+constexpr double MPR_EPS_DIR = 1e-10, MPR_EPS_LEN = 1e-13, MPR_EPS_VOL = 1e-16;
+
+struct Geom {  // a convex collision geom in the world: box (half extents s) or cylinder (radius s.x, half length s.y)
+  V3 c;
+  M3 R;
+  V3 s;
+  bool box;
+};
+struct Contact {
+  double dist;
+  V3 pos, n;
+  int ba, bb;  // bodies: 0 = world, 1 = arm (a geom welded to link 6), 2 + i = block i; normal points from a to b
+  double tran; // body_invweight0 (translation) of the two bodies, summed: diagApprox of the pyramid rows
+};
+
+MJS_DEV V3 support(const Geom& g, V3 dir) {
+  const V3 loc = rot_t(g.R, dir);
+  V3 res;
+  if (g.box) {
+    res = v3(loc.x >= -MPR_EPS_DIR ? g.s.x : -g.s.x, loc.y >= -MPR_EPS_DIR ? g.s.y : -g.s.y, loc.z >= -MPR_EPS_DIR ? g.s.z : -g.s.z);
+  } else {
+    const double len = sqrt(loc.x * loc.x + loc.y * loc.y);
+    if (len > MPR_EPS_DIR) res = v3(g.s.x * loc.x / len, g.s.x * loc.y / len, 0); else res = v3(0, 0, 0);
+    res.z = loc.z >= -MPR_EPS_DIR ? g.s.y : -g.s.y;
+  }
+  const V3 w = v3(g.R.cx.x * res.x + g.R.cy.x * res.y + g.R.cz.x * res.z, g.R.cx.y * res.x + g.R.cy.y * res.y + g.R.cz.y * res.z,
+                  g.R.cx.z * res.x + g.R.cy.z * res.y + g.R.cz.z * res.z);
+  return v3(w.x + g.c.x, w.y + g.c.y, w.z + g.c.z);
+}
+struct MprVert { V3 v, a, b; };
+MJS_DEV MprVert mpr_support(const Geom& g1, const Geom& g2, V3 dir) {
+  MprVert s;
+  s.a = support(g1, dir);
+  s.b = support(g2, v3(-dir.x, -dir.y, -dir.z));
+  s.v = v3(s.a.x - s.b.x, s.a.y - s.b.y, s.a.z - s.b.z);
+  return s;
+}
+MJS_DEV double dot_nc(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+MJS_DEV V3 cross_nc(V3 a, V3 b) { return v3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+MJS_DEV bool normalize_nc(V3& v) {
+  const double n = sqrt(dot_nc(v, v));
+  if (n < 1e-14) return false;
+  v = v3(v.x / n, v.y / n, v.z / n);
+  return true;
+}
+MJS_DEV V3 sub_nc(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+MJS_DEV V3 any_perpendicular(V3 v) {
+  const double ax = fabs(v.x), ay = fabs(v.y), az = fabs(v.z);
+  const int k = ax <= ay ? (ax <= az ? 0 : 2) : (ay <= az ? 1 : 2);
+  return cross_nc(v, v3(k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0));
+}
+// Minkowski portal refinement on g1 - g2; true + (depth, normal g1 -> g2, pos) when the geoms overlap
+__device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
+  MprVert v0, v1, v2, v3_, v4;
+  v0.a = g1.c; v0.b = g2.c; v0.v = sub_nc(g1.c, g2.c);
+  if (sqrt(dot_nc(v0.v, v0.v)) < 1e-12) v0.v.x = 1e-5;
+  V3 dir = v3(-v0.v.x, -v0.v.y, -v0.v.z);
+  normalize_nc(dir);
+  v1 = mpr_support(g1, g2, dir);
+  if (dot_nc(v1.v, dir) <= 0) return false;
+  dir = cross_nc(v0.v, v1.v);
+  if (!normalize_nc(dir)) { dir = any_perpendicular(v0.v); normalize_nc(dir); }
+  v2 = mpr_support(g1, g2, dir);
+  if (dot_nc(v2.v, dir) <= 0) return false;
+  dir = cross_nc(sub_nc(v1.v, v0.v), sub_nc(v2.v, v0.v));
+  if (!normalize_nc(dir)) return false;
+  if (dot_nc(dir, v0.v) > MPR_EPS_LEN) { MprVert t = v1; v1 = v2; v2 = t; dir = v3(-dir.x, -dir.y, -dir.z); }
+  for (int it = 0;; it++) {  // portal discovery
+    if (it >= MJS_MPR_MAX_ITER) return false;
+    v3_ = mpr_support(g1, g2, dir);
+    if (dot_nc(v3_.v, dir) <= 0) return false;
+    bool cont = false;
+    if (dot_nc(cross_nc(v1.v, v3_.v), v0.v) < -MPR_EPS_VOL) { v2 = v3_; cont = true; }
+    else if (dot_nc(cross_nc(v3_.v, v2.v), v0.v) < -MPR_EPS_VOL) { v1 = v3_; cont = true; }
+    if (!cont) break;
+    dir = cross_nc(sub_nc(v1.v, v0.v), sub_nc(v2.v, v0.v));
+    if (!normalize_nc(dir)) return false;
+  }
+  bool hit = false;
+  for (int it = 0; it < MJS_MPR_MAX_ITER; it++) {  // portal refinement
+    dir = cross_nc(sub_nc(v2.v, v1.v), sub_nc(v3_.v, v1.v));
+    if (!normalize_nc(dir)) return false;
+    if (dot_nc(dir, v1.v) >= -MPR_EPS_LEN) hit = true;
+    v4 = mpr_support(g1, g2, dir);
+    const double reach = dot_nc(v4.v, dir);
+    if (!hit && reach < 0) return false;
+    const double progress = dot_nc(sub_nc(v4.v, v3_.v), dir);
+    if (progress <= MJS_MPR_TOLERANCE || it == MJS_MPR_MAX_ITER - 1) {
+      if (!hit) return false;
+      depth = dot_nc(v1.v, dir);
+      normal = dir;
+      const V3 c23 = cross_nc(v2.v, v3_.v), c13 = cross_nc(v1.v, v3_.v), c12 = cross_nc(v1.v, v2.v);
+      double b0 = dot_nc(v1.v, c23), b1 = -dot_nc(v0.v, c23), b2 = dot_nc(v0.v, c13), b3 = -dot_nc(v0.v, c12);
+      double sum = b0 + b1 + b2 + b3;
+      if (fabs(sum) < 1e-30) { b0 = 0; b1 = b2 = b3 = 1; sum = 3; }
+      const double pax = (b0 * v0.a.x + b1 * v1.a.x + b2 * v2.a.x + b3 * v3_.a.x) / sum, pbx = (b0 * v0.b.x + b1 * v1.b.x + b2 * v2.b.x + b3 * v3_.b.x) / sum;
+      const double pay = (b0 * v0.a.y + b1 * v1.a.y + b2 * v2.a.y + b3 * v3_.a.y) / sum, pby = (b0 * v0.b.y + b1 * v1.b.y + b2 * v2.b.y + b3 * v3_.b.y) / sum;
+      const double paz = (b0 * v0.a.z + b1 * v1.a.z + b2 * v2.a.z + b3 * v3_.a.z) / sum, pbz = (b0 * v0.b.z + b1 * v1.b.z + b2 * v2.b.z + b3 * v3_.b.z) / sum;
+      pos = v3(0.5 * (pax + pbx), 0.5 * (pay + pby), 0.5 * (paz + pbz));
+      return true;
+    }
+    const V3 t1 = cross_nc(v4.v, v0.v);
+    if (dot_nc(v1.v, t1) > MPR_EPS_VOL) {
+      if (dot_nc(v2.v, t1) > MPR_EPS_VOL) v1 = v4; else v3_ = v4;
+    } else {
+      if (dot_nc(v3_.v, t1) > MPR_EPS_VOL) v2 = v4; else v1 = v4;
+    }
+  }
+  return false;
+}
+MJS_DEV double rbound(const Geom& g) { return g.box ? sqrt(g.s.x * g.s.x + g.s.y * g.s.y + g.s.z * g.s.z) : sqrt(g.s.x * g.s.x + g.s.y * g.s.y); }
+MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, double tran, Contact& c) {
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return false;
+  double depth;
+  if (!mpr_penetration(g1, g2, depth, c.n, c.pos)) return false;
+  c.dist = -depth;
+  c.ba = ba; c.bb = bb;
+  c.tran = tran;
+  return true;
+}
+MJS_DEV Geom block_geom(const Block& b, const M3& R) {
+  Geom g;
+  g.R = R;
+  const double gz = MJS_BLOCK_GEOM_Z;  // geom_xpos = xpos + xmat * geom_pos
+  g.c = v3(b.p.x + R.cz.x * gz, b.p.y + R.cz.y * gz, b.p.z + R.cz.z * gz);
+  g.s = v3(MJS_BLOCK_HALF[0], MJS_BLOCK_HALF[1], MJS_BLOCK_HALF[2]);
+  g.box = true;
+  return g;
+}
+// mjc_PlaneBox against the floor z = 0: corners at or below the plane, at most 4, x index fastest
+MJS_DEV int floor_box(const Geom& g, int bb, Contact* out) {
+  int cnt = 0;
+  for (int i = 0; i < 8 && cnt < 4; i++) {
+    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+    const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
+                         g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
+    const double dist = corner.z;  // (corner - plane pos) . n with n = +z, plane through the origin
+    if (dist > 0.0) continue;
+    Contact& c = out[cnt++];
+    c.dist = dist;
+    c.n = v3(0, 0, 1);
+    c.pos = v3(corner.x, corner.y, corner.z - dist * 0.5);
+    c.ba = 0; c.bb = bb;
+    c.tran = 1.0 / MJS_BLOCK_MASS;  // world 0 + free block 1/m
+  }
+  return cnt;
+}
+#pragma clang fp contract(on)
+
+MJS_DEV Geom eef_geom(const rr::Chain& ch) {  // CylinderEEF: axis = flange z = wrist_3 y, centre at flange z = 0.051
+  Geom g;
+  const M3 R6 = ch.R[6];
+  g.R = M3{R6.cx, -R6.cz, R6.cy};  // flange frame (MJS_UR_FLANGE_QUAT): x = wrist_3 x, y = -wrist_3 z, z = wrist_3 y
+  g.c = madd(ch.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_POS_Z, R6.cy);
+  g.s = v3(MJS_CYL_RADIUS, MJS_CYL_HALFLEN, 0);
+  g.box = false;
+  return g;
+}
+MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collision proxy is a CYLINDER (MJS_UR_COL_* index 9):
+  Geom g;                                             // the only arm geom whose pair with a box is evaluated (convex-convex)
+  constexpr int G = MJS_UR_NCOLGEOM - 1;
+  const M3 R6 = ch.R[6];
+  g.R = M3{R6.cx, R6.cz, -R6.cy};  // geom quat (1,1,0,0): +90 deg about x of the body frame
+  g.c = madd(madd(madd(ch.p[6], MJS_UR_COL_POS[G][0], R6.cx), MJS_UR_COL_POS[G][1], R6.cy), MJS_UR_COL_POS[G][2], R6.cz);
+  g.s = v3(MJS_UR_COL_SIZE[G][0], MJS_UR_COL_SIZE[G][1], 0);
+  g.box = false;
+  return g;
+}
+MJS_DEV V3 eef_tcp_position(const rr::Chain& c) { return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_TCP_Z, c.R[6].cy); }
+
+// ---- hot-path detection: static slots only (no indexed memory)
+struct FloorSlots {
+  bool on[4];       // slot k = k-th corner at or below the floor in mjc_PlaneBox order (active when dist < 0)
+  double dist[4];
+  V3 r[4];          // contact point - body origin
+};
+#pragma clang fp contract(off)
+MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
+  FloorSlots fs;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
+  int rank = 0;  // number of detected corners so far
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+    const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
+                         g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
+    const double dist = corner.z;
+    const bool hit = !(dist > 0.0) && rank < 4;
+    const V3 r = v3(corner.x - origin.x, corner.y - origin.y, (corner.z - dist * 0.5) - origin.z);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (hit && rank == k) { fs.on[k] = dist < 0.0; fs.dist[k] = dist; fs.r[k] = r; }
+    rank += hit ? 1 : 0;
+  }
+  return fs;
+}
+// convex pairs of the scene in MuJoCo's pair order: wrist proxy - block b (NB slots), EEF - block b (NB), block a - block b
+// (a < b, row-major)
+constexpr int NCVX = 2 * NB + (NB * (NB - 1)) / 2;
+constexpr int pair_slot(int a, int b) { return 2 * NB + a * NB - (a * (a + 1)) / 2 + (b - a - 1); }
+struct ConvexHits {
+  bool hit[NCVX];
+  double dist[NCVX];
+  V3 pos[NCVX], n[NCVX];
+};
+MJS_DEV void convex_slot(const Geom& g1, const Geom& g2, ConvexHits& h, int k) {  // k is a compile-time constant at every call site
+  h.hit[k] = false; h.dist[k] = 0; h.pos[k] = v3(0, 0, 0); h.n[k] = v3(0, 0, 1);
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return;
+  double depth;
+  V3 nn, pp_;
+  if (!mpr_penetration(g1, g2, depth, nn, pp_)) return;
+  h.hit[k] = true; h.dist[k] = -depth; h.pos[k] = pp_; h.n[k] = nn;
+}
+MJS_DEV bool convex_penetrating(const Geom& g1, const Geom& g2) {  // an ACTIVE contact (dist < 0) between two convex geoms?
+  const V3 diff = sub_nc(g2.c, g1.c);
+  const double bound = rbound(g1) + rbound(g2);
+  if (dot_nc(diff, diff) > bound * bound) return false;
+  double depth;
+  V3 n, pos;
+  if (!mpr_penetration(g1, g2, depth, n, pos)) return false;
+  return -depth < 0.0;
+}
+#pragma clang fp contract(on)
+
+// all contacts of the scene in MuJoCo's pair order (geom ids: floor, arm capsules, EEF cylinder, blocks): floor-block i
+// (<= 4 each), EEF-block i, block-block. Arm capsules vs floor and EEF vs floor are only COUNTED (D-8): `extra`.
+MJS_DEV int detect_contacts(const rr::Chain& ch, const World& s, const M3* Rb, int nb, Contact* con, int& extra, bool& eef_floor_active) {
+  int n = 0;
+  extra = rr::count_floor_contacts(ch);
+  const Geom eg = eef_geom(ch);
+  {  // mjc_PlaneCylinder first test: the deepest rim point of the EEF cylinder (active only if the arm sags by 19 mm)
+    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+    const double lowest = eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x;
+    eef_floor_active = lowest < 0.0;
+    if (!(lowest > 0.0)) extra += 1;
+  }
+  Geom bg[NB];
+  for (int b = 0; b < nb; b++) {
+    bg[b] = block_geom(s.b[b], Rb[b]);
+    n += floor_box(bg[b], 2 + b, con + n);
+  }
+  const Geom wg = wrist3_proxy_geom(ch);
+  for (int b = 0; b < nb; b++)
+    if (collide_convex(wg, bg[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS, con[n])) n++;
+  for (int b = 0; b < nb; b++)
+    if (collide_convex(eg, bg[b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS, con[n])) n++;
+  for (int a = 0; a < nb; a++)
+    for (int b = a + 1; b < nb; b++)
+      if (collide_convex(bg[a], bg[b], 2 + a, 2 + b, 2.0 / MJS_BLOCK_MASS, con[n])) n++;
+  return n;
+}
+
+// ------------------------------------------------------------------------------------------------ dynamics
+// Free block, generalised velocity (v_origin in the world, w in the body frame), COM at c_l = (0, 0, gz) in the body:
+//   M = [[m I, -m R C], [m C R^T, I_c - m C C]],  C = [c_l]x
+//   smooth force = -( m R (w x (w x c_l)) - m g ;  w x I_c w + m c_l x (w x (w x c_l)) - m c_l x R^T g )
+constexpr double BLK_IXX = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+constexpr double BLK_IYY = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+constexpr double BLK_IZZ = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1]) / 3;
+constexpr double BLK_INVW_TRAN = 1.0 / MJS_BLOCK_MASS, BLK_INVW_ROT = (1.0 / BLK_IXX + 1.0 / BLK_IYY + 1.0 / BLK_IZZ) / 3;
+MJS_DEV void block_mass_matrix(const M3& R, double (*M)[NV], int o) {  // writes the 6x6 block at offset o (both triangles)
+  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) M[o + i][o + j] = 0;
+  for (int k = 0; k < 3; k++) M[o + k][o + k] = m;
+  M[o + 3][o + 3] = BLK_IXX + m * g * g; M[o + 4][o + 4] = BLK_IYY + m * g * g; M[o + 5][o + 5] = BLK_IZZ;
+  // -m R C: column for w_x is -m g R.cy, for w_y is +m g R.cx, for w_z is 0
+  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
+  const double colx[3] = {cx.x, cx.y, cx.z}, coly[3] = {cy.x, cy.y, cy.z};
+  for (int k = 0; k < 3; k++) { M[o + k][o + 3] = M[o + 3][o + k] = colx[k]; M[o + k][o + 4] = M[o + 4][o + k] = coly[k]; }
+}
+MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
+  const double m = MJS_BLOCK_MASS;
+  const V3 c = v3(0, 0, MJS_BLOCK_GEOM_Z), grav = v3(0, 0, MJS_GRAVITY_Z);
+  const V3 wwc = cross(w, cross(w, c));
+  const V3 lin = m * rot(R, wwc) - m * grav;
+  const V3 Iw = v3(BLK_IXX * w.x, BLK_IYY * w.y, BLK_IZZ * w.z);
+  const V3 ang = cross(w, Iw) + m * cross(c, wwc) - m * cross(c, rot_t(R, grav));
+  f[0] = -lin.x; f[1] = -lin.y; f[2] = -lin.z; f[3] = -ang.x; f[4] = -ang.y; f[5] = -ang.z;
+}
+
+// dense symmetric positive definite solve helpers on [NV][NV] scratch arrays, n <= NV
+MJS_DEV bool chol_n(int n, double (*A)[NV]) {  // in place, lower triangle
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double s = A[i][j];
+      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
+      if (i == j) {
+        if (s < MJS_MINVAL) return false;
+        A[i][i] = sqrt(s);
+      } else
+        A[i][j] = s / A[j][j];
+    }
+  return true;
+}
+MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
+    x[i] = s / L[i][i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k];
+    x[i] = s / L[i][i];
+  }
+}
+
+// Decoupled case (the common one): no active arm-block or block-block contact and no joint limit. The constraint
+// problem is then separable: each block with its floor contacts is an independent 6-dof problem with at most 4
+// corner contacts x 6 pyramid edges. Static slots, everything unrolled (no indexed memory). The floor frame is
+// constant (n = +z, t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)), so a row is (F, (axis_d x r) . F) for the three
+// frame vectors F and (0, axis_d . n) for the torsional row. `Mb`: the block's 6x6 mass matrix (lower triangle used),
+// `f`: qfrc_smooth of the block in, qfrc_smooth + qfrc_constraint out.
+MJS_DEV void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
+                                               double* f) {
+  const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};  // max(block, floor) per component
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  // contact-frame Jacobians: rows normal, t1, t2, torsion over the block's 6 dofs
+  double Jc[4][4][6], D[4], aref[4][6];
+  const V3 axs[3] = {R.cx, R.cy, R.cz};
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const V3 lin = cross(axs[d], fs.r[c]);
+      Jc[c][0][d] = d == 2 ? 1.0 : 0.0; Jc[c][0][3 + d] = lin.z;    // n  = (0, 0, 1)
+      Jc[c][1][d] = d == 1 ? 1.0 : 0.0; Jc[c][1][3 + d] = lin.y;    // t1 = (0, 1, 0)
+      Jc[c][2][d] = d == 0 ? -1.0 : 0.0; Jc[c][2][3 + d] = -lin.x;  // t2 = (-1, 0, 0)
+      Jc[c][3][d] = 0.0; Jc[c][3][3 + d] = axs[d].z;                // torsion: rotation about n
+    }
+    const double imp = impedance_default(fs.dist[c]);
+    const double tran = 1.0 / MJS_BLOCK_MASS;
+    D[c] = 1 / (2 * mu[0] * mu[0] * fmax(MJS_MINVAL, (1 - imp) * (tran + mu[0] * mu[0] * tran) / imp));
+    double vel[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) vel[rw] += Jc[c][rw][d] * qvel[d];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) aref[c][e] = -B * (vel[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * vel[1 + (e >> 1)]) - K * imp * fs.dist[c];
+  }
+  auto edge_values = [&](const double* x, int c, double* out6) {
+    double u[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) u[rw] += Jc[c][rw][d] * x[d];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) out6[e] = u[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * u[1 + (e >> 1)];
+  };
+  double L[6][6], a[6], a_s[6], Ma[6], jar[4][6], force[4][6];
+  bool act[4][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = Mb[i][j];
+    a_s[i] = f[i];
+  }
+  rr::chol6(L);
+  rr::chol6_solve(L, a_s);
+#pragma unroll
+  for (int i = 0; i < 6; i++) a[i] = a_s[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double m = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * a[k];
+    Ma[i] = m;
+  }
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    double ja[6];
+    edge_values(a, c, ja);
+#pragma unroll
+    for (int e = 0; e < 6; e++) jar[c][e] = ja[e] - aref[c][e];
+  }
+  auto update = [&]() {
+    double cost = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const bool on = fs.on[c] && jar[c][e] < 0;
+        act[c][e] = on;
+        force[c][e] = on ? -D[c] * jar[c][e] : 0.0;
+        if (on) cost += 0.5 * D[c] * jar[c][e] * jar[c][e];
+      }
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gauss += (Ma[i] - f[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+  auto constraint_force = [&](double* fc) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) fc[i] = 0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const double fn = force[c][0] + force[c][1] + force[c][2] + force[c][3] + force[c][4] + force[c][5];
+      const double f1 = mu[0] * (force[c][0] - force[c][1]), f2 = mu[1] * (force[c][2] - force[c][3]), f3 = mu[2] * (force[c][4] - force[c][5]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) fc[i] += fn * Jc[c][0][i] + f1 * Jc[c][1][i] + f2 * Jc[c][2][i] + f3 * Jc[c][3][i];
+    }
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv_total);
+#pragma unroll 1
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[6], search[6], Mv[6], H[6][6], fc[6];
+    constraint_force(fc);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      grad[i] = Ma[i] - f[i] - fc[i];
+      search[i] = -grad[i];
+#pragma unroll
+      for (int j = 0; j <= i; j++) H[i][j] = Mb[i][j];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      // sum over active edges of D (Jn + s mu_k Jk)(Jn + s mu_k Jk)^T, k = t1, t2, torsion
+      double wn = 0, w[3], ww[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double np_ = act[c][2 * k], nm = act[c][2 * k + 1];
+        wn += np_ + nm;
+        w[k] = D[c] * mu[k] * (np_ - nm);
+        ww[k] = D[c] * mu[k] * mu[k] * (np_ + nm);
+      }
+      wn *= D[c];
+      if (wn != 0.0) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const double jn = Jc[c][0][i];
+          const double rn = wn * jn + w[0] * Jc[c][1][i] + w[1] * Jc[c][2][i] + w[2] * Jc[c][3][i];
+          const double r1 = w[0] * jn + ww[0] * Jc[c][1][i], r2 = w[1] * jn + ww[1] * Jc[c][2][i], r3 = w[2] * jn + ww[2] * Jc[c][3][i];
+#pragma unroll
+          for (int j = 0; j <= i; j++) H[i][j] += rn * Jc[c][0][j] + r1 * Jc[c][1][j] + r2 * Jc[c][2][j] + r3 * Jc[c][3][j];
+        }
+      }
+    }
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * search[k];
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { g1 += search[i] * (Ma[i] - f[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    double jv[4][6];
+#pragma unroll
+    for (int c = 0; c < 4; c++) edge_values(search, c, jv[c]);
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+#pragma unroll
+        for (int e = 0; e < 6; e++) {
+          const double x = jar[c][e] + alpha * jv[c][e];
+          if (fs.on[c] && x < 0) { d1 += D[c] * x * jv[c][e]; d2 += D[c] * jv[c][e] * jv[c][e]; }
+        }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+#pragma unroll
+      for (int e = 0; e < 6; e++) jar[c][e] += alpha * jv[c][e];
+    }
+    const double oldcost = cost;
+    cost = update();
+    constraint_force(fc);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const double g = Ma[i] - f[i] - fc[i];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  double fc[6];
+  constraint_force(fc);
+#pragma unroll
+  for (int i = 0; i < 6; i++) f[i] += fc[i];
+}
+
+MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangle + the coupling block both ways
+  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j < 6; j++) M[i][j] = 0;
+  }
+  M[0][0] = M[1][1] = M[2][2] = m;
+  M[3][3] = BLK_IXX + m * g * g; M[4][4] = BLK_IYY + m * g * g; M[5][5] = BLK_IZZ;
+  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
+  M[3][0] = M[0][3] = cx.x; M[3][1] = M[1][3] = cx.y; M[3][2] = M[2][3] = cx.z;
+  M[4][0] = M[0][4] = cy.x; M[4][1] = M[1][4] = cy.y; M[4][2] = M[2][4] = cy.z;
+}
+
+struct StepInfo {
+  bool bad, rows_active, unsupported;
+  int ncon;
+#ifdef MJS_STAMPS
+  unsigned long long cyc[6];
+#endif
+};
+#ifndef PP_TIC
+#ifdef MJS_STAMPS
+#define PP_TIC(t) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PP_ACC(info, k, t0) do { unsigned long long t1_; PP_TIC(t1_); (info).cyc[k] += t1_ - (t0); (t0) = t1_; } while (0)
+#else
+#define PP_TIC(t) do { } while (0)
+#define PP_ACC(info, k, t0) do { } while (0)
+#endif
+#endif
+
+// The coupled case (an arm-block or block-block contact is active, or a joint is beyond its range): the constraint
+// problem couples all nv = 6 + 6 n dofs. It is solved by the WHOLE WAVEFRONT for one env at a time: the env's lane
+// publishes M, qfrc_smooth and its rows (<= 78 x 18) in LDS, then the 64 lanes share the dense Newton iteration of
+// mj_solPrimal: rows are dealt to lanes (residuals, forces, line-search sums with wave reductions), the Hessian
+// entries are dealt to lanes, the 18 x 18 Cholesky and the triangular solves run column by column in LDS.
+// The function must be called by all 64 lanes of the workgroup (uniform control flow).
+constexpr int LDP = NV + 1;  // padded leading dimension in LDS
+// The cooperating lanes are ONE wavefront (several wavefronts share a workgroup only to share the instruction
+// cache). A wavefront's LDS instructions execute in program order, so the only things a "sync" has to do are (1) keep
+// the COMPILER from moving one lane's LDS load above another lane's earlier store and (2) drain the LDS queue. A
+// release/acquire fence pair also waited for every outstanding scratch/global access (s_waitcnt vmcnt(0)) at each of
+// the ~60 syncs of a solve; an explicit lgkmcnt wait with a compiler memory barrier does not.
+#ifndef MJS_WAVE_SYNC
+#define MJS_WAVE_SYNC()                                          \
+  do {                                                           \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    __builtin_amdgcn_wave_barrier();                             \
+  } while (0)
+#endif
+struct CoopLds {
+  double J[MAXROW][LDP], D[MAXROW], aref[MAXROW], jar[MAXROW], jv[MAXROW], force[MAXROW];
+  double M[NV][LDP], H[NV][LDP];
+  double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
+  int active[MAXROW];
+  int nrow;
+  // problem description written by the owner lane; the rows are then built by all lanes
+  int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
+  double c_dist[MAXCON], c_tran[MAXCON], c_pos[MAXCON][3], c_n[MAXCON][3];
+  double ax[NJ][3], an[NJ][3];     // joint axes and anchors (world)
+  double bp[NB][3], bR[NB][9];     // block origins and rotation columns (cx, cy, cz)
+  double qvel[NV], q[NJ];
+};
+// The cooperative workspace lives in dynamic LDS declared at namespace scope so that every device function reaches it
+// as an LDS (address space 3) object: passing it by reference through a non-inlined call would degrade every access
+// to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
+extern __shared__ double pp_lds_raw[];
+MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
+MJS_DEV double wave_sum(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
+  return x;
+}
+// wave broadcast of a double from a compile-time lane
+MJS_DEV double bcast(double x, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
+  return __hiloint2double(hi, lo);
+}
+// Solve H x = b (H = sh.H, lower triangle, SPD; b and x in `vec`, LDS) with the factorisation in REGISTERS: lane i owns
+// row i of H; the pivot, the column-j entries of the other rows and the right-hand side travel by v_readlane
+// broadcasts (all lane indices are compile-time constants of the unrolled loops), so the 153 trailing updates and
+// the forward substitution touch no memory. The rows of L then go to LDS once and every lane fetches its column of
+// L for the backward substitution. Rows >= nv are identity padding (one block instead of two).
+MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
+  double row[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) row[j] = (lane < nv && j <= lane) ? sh.H[lane < NV ? lane : 0][j] : (j == lane ? 1.0 : 0.0);
+  double b = lane < nv ? vec[lane < NV ? lane : 0] : 0.0;
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const double d = bcast(row[j], j);
+    if (d < MJS_MINVAL) ok = false;
+    const double inv = rr::rsqrt_fast(fmax(d, MJS_MINVAL));
+    row[j] = lane == j ? inv : row[j] * inv;  // L_ij for the rows below; the pivot row keeps 1 / L_jj
+    const double yj = bcast(b, j) * inv;      // forward substitution fused in
+    b = lane == j ? yj : (lane > j ? b - row[j] * yj : b);
+#pragma unroll
+    for (int k = j + 1; k < NV; k++) {
+      const double lkj = bcast(row[j], k);
+      if (lane >= k) row[k] -= row[j] * lkj;
+    }
+  }
+  // rows of L to LDS, then each lane reads its column: L[k][lane], k > lane
+  if (lane < NV) {
+#pragma unroll
+    for (int j = 0; j < NV; j++)
+      if (j <= lane) sh.H[lane][j] = row[j];
+  }
+  MJS_WAVE_SYNC();
+  double col[NV];
+#pragma unroll
+  for (int k = 0; k < NV; k++) col[k] = (lane < NV && k > lane) ? sh.H[k][lane < NV ? lane : 0] : 0.0;
+#pragma unroll
+  for (int k = NV - 1; k >= 0; k--) {
+    const double xk = bcast(b, k) * bcast(row[k], k);  // y_k / L_kk
+    b = lane == k ? xk : (lane < k ? b - col[k] * xk : b);
+  }
+  if (lane < nv) vec[lane] = b;
+  MJS_WAVE_SYNC();
+  return ok;
+}
+// cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
+MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
+  const int nrow = sh.nrow;
+  // qacc_smooth = M^-1 qfrc_smooth: M is block diagonal (arm, block 0, block 1), one lane per 6x6 block
+  if (lane < nv / 6) {
+    double L[6][6], x[6];
+    const int o = 6 * lane;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i][j] = sh.M[o + i][o + j];
+      x[i] = sh.qs[o + i];
+    }
+    rr::chol6(L);
+    rr::chol6_solve(L, x);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { sh.a_s[o + i] = x[i]; sh.a[o + i] = x[i]; }
+  }
+  MJS_WAVE_SYNC();
+  if (lane < nv) {
+    double m = 0;
+    for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.a[k];
+    sh.Ma[lane] = m;
+  }
+  for (int r = lane; r < nrow; r += 64) {
+    double x = -sh.aref[r];
+    for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.a[k];
+    sh.jar[r] = x;
+  }
+  MJS_WAVE_SYNC();
+  auto update = [&]() {  // forces / active set from jar; returns the total cost (all lanes)
+    double cost = 0;
+    for (int r = lane; r < nrow; r += 64) {
+      const double x = sh.jar[r];
+      const bool act = x < 0;
+      sh.active[r] = act;
+      sh.force[r] = act ? -sh.D[r] * x : 0.0;
+      if (act) cost += 0.5 * sh.D[r] * x * x;
+    }
+    if (lane < nv) cost += 0.5 * (sh.Ma[lane] - sh.qs[lane]) * (sh.a[lane] - sh.a_s[lane]);
+    MJS_WAVE_SYNC();
+    return wave_sum(cost);
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv);
+  // this lane's (up to NHE) entries of the lower triangle of the Hessian
+  constexpr int NHE = (NV * (NV + 1) / 2 + 63) / 64;
+  int hi[NHE], hj[NHE];
+  bool he[NHE];
+#pragma unroll
+  for (int q = 0; q < NHE; q++) {
+    const int e = lane + 64 * q;
+    he[q] = e < nv * (nv + 1) / 2;
+    int i = (int)((sqrt(8.0 * (he[q] ? e : 0) + 1.0) - 1.0) * 0.5);
+    while ((i + 1) * (i + 2) / 2 <= (he[q] ? e : 0)) i++;
+    while (i * (i + 1) / 2 > (he[q] ? e : 0)) i--;
+    hi[q] = i;
+    hj[q] = (he[q] ? e : 0) - i * (i + 1) / 2;
+  }
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    // gradient -> search = -grad ; Hessian = M + J^T diag(D active) J
+    if (lane < nv) {
+      double g = sh.Ma[lane] - sh.qs[lane];
+      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
+      sh.search[lane] = -g;
+    }
+    {
+      double h[NHE];
+#pragma unroll
+      for (int q = 0; q < NHE; q++) h[q] = he[q] ? sh.M[hi[q]][hj[q]] : 0.0;
+      for (int r = 0; r < nrow; r++) {
+        if (!sh.active[r]) continue;  // wave-uniform
+        const double d = sh.D[r];
+#pragma unroll
+        for (int q = 0; q < NHE; q++) h[q] += sh.J[r][hi[q]] * d * sh.J[r][hj[q]];
+      }
+#pragma unroll
+      for (int q = 0; q < NHE; q++)
+        if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
+    }
+    MJS_WAVE_SYNC();
+    if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
+    if (lane < nv) {
+      double m = 0;
+      for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
+      sh.Mv[lane] = m;
+    }
+    for (int r = lane; r < nrow; r += 64) {
+      double x = 0;
+      for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.search[k];
+      sh.jv[r] = x;
+    }
+    MJS_WAVE_SYNC();
+    double g1 = 0, g2 = 0, sn2 = 0;
+    if (lane < nv) { g1 = sh.search[lane] * (sh.Ma[lane] - sh.qs[lane]); g2 = sh.search[lane] * sh.Mv[lane]; sn2 = sh.search[lane] * sh.search[lane]; }
+    g1 = wave_sum(g1); g2 = wave_sum(g2); sn2 = wave_sum(sn2);
+    if (sqrt(sn2) < MJS_MINVAL) break;
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(sn2) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+    for (int it = 0; it < 50; it++) {  // exact 1-D Newton; every lane follows the same alpha sequence
+      double p1 = 0, p2 = 0;
+      for (int r = lane; r < nrow; r += 64) {
+        const double x = sh.jar[r] + alpha * sh.jv[r];
+        if (x < 0) { p1 += sh.D[r] * x * sh.jv[r]; p2 += sh.D[r] * sh.jv[r] * sh.jv[r]; }
+      }
+      const double d1 = g1 + alpha * g2 + wave_sum(p1), d2 = g2 + wave_sum(p2);
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+    if (lane < nv) { sh.a[lane] += alpha * sh.search[lane]; sh.Ma[lane] += alpha * sh.Mv[lane]; }
+    for (int r = lane; r < nrow; r += 64) sh.jar[r] += alpha * sh.jv[r];
+    MJS_WAVE_SYNC();
+    const double oldcost = cost;
+    cost = update();
+    double gn = 0;
+    if (lane < nv) {
+      double g = sh.Ma[lane] - sh.qs[lane];
+      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
+      gn = g * g;
+    }
+    gn = wave_sum(gn);
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  MJS_WAVE_SYNC();
+  if (lane < nv) {
+    double f = 0;
+    for (int r = 0; r < nrow; r++) f += sh.J[r][lane] * sh.force[r];
+    sh.fc[lane] = f;
+  }
+  MJS_WAVE_SYNC();
+}
+// the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
+MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
+                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
+  CoopLds& sh = coop_lds();
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  // contact list in MuJoCo's pair order from the hot path's static slots (no second collision pass)
+  int ncon = 0;
+  auto put = [&](double dist, V3 pos, V3 n, int ba, int bb, double tran) {
+    sh.c_ba[ncon] = ba; sh.c_bb[ncon] = bb; sh.c_act[ncon] = dist < 0.0;
+    sh.c_dist[ncon] = dist; sh.c_tran[ncon] = tran;
+    sh.c_pos[ncon][0] = pos.x; sh.c_pos[ncon][1] = pos.y; sh.c_pos[ncon][2] = pos.z;
+    sh.c_n[ncon][0] = n.x; sh.c_n[ncon][1] = n.y; sh.c_n[ncon][2] = n.z;
+    ncon++;
+  };
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const FloorSlots& f = fs[b];
+#pragma unroll
+    for (int k = 0; k < 4; k++)  // only ACTIVE corners make rows (a corner exactly on the floor is detected but inactive)
+      if (f.on[k]) put(f.dist[k], f.r[k] + s.b[b].p, v3(0, 0, 1), 0, 2 + b, 1.0 / MJS_BLOCK_MASS);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+    if (b < nb && cvx.hit[b]) put(cvx.dist[b], cvx.pos[b], cvx.n[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+    if (b < nb && cvx.hit[NB + b]) put(cvx.dist[NB + b], cvx.pos[NB + b], cvx.n[NB + b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+#pragma unroll
+  for (int a = 0; a < NB; a++) {
+#pragma unroll
+    for (int b = a + 1; b < NB; b++) {
+      const int k = pair_slot(a, b);
+      if (b < nb && cvx.hit[k]) put(cvx.dist[k], cvx.pos[k], cvx.n[k], 2 + a, 2 + b, 2.0 / MJS_BLOCK_MASS);
+    }
+  }
+  sh.ncon = ncon;
+  for (int j = 0; j < NJ; j++) {
+    const V3 a = rr::joint_axis(ch, j), p = ch.p[j + 1];
+    sh.ax[j][0] = a.x; sh.ax[j][1] = a.y; sh.ax[j][2] = a.z;
+    sh.an[j][0] = p.x; sh.an[j][1] = p.y; sh.an[j][2] = p.z;
+    sh.q[j] = s.q[j];
+    sh.qvel[j] = s.v[j];
+    sh.qs[j] = qs_arm[j];
+    sh.lim_act[2 * j] = s.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.0;
+    sh.lim_act[2 * j + 1] = MJS_UR_JNT_RANGE[j][1] - s.q[j] < 0.0;
+    for (int k = 0; k <= j; k++) sh.M[j][k] = sh.M[k][j] = Marm[j * (j + 1) / 2 + k];
+    sh.M[j][j] += MJS_UR_ARMATURE;
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const int o = NJ + 6 * b;
+    double Mb[6][6], f[6];
+    block_mass_matrix6(Rb[b], Mb);
+    block_smooth_force(Rb[b], s.b[b].w, f);
+    for (int i = 0; i < 6; i++) {
+      for (int j = 0; j < 6; j++) sh.M[o + i][o + j] = Mb[i][j];
+      sh.qs[o + i] = f[i];
+    }
+    sh.qvel[o] = s.b[b].v.x; sh.qvel[o + 1] = s.b[b].v.y; sh.qvel[o + 2] = s.b[b].v.z;
+    sh.qvel[o + 3] = s.b[b].w.x; sh.qvel[o + 4] = s.b[b].w.y; sh.qvel[o + 5] = s.b[b].w.z;
+    sh.bp[b][0] = s.b[b].p.x; sh.bp[b][1] = s.b[b].p.y; sh.bp[b][2] = s.b[b].p.z;
+    sh.bR[b][0] = Rb[b].cx.x; sh.bR[b][1] = Rb[b].cx.y; sh.bR[b][2] = Rb[b].cx.z;
+    sh.bR[b][3] = Rb[b].cy.x; sh.bR[b][4] = Rb[b].cy.y; sh.bR[b][5] = Rb[b].cy.z;
+    sh.bR[b][6] = Rb[b].cz.x; sh.bR[b][7] = Rb[b].cz.y; sh.bR[b][8] = Rb[b].cz.z;
+  }
+}
+// one frame row (F . translational or rotational Jacobian of (body b - body a)) of a published contact, all nv columns
+MJS_DEV void coop_frame_row(const CoopLds& sh, int c, V3 F, bool rotational, int nv, double* out) {
+  for (int d = 0; d < nv; d++) out[d] = 0;
+  const V3 pos = v3(sh.c_pos[c][0], sh.c_pos[c][1], sh.c_pos[c][2]);
+  for (int side = 0; side < 2; side++) {
+    const int body = side == 0 ? sh.c_ba[c] : sh.c_bb[c];
+    const double sg = side == 0 ? -1.0 : 1.0;
+    if (body == 1) {
+      for (int j = 0; j < NJ; j++) {
+        const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
+        const V3 col = rotational ? ax : cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
+        out[j] += sg * dot(F, col);
+      }
+    } else if (body >= 2) {
+      const int b = body - 2, o = NJ + 6 * b;
+      const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
+      for (int d = 0; d < 3; d++) {
+        const V3 axs = v3(sh.bR[b][3 * d], sh.bR[b][3 * d + 1], sh.bR[b][3 * d + 2]);
+        if (!rotational) out[o + d] += sg * (d == 0 ? F.x : d == 1 ? F.y : F.z);
+        out[o + 3 + d] += sg * dot(F, rotational ? axs : cross(axs, rvec));
+      }
+    }
+  }
+}
+// all lanes: limit rows + pyramid rows (6 per active contact, condim 4) in the oracle's order
+MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
+  const int nv = NJ + 6 * nb;
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  int nlim = 0;
+  for (int k = 0; k < 2 * NJ; k++) nlim += sh.lim_act[k];
+  if (lane < 2 * NJ && sh.lim_act[lane]) {
+    int row = 0;
+    for (int k = 0; k < lane; k++) row += sh.lim_act[k];
+    const int j = lane >> 1;
+    const double sgn = (lane & 1) ? -1.0 : 1.0;
+    const double dist = (lane & 1) ? MJS_UR_JNT_RANGE[j][1] - sh.q[j] : sh.q[j] - MJS_UR_JNT_RANGE[j][0];
+    for (int d = 0; d < nv; d++) sh.J[row][d] = d == j ? sgn : 0.0;
+    const double imp = impedance_default(dist);
+    sh.D[row] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
+    sh.aref[row] = -B * (sgn * sh.qvel[j]) - K * imp * dist;
+  }
+  int nact = 0;
+  for (int c = 0; c < sh.ncon; c++) nact += sh.c_act[c];
+  for (int t = lane; t < 6 * sh.ncon; t += 64) {  // task = (contact, pyramid edge)
+    const int c = t / 6, e = t - 6 * c;
+    if (!sh.c_act[c]) continue;
+    int rank = 0;
+    for (int k = 0; k < c; k++) rank += sh.c_act[k];
+    const int row = nlim + 6 * rank + e;
+    const V3 n = v3(sh.c_n[c][0], sh.c_n[c][1], sh.c_n[c][2]);
+    V3 t1, t2;
+    {  // mju_makeFrame
+      V3 y = (n.y > -0.5 && n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
+      y = madd(y, -dot(n, y), n);
+      t1 = (1.0 / sqrt(dot(y, y))) * y;
+      t2 = cross(n, t1);
+    }
+    const int kk = e >> 1;  // 0: t1, 1: t2, 2: torsion
+    const double sgn = (e & 1) ? -1.0 : 1.0;
+    const bool blocks_only = sh.c_ba[c] >= 2 && sh.c_bb[c] >= 2;
+    const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
+    double Jn[NV], Jk[NV];
+    coop_frame_row(sh, c, n, false, nv, Jn);
+    coop_frame_row(sh, c, kk == 0 ? t1 : kk == 1 ? t2 : n, kk == 2, nv, Jk);
+    double vel = 0;
+    for (int d = 0; d < nv; d++) {
+      const double j = Jn[d] + sgn * fri[kk] * Jk[d];
+      sh.J[row][d] = j;
+      vel += j * sh.qvel[d];
+    }
+    const double imp = impedance_default(sh.c_dist[c]);
+    const double R0 = fmax(MJS_MINVAL, (1 - imp) * (sh.c_tran[c] + fri[0] * fri[0] * sh.c_tran[c]) / imp);
+    sh.D[row] = 1 / (2 * fri[0] * fri[0] * R0);
+    sh.aref[row] = -B * vel - K * imp * sh.c_dist[c];
+  }
+  if (lane == 0) sh.nrow = nlim + 6 * nact;
+}
+MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
+                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
+  CoopLds& sh = coop_lds();
+  const int lane = threadIdx.x & 63, nv = NJ + 6 * nb;
+  const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+  unsigned long long todo = __ballot(need);
+  while (todo) {  // wave-uniform loop over the lanes whose env needs the coupled solve
+    const int owner = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    for (int e = lane; e < nv * nv; e += 64) sh.M[e / nv][e % nv] = 0;  // all lanes: clear M, the owner fills its diagonal blocks
+    MJS_WAVE_SYNC();
+    unsigned long long tp = 0;
+    PP_TIC(tp);
+    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb);
+    MJS_WAVE_SYNC();
+    PP_ACC(info, 5, tp);
+    coop_build_rows(sh, nb, lane);
+    MJS_WAVE_SYNC();
+    if (sh.nrow > 0) coop_newton(sh, nv, meaninertia, lane);
+    if (lane == owner) {
+      for (int i = 0; i < nv; i++) qacc[i] = sh.qs[i] + (sh.nrow > 0 ? sh.fc[i] : 0.0);
+    }
+    MJS_WAVE_SYNC();
+  }
+}
+
+// One Physics.step() (mj_step2 of the current state; the next mj_step1 is the start of the next call): smooth
+// dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
+// `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
+// neighbours (all 64 lanes of the workgroup must call this function together).
+__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info, bool live) {
+  const int nv = NJ + 6 * nb;
+  double Marm[21], qacc[NV];
+  int clamped = 0;
+  bool coupled = false;
+  ConvexHits cvx;
+  FloorSlots fs[NB];
+  M3 Rb[NB];
+  unsigned long long tt = 0;
+  PP_TIC(tt);
+  if (live) {
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    double qn[4];
+    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
+#pragma unroll
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    Rb[b] = quat_to_m3(qn);
+  }
+  // contacts (static slots): floor corners per block; is any arm-block / block-block pair penetrating?
+  Geom bg[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    bg[b] = block_geom(s.b[b], Rb[b]);
+    fs[b] = floor_slots(bg[b], s.b[b].p);
+  }
+  {
+    const Geom eg = eef_geom(ch), wg = wrist3_proxy_geom(ch);
+    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+    info.unsupported = info.unsupported || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);  // EEF cylinder below the floor (D-8)
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) { cvx.hit[k] = false; cvx.dist[k] = 0; cvx.pos[k] = v3(0, 0, 0); cvx.n[k] = v3(0, 0, 1); }
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if (b < nb) { convex_slot(wg, bg[b], cvx, b); convex_slot(eg, bg[b], cvx, NB + b); }
+#pragma unroll
+    for (int a = 0; a < NB; a++) {
+#pragma unroll
+      for (int b = a + 1; b < NB; b++)
+        if (b < nb) convex_slot(bg[a], bg[b], cvx, pair_slot(a, b));
+    }
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) coupled = coupled || (cvx.hit[k] && cvx.dist[k] < 0.0);
+  }
+  PP_ACC(info, 0, tt);
+  // arm smooth dynamics
+  double bias[NJ], fact[NJ];
+  ur5e_pp_M_gen(cs, sn, Marm);
+  ur5e_pp_bias_gen(cs, sn, s.v, bias);
+  clamped = rr::actuator_forces(s.q, s.v, ctrl, fact);
+#pragma unroll
+  for (int i = 0; i < NJ; i++) qacc[i] = fact[i] - bias[i];
+  PP_ACC(info, 1, tt);
+  // which constraint problem?
+#pragma unroll
+  for (int j = 0; j < NJ; j++) coupled = coupled || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
+  if (coupled) {
+    info.rows_active = true;
+  } else {
+    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b >= nb) continue;
+      const int o = NJ + 6 * b;
+      block_smooth_force(Rb[b], s.b[b].w, qacc + o);
+      const bool any = fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3];
+      if (any) {
+        double Mb[6][6];
+        block_mass_matrix6(Rb[b], Mb);
+        const double qv[6] = {s.b[b].v.x, s.b[b].v.y, s.b[b].v.z, s.b[b].w.x, s.b[b].w.y, s.b[b].w.z};
+        solve_block_floor(Mb, Rb[b], fs[b], qv, meaninertia, nv, qacc + o);
+        info.rows_active = true;
+      }
+    }
+  }
+  }  // live
+  PP_ACC(info, 2, tt);
+  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb);  // all lanes
+  PP_ACC(info, 3, tt);
+  if (!live) return;
+  // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
+  {
+    double A[NJ][NJ], rhs[NJ], Dinv[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = Marm[i * (i + 1) / 2 + j];
+      rhs[i] = qacc[i];
+    }
+    rr::factor_system(A, clamped, Dinv);
+    rr::udu_solve(A, Dinv, rhs);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) qacc[i] = rhs[i];
+  }
+  double acc2 = 0, dq2 = 0;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const int o = NJ + 6 * b;
+    double Lb[6][6], x[6];
+    block_mass_matrix6(Rb[b], Lb);
+#pragma unroll
+    for (int i = 0; i < 6; i++) x[i] = qacc[o + i];
+    rr::chol6(Lb);
+    rr::chol6_solve(Lb, x);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { qacc[o + i] = x[i]; acc2 = fma(x[i], x[i], acc2); }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    acc2 = fma(qacc[j], qacc[j], acc2);
+    s.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+    const double dq = MJS_RR_PHYSICS_DT * s.v[j];
+    s.q[j] += dq;
+    dq2 = fma(dq, dq, dq2);
+    rr::rotate_small(cs[j], sn[j], dq);
+  }
+  if (!(dq2 <= 0.01)) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  }
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    if (b >= nb) continue;
+    const int o = NJ + 6 * b;
+    Block& k = s.b[b];
+    k.v = madd(k.v, MJS_RR_PHYSICS_DT, v3(qacc[o], qacc[o + 1], qacc[o + 2]));
+    k.w = madd(k.w, MJS_RR_PHYSICS_DT, v3(qacc[o + 3], qacc[o + 4], qacc[o + 5]));
+    k.p = madd(k.p, MJS_RR_PHYSICS_DT, k.v);
+    // mju_quatIntegrate with the body-frame angular velocity
+    double nrm = sqrt(k.q[0] * k.q[0] + k.q[1] * k.q[1] + k.q[2] * k.q[2] + k.q[3] * k.q[3]);
+    const double ang = sqrt(dot(k.w, k.w));
+    if (ang >= MJS_MINVAL) {
+      const V3 ax = (1.0 / ang) * k.w;
+      double sh, chf;
+      sincos(0.5 * ang * MJS_RR_PHYSICS_DT, &sh, &chf);
+      const double q0 = k.q[0] / nrm, q1 = k.q[1] / nrm, q2 = k.q[2] / nrm, q3 = k.q[3] / nrm;
+      const double r0 = chf, r1 = ax.x * sh, r2 = ax.y * sh, r3 = ax.z * sh;
+      k.q[0] = q0 * r0 - q1 * r1 - q2 * r2 - q3 * r3;
+      k.q[1] = q0 * r1 + q1 * r0 + q2 * r3 - q3 * r2;
+      k.q[2] = q0 * r2 - q1 * r3 + q2 * r0 + q3 * r1;
+      k.q[3] = q0 * r3 + q1 * r2 - q2 * r1 + q3 * r0;
+      nrm = sqrt(k.q[0] * k.q[0] + k.q[1] * k.q[1] + k.q[2] * k.q[2] + k.q[3] * k.q[3]);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) k.q[i] /= nrm;
+  }
+  info.bad = info.bad || !(acc2 <= 1e20);
+  s.time += MJS_RR_PHYSICS_DT;
+  PP_ACC(info, 4, tt);
+}
+
+// contacts of the current state as mj_forward / the trailing mj_step1 would report them (d->ncon)
+__device__ __noinline__ int count_contacts(const World& s, const double* cs, const double* sn, int nb) {
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  M3 Rb[NB];
+  for (int b = 0; b < nb; b++) {
+    double qn[4];
+    const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    Rb[b] = quat_to_m3(qn);
+  }
+  Contact con[MAXCON];
+  int extra;
+  bool eef_floor;
+  return detect_contacts(ch, s, Rb, nb, con, extra, eef_floor) + extra;
+}
+
+MJS_DEV bool tcp_to_joints(const double* pos, const double* guess, double* q_out) { return rr::tcp_pose_to_joints_offset(pos, MJS_CYL_TCP_Z, guess, q_out); }
+
+MJS_DEV void make_obs(const World& s, const double* cs, const double* sn, int nb, double* obs) {
+  rr::Chain c;
+  rr::fk_cs(cs, sn, c);
+  const V3 tcp = eef_tcp_position(c);
+  obs[0] = tcp.x; obs[1] = tcp.y; obs[2] = tcp.z;            // ur5e/tcp_position
+  obs[3] = s.target[0]; obs[4] = s.target[1];                // target_position = site.pos[:2]
+  for (int b = 0; b < NB; b++) {                             // block_positions = body xpos[:2]
+    obs[5 + 2 * b] = b < nb ? s.b[b].p.x : 0.0;
+    obs[6 + 2 * b] = b < nb ? s.b[b].p.y : 0.0;
+  }
+}
+
+// initialize_episode (robot_planar_push.py:149-176, intended semantics), first part: the draws. The 150 settle steps
+// run in the kernel's uniform substep loop. `commit` = false leaves the env's RNG stream untouched (padding lanes).
+__device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, bool commit) {
+  RngCursor c = rng_open(rng, i);
+  double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
+  for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
+  const bool ok = tcp_to_joints(rp, zeros, q);
+  for (int j = 0; j < NJ; j++) { s.q[j] = ok ? q[j] : 0.0; s.v[j] = 0; }
+  for (int k = 0; k < 3; k++) s.target[k] = rng_uniform(rng, i, c, MJS_PP_TARGET_SPACE_LO[k], MJS_PP_TARGET_SPACE_HI[k]);
+  s.time = 0;
+  s.episode_step = 0;
+  double cs[NJ], sn[NJ];
+  for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  for (int b = 0; b < NB; b++) { s.b[b].p = v3(0, 0, 0); s.b[b].q[0] = 1; s.b[b].q[1] = s.b[b].q[2] = s.b[b].q[3] = 0; s.b[b].v = v3(0, 0, 0); s.b[b].w = v3(0, 0, 0); }
+  for (int attempt = 0; attempt < 1000; attempt++) {  // randomize_object_position: until mj_forward reports ncon == 0
+    for (int b = 0; b < nb; b++) {
+      double bp[3];
+      for (int k = 0; k < 3; k++) bp[k] = rng_uniform(rng, i, c, MJS_PP_OBJECT_SPACE_LO[k], MJS_PP_OBJECT_SPACE_HI[k]);
+      s.b[b].p = v3(bp[0], bp[1], bp[2]);
+    }
+    if (count_contacts(s, cs, sn, nb) == 0) break;
+  }
+  if (commit) rng_close(rng, i, c);
+}
+
+// One workgroup = one wavefront = 64 envs, lane per env. Control flow is UNIFORM across the wavefront (the coupled
+// constraint problems are solved cooperatively): every lane runs the same substep loop, with `live` masking lanes
+// that have nothing to do in an iteration (padding lanes of the last workgroup, lanes that step while their neighbours
+// run the 150 settle steps of a reset).
+// wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines; the 5-slot
+// instance's cooperative workspace (~113 KB) leaves room for one wavefront per CU
+constexpr int WAVES = NB <= 2 ? 4 : 1;
+// Envs per wavefront. The coupled constraint problems of a wavefront's envs are solved one after the other by the
+// whole wavefront, so the critical path of a launch is set by the wavefront with the most coupled envs; at 4096 envs
+// the chip has 16x more SIMDs than 64-env wavefronts would use, so fewer envs per wavefront (the other lanes only
+// help in the cooperative solves) shorten that path.
+#ifndef MJS_PP_ENVS_PER_WAVE
+#define MJS_PP_ENVS_PER_WAVE 4
+#endif
+constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
+template <bool IS_RESET>
+__global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
+  const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
+  const bool valid = (threadIdx.x & 63) < EPW && gi < p.N;
+  const int i = valid ? gi : 0;  // helper / padding lanes shadow env 0 and never write
+  const int nb = p.n_objects;
+  uint8_t flags = p.flags[i];
+  double obs[OBS_DIM], cs[NJ], sn[NJ], ctrl0[NJ], q0[NJ], q1[NJ];
+  World s;
+  const bool masked_out = IS_RESET && p.reset_mask && !p.reset_mask[i];
+  const bool resetting = valid && !masked_out && (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP));
+  const bool stepping = valid && !IS_RESET && !resetting;
+  double t0 = 0, t1 = 1, inv_span = 1;
+  int nsub = 0;
+  if (resetting) {
+    episode_draws(p.rng, i, nb, s, valid);
+    nsub = MJS_PP_SETTLE_STEPS;
+    for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189)
+  } else if (stepping) {
+    s = load_world(p, i);
+    // before_step (base.py:31-32, robot_planar_push.py:185-201)
+    s.episode_step += 1.0;
+    double act[3] = {p.actions[(size_t)i * ACT_DIM], p.actions[(size_t)i * ACT_DIM + 1], MJS_PP_ACTION_Z};
+    for (int j = 0; j < NJ; j++) q0[j] = s.q[j];
+    if (!tcp_to_joints(act, q0, q1)) {
+      flags |= FLAG_IK_FAILED;
+      for (int j = 0; j < NJ; j++) q1[j] = q0[j];
+    }
+    t0 = s.time; t1 = s.time + MJS_RR_CONTROL_DT; inv_span = 1.0 / (t1 - t0);
+    nsub = MJS_RR_NSUB;
+  } else {
+    s = load_world(p, i);
+  }
+  for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  if (!valid) nsub = 0;  // helper lanes only take part in the cooperative solves
+  StepInfo info{false, false, false, 0};
+#ifdef MJS_STAMPS
+  for (int k = 0; k < 6; k++) info.cyc[k] = 0;
+#endif
+  int nmax = nsub;
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+#pragma unroll 1
+  for (int sub = 0; sub < nmax; sub++) {
+    double ctrl[NJ];
+    if (stepping) {
+      const double t = fmin(fmax(s.time, t0), t1);
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+    } else {
+      for (int j = 0; j < NJ; j++) ctrl[j] = ctrl0[j];
+    }
+    physics_step(s, ctrl, cs, sn, nb, info, sub < nsub);
+  }
+#ifdef MJS_STAMPS
+  if (p.stamps && threadIdx.x == 0 && !IS_RESET)
+    for (int k = 0; k < 6; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
+#endif
+  bool bad = info.bad, terminate = false;
+  if (resetting) {
+    const int ncon = count_contacts(s, cs, sn, nb);
+    if (valid) {
+      store_world(p, i, s);
+      p.flags[i] = 0;
+      make_obs(s, cs, sn, nb, obs);
+      write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
+    }
+  } else if (stepping) {
+    for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
+    for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
+    make_obs(s, cs, sn, nb, obs);
+    // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
+    double sum = 0, nearest = INFINITY;
+    int inside = 0;
+    for (int b = 0; b < nb; b++) {
+      const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
+      const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
+      sum += dt;
+      inside += dt < MJS_PP_TARGET_RADIUS;
+      nearest = fmin(nearest, dr);
+    }
+    const bool success = inside == nb;
+    double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
+    double discount = success ? 0.0 : 1.0;
+    terminate = success || s.episode_step >= (double)p.max_episode_steps;
+    if (bad) { reward = 0; discount = 0; terminate = true; }
+    if (s.time >= p.time_limit) terminate = true;
+    const int ncon = count_contacts(s, cs, sn, nb);
+    const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+                      (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
+    const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+    if (valid) {
+      store_world(p, i, s);
+      p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+      write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+    }
+  }
+  // same-step auto-reset (SB3 VecEnv convention): the lanes whose episode just ended run a reset, the others idle
+  if (!IS_RESET && p.autoreset == MJS_AUTORESET_SAME_STEP && __any(stepping && terminate)) {
+    const bool again = stepping && terminate;
+    if (again) {
+      if (valid && p.out.terminal_obs)
+        for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+      episode_draws(p.rng, i, nb, s, valid);
+      for (int j = 0; j < NJ; j++) { ctrl0[j] = s.q[j]; sincos(s.q[j], &sn[j], &cs[j]); }
+    }
+    StepInfo info2{false, false, false, 0};
+#ifdef MJS_STAMPS
+    for (int k = 0; k < 6; k++) info2.cyc[k] = 0;
+#endif
+#pragma unroll 1
+    for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid);
+    if (again) {
+      const int ncon2 = count_contacts(s, cs, sn, nb);
+      if (valid) {
+        store_world(p, i, s);
+        p.flags[i] = 0;
+        make_obs(s, cs, sn, nb, obs);
+        if (p.out.obs)
+          for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+        if (p.out.ncon) p.out.ncon[i] = ncon2;
+      }
+    }
+  }
+}
+
+}  // namespace MJS_PP_NS

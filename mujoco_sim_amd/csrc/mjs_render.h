@@ -337,9 +337,9 @@ __global__ __launch_bounds__(64) void button_prims_kernel(const double* state, c
 }
 
 // Planar-Push scene (robot_planar_push.py:81-117): arm proxies + base stand-in, CylinderEEF, target site disc, blocks
-constexpr int PP_NPRIM = ARM_NREC + 1 + pp::NB;
+constexpr int PP_NPRIM = ARM_NREC + 1 + MJS_PP_MAX_OBJECTS;  // capacity; a launch uses ARM_NREC + 1 + block slots of its handle
 static_assert(PP_NPRIM <= MAX_NPRIM, "one candidate bit per primitive");
-__global__ __launch_bounds__(64) void push_prims_kernel(const double* state, float* prims, int N, int nb) {
+__global__ __launch_bounds__(64) void push_prims_kernel(const double* state, float* prims, int N, int nb, int nslots) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= N) return;
   double q[6];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(64) void push_prims_kernel(const double* state, flo
   for (int j = 0; j < 6; j++) q[j] = state[(size_t)(pp::S_Q + j) * N + i];
   rr::Chain c;
   rr::fk(q, c);
-  float* out = prims + (size_t)i * PP_NPRIM * PRIM_FLOATS;
+  float* out = prims + (size_t)i * (ARM_NREC + 1 + nslots) * PRIM_FLOATS;
   arm_prims(c, out);
   {  // CylinderEEF replaces the gripper stand-in record: axis = flange z = wrist_3 y
     float* pr = out + (ARM_NREC - 1) * PRIM_FLOATS;
@@ -369,8 +369,7 @@ __global__ __launch_bounds__(64) void push_prims_kernel(const double* state, flo
     pr[17] = bound_radius((float)MJS_PP_TARGET_RADIUS + MJS_PP_TARGET_HALF_HEIGHT);
     put_rgb(pr + 14, MJS_PP_TARGET_RGB);
   }
-#pragma unroll
-  for (int b = 0; b < pp::NB; b++) {
+  for (int b = 0; b < nslots; b++) {
     float* pr = out + (ARM_NREC + 1 + b) * PRIM_FLOATS;
     const double* bs = state + (size_t)(pp::S_BLOCK + pp::BLOCK_DIM * b) * N + i;
     double qn[4] = {bs[3 * (size_t)N], bs[4 * (size_t)N], bs[5 * (size_t)N], bs[6 * (size_t)N]};

@@ -135,8 +135,10 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)
+  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects <= MJS_PP_FAST_OBJECTS)
     pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, sizeof(pp::CoopLds) * pp::WAVES, s>>>(p);
+  else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)  // 3..5 blocks: the 5-slot instance, its cooperative workspace needs the large-LDS opt-in (mjs_create)
+    pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, sizeof(pp5::CoopLds) * pp5::WAVES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
@@ -164,6 +166,8 @@ int mjs_action_dim(int task) { return mjs_action_dim_for(task, MJS_ACTION_ABS_JO
 int mjs_state_dim(int task) {
   return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : task == MJS_TASK_BUTTON_PUSH ? bp::STATE_DIM + 1 : task == MJS_TASK_PLANAR_PUSH ? pp::STATE_DIM + 1 : -1;
 }
+int mjs_env_obs_dim(const mjs_handle* h) { return h ? h->obs_dim : -1; }
+int mjs_env_state_dim(const mjs_handle* h) { return h ? h->state_dim + 1 : -1; }
 int mjs_substeps(int task) {
   return task == MJS_TASK_POINTMASS_REACH ? MJS_PM_NSUB : (task == MJS_TASK_ROBOT_REACH || task == MJS_TASK_BUTTON_PUSH || task == MJS_TASK_PLANAR_PUSH) ? MJS_RR_NSUB : -1;
 }
@@ -202,15 +206,22 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (!h) return fail(nullptr, MJS_ERR_ALLOC, "mjs_create: out of host memory");
   h->cfg = *cfg;
   if (h->cfg.reward_type < 0) h->cfg.reward_type = default_reward(cfg->task);
-  if (h->cfg.n_objects <= 0) h->cfg.n_objects = MJS_PP_MAX_OBJECTS;
+  if (h->cfg.n_objects <= 0) h->cfg.n_objects = MJS_PP_FAST_OBJECTS;
   if (h->cfg.max_episode_steps <= 0) h->cfg.max_episode_steps = MJS_PP_MAX_CONTROL_STEPS;
   if (!(h->cfg.time_limit > 0)) h->cfg.time_limit = default_time_limit(cfg->task);
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);
+  if (cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) { h->state_dim = pp5::STATE_DIM; h->obs_dim = pp5::OBS_DIM; }
   h->act_dim = mjs_action_dim_for(cfg->task, cfg->action_type);
   h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr; h->cams = nullptr;
   const size_t N = (size_t)cfg->num_envs;
   hipError_t e = hipSetDevice(cfg->device);
+  if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) {
+    // > 64 KB of dynamic LDS per workgroup is an opt-in (gfx950 has 160 KB per CU)
+    static_assert(sizeof(pp5::CoopLds) * pp5::WAVES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(pp5::CoopLds) * pp5::WAVES));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(pp5::CoopLds) * pp5::WAVES));
+  }
   if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(double) * h->state_dim * N);
   if (e == hipSuccess) e = hipMalloc(&h->flags, N);
   if (e == hipSuccess) e = hipMalloc(&h->rng_mt, sizeof(uint32_t) * 624 * N);
@@ -367,8 +378,9 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
     if (wrist) p.env_cams = h->cams;
     rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   } else if (task == MJS_TASK_PLANAR_PUSH) {  // robot_planar_push.py:45,66: the FRONT_TILTED camera of Robot-Reach
-    rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects);
-    p.nprim = rend::PP_NPRIM;
+    const int nslots = MJS_PP_OBJECT_SLOTS(h->cfg.n_objects);
+    rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects, nslots);
+    p.nprim = rend::ARM_NREC + 1 + nslots;
     rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   } else {
     rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);

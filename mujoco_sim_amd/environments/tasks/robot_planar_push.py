@@ -1,8 +1,7 @@
 """Planar-Push task description (host side).
 
 Mirrors ``mujoco_sim/environments/tasks/robot_planar_push.py:28-73`` (RobotPushConfig dataclass: same fields and
-defaults, except ``n_objects`` which defaults to 2 = BASELINE config 4 and is limited to 2, the reference default
-is 5) and the task surface at :76-241 (``action_spec``, ``create_random_policy``). Physics and task logic run in
+defaults: ``n_objects`` = 5, the registered env and BASELINE config 4 use 2) and the task surface at :76-241 (``action_spec``, ``create_random_policy``). Physics and task logic run in
 csrc/mjs_push.h with the INTENDED semantics where the reference is broken at HEAD (seeded object
 draws, ``episode_step`` limit); blocks are box stand-ins for the cube mesh.
 """
@@ -34,15 +33,15 @@ class RobotPushConfig:
     image_resolution: int = 64
     nearest_object_reward_coefficient: float = 0.1
     target_radius = 0.05
-    n_objects: int = 2
+    n_objects: int = 5  # robot_planar_push.py:61; 1..2 run the 2-slot kernel, 3..5 the 5-slot kernel
 
     def __post_init__(self):
         self.reward_type = self.reward_type or RobotPushConfig.DENSE_NEG_DISTANCE_REWARD
         self.observation_type = self.observation_type or RobotPushConfig.STATE_OBS
         assert self.observation_type in RobotPushConfig.OBSERVATION_TYPES
         assert self.reward_type in RobotPushConfig.REWARD_TYPES
-        if not 1 <= self.n_objects <= 2:
-            raise NotImplementedError("n_objects must be 1 or 2 (MJS_PP_MAX_OBJECTS)")
+        if not 1 <= self.n_objects <= 5:
+            raise NotImplementedError("n_objects must be 1..5 (MJS_PP_MAX_OBJECTS)")
         if self.nearest_object_reward_coefficient != 0.1 or self.physics_timestep != 0.005 or self.control_timestep != 0.1:
             raise NotImplementedError("timesteps and the reward coefficient are compiled-in scene constants")
 

@@ -132,10 +132,13 @@ class HipVectorEnv:
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h
-        self.obs_dim = self._lib.mjs_obs_dim(self.spec.task_id)
+        self.obs_dim = self._lib.mjs_env_obs_dim(h)  # Planar-Push: 2 block slots for n_objects <= 2, 5 for 3..5
         self.action_dim = self._lib.mjs_action_dim_for(self.spec.task_id, _ACTION_IDS.get(action_type, 0))
-        self.state_dim = self._lib.mjs_state_dim(self.spec.task_id)
+        self.state_dim = self._lib.mjs_env_state_dim(h)
         self.algorithmic_bytes_per_env_step = self._lib.mjs_algorithmic_bytes_per_env_step(self.spec.task_id)
+        if self.state_dim != self._lib.mjs_state_dim(self.spec.task_id):  # Planar-Push, 5 block slots: same formula, wider rows
+            S = self.state_dim - 1
+            self.algorithmic_bytes_per_env_step = 8 * S + 8 * (S - 3) + 2 + 8 * self.action_dim + 8 * self.obs_dim + 25
         N, dev = self.num_envs, self.device
         self._buf = {
             "obs": torch.zeros(N, self.obs_dim, dtype=torch.float64, device=dev),

@@ -27,14 +27,14 @@ extern "C" {
 
 #define OM_MAXBODY 16
 #define OM_MAXJNT 24
-#define OM_MAXQ 32
-#define OM_MAXV 24
+#define OM_MAXQ 48
+#define OM_MAXV 36
 #define OM_MAXU 8
 #define OM_MAXGEOM 40
 #define OM_MAXSITE 8
 #define OM_MAXEQ 2
 #define OM_MAXCON 48
-#define OM_MAXEFC 200
+#define OM_MAXEFC 320
 #define OM_MAXMOCAP 1
 
 /* MuJoCo enums (values as in mjmodel.h) */
@@ -141,7 +141,7 @@ typedef struct {
   int terminate_on_success;  /* Robot-Reach only: opt-in (deviation D-2) */
   int action_type;           /* Button-Push only */
   int button_disturbances;   /* Button-Push only: robot_push_button.py:159-165 */
-  int n_objects;             /* Planar-Push only: 1..MJS_PP_MAX_OBJECTS blocks */
+  int n_objects;             /* Planar-Push only: 1..MJS_PP_MAX_OBJECTS blocks (<= 0: 2) */
   int max_episode_steps;     /* Planar-Push only: RobotTask step limit (base.py:47-51), default 500 */
 } om_task_config;
 
@@ -175,6 +175,7 @@ typedef struct {
 
 void om_default_config(int task, om_task_config* cfg);
 int om_obs_dim(int task);
+int om_obs_dim_for(const om_task_config* cfg); /* Planar-Push: 5 + 2 * block slots of cfg->n_objects */
 int om_action_dim(int task);
 void om_env_init(om_env* e, const om_task_config* cfg, uint32_t seed);
 void om_env_seed(om_env* e, uint32_t seed);

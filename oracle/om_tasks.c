@@ -253,7 +253,7 @@ void om_default_config(int task, om_task_config* cfg) {
   } else if (task == OM_TASK_PLANAR_PUSH) {
     cfg->reward_type = OM_REW_DENSE_NEG_DISTANCE;                         /* robot_planar_push.py:69 */
     cfg->time_limit = 1e300;                                              /* scripts/sb3/planar_push.py:72: no Environment time limit */
-    cfg->n_objects = MJS_PP_MAX_OBJECTS;                                  /* BASELINE config 4 */
+    cfg->n_objects = MJS_PP_FAST_OBJECTS;                                 /* BASELINE config 4 / robot_planar_push.py:315 */
     cfg->max_episode_steps = MJS_PP_MAX_CONTROL_STEPS;                    /* robot_planar_push.py:53 */
   } else if (task == OM_TASK_BUTTON_PUSH) {
     cfg->reward_type = OM_REW_SPARSE;                                     /* robot_push_button.py:47 */
@@ -265,8 +265,12 @@ void om_default_config(int task, om_task_config* cfg) {
   }
 }
 /* Button-Push flat obs: ur5e/joint_configuration(6), ur5e/tcp_position(3), switch position(3), active(1) */
-/* Planar-Push flat obs: ur5e/tcp_position(3), target_position(2), block_positions(2 per block, MAX_OBJECTS slots) */
-int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : task == OM_TASK_BUTTON_PUSH ? 13 : task == OM_TASK_PLANAR_PUSH ? 5 + 2 * MJS_PP_MAX_OBJECTS : 12; }
+/* Planar-Push flat obs: ur5e/tcp_position(3), target_position(2), block_positions(2 per block slot: 2 slots for
+ * n_objects <= 2, 5 otherwise; om_obs_dim() is the 2-slot layout, om_obs_dim_for() the configured one) */
+int om_obs_dim(int task) { return task == OM_TASK_POINTMASS ? 4 : task == OM_TASK_BUTTON_PUSH ? 13 : task == OM_TASK_PLANAR_PUSH ? 5 + 2 * MJS_PP_FAST_OBJECTS : 12; }
+int om_obs_dim_for(const om_task_config* cfg) {
+  return cfg->task == OM_TASK_PLANAR_PUSH ? 5 + 2 * MJS_PP_OBJECT_SLOTS(cfg->n_objects > 0 ? cfg->n_objects : MJS_PP_FAST_OBJECTS) : om_obs_dim(cfg->task);
+}
 int om_action_dim(int task) { return task == OM_TASK_POINTMASS ? 2 : task == OM_TASK_BUTTON_PUSH ? 7 : task == OM_TASK_PLANAR_PUSH ? 2 : 3; }
 int om_sizeof_step_out(void) { return (int)sizeof(om_step_out); }
 
@@ -314,7 +318,7 @@ static void write_obs(const om_env* e, double* obs) {
   } else if (e->cfg.task == OM_TASK_PLANAR_PUSH) {
     get_tcp_position(e, obs);                                /* ur5e/tcp_position */
     obs[3] = e->target_pos[0]; obs[4] = e->target_pos[1];   /* target_position = site.pos[:2] (robot_planar_push.py:120) */
-    for (int i = 0; i < MJS_PP_MAX_OBJECTS; i++)             /* block_positions = body xpos[:2] per block (:178-179) */
+    for (int i = 0; i < MJS_PP_OBJECT_SLOTS(e->cfg.n_objects); i++) /* block_positions = body xpos[:2] per block (:178-179) */
       for (int k = 0; k < 2; k++) obs[5 + 2 * i + k] = i < e->cfg.n_objects ? e->d.qpos[6 + 7 * i + k] : 0.0;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {
     for (int j = 0; j < 6; j++) obs[j] = e->d.qpos[j];       /* ur5e/joint_configuration (robot.py:296-298) */

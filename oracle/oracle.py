@@ -179,7 +179,8 @@ class OracleBatch:
         if max_episode_steps is not None:
             cfg.max_episode_steps = max_episode_steps
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
-        self.obs_dim, self.action_dim = L.om_obs_dim(task), L.om_action_dim(task)
+        L.om_obs_dim_for.argtypes = [C.c_void_p]
+        self.obs_dim, self.action_dim = L.om_obs_dim_for(C.byref(cfg)), L.om_action_dim(task)
         if task == TASK_BUTTON_PUSH and cfg.action_type == ACTION_ABS_EEF:
             self.action_dim = 4
         self._h = L.om_batch_create(C.byref(cfg), n, base_seed & 0xFFFFFFFF)

@@ -50,7 +50,7 @@ def test_create_rejects_bad_arguments(native):
     assert L.mjs_create(None, C.byref(h)) == -1
     cfg = native.MjsConfig(task=3, num_envs=4, device=0, reward_type=-1, autoreset=0, action_type=9)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1  # bad action_type
-    cfg = native.MjsConfig(task=2, num_envs=4, device=0, reward_type=-1, autoreset=0, n_objects=5)
+    cfg = native.MjsConfig(task=2, num_envs=4, device=0, reward_type=-1, autoreset=0, n_objects=6)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"n_objects" in L.mjs_last_error(None)
     cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=7)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"autoreset" in L.mjs_last_error(None)

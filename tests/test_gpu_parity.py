@@ -730,6 +730,65 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
     assert sens.mean() < 0.2 and n_last >= N
 
 
+@pytest.mark.parametrize("n_objects", [3, 5])
+def test_planar_push_many_objects(oracle_mod, n_objects):
+    """n_objects 3..5 (5 = RobotPushConfig's default, robot_planar_push.py:61) run the 5-slot kernel instance: 15-wide flat
+    observation, up to 10 block-block pairs, nv = 36. Seeded episodes with pushes, step-limit truncations and
+    device-side resets against the oracle, on the envs the oracle itself calls well-conditioned."""
+    import ctypes as C
+
+    import mujoco_sim_amd as m
+
+    N, T, LIMIT = 16, 16, 7
+    knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=77, n_objects=n_objects, max_episode_steps=LIMIT)
+    assert venv.obs_dim == 15 and venv.state_dim == 1 + 17 + 13 * 5
+    assert venv.single_observation_space["block_positions"].shape == (2 * n_objects,)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    venv.reset()
+    o = ob.reset()
+    knob.value = 1e-13
+    o2 = ob2.reset()
+    knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    g = _gpu_result(venv)
+    np.testing.assert_allclose(g["obs"][~sens], o["obs"][~sens], rtol=0, atol=1e-8, err_msg="reset obs")
+    assert np.array_equal(np.asarray(g["ncon"])[~sens], o["ncon"][~sens])
+    rs = np.random.RandomState(5)
+    n_last, beyond_floor = 0, 0
+    for t in range(T):
+        k = 5 + 2 * ((t // 4) % n_objects)  # chase one block for a few steps, then the next
+        tcp, blk = o["obs"][:, :2], o["obs"][:, k:k + 2]
+        a = tcp + np.clip(blk - tcp, -0.025, 0.025) + rs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        knob.value = 1e-13
+        o2 = ob2.step(a)
+        knob.value = 0.0
+        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        g = _gpu_result(venv)
+        ok = ~sens
+        np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
+        np.testing.assert_allclose(g["reward"][ok], o["reward"][ok], rtol=0, atol=1e-8)
+        for key in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[key])[ok].astype(int), np.asarray(o[key])[ok].astype(int)), (key, t)
+        assert not (np.asarray(g["fault"])[ok] & (1 | 8)).any()
+        n_last += int(((o["step_type"] == 2) & ok).sum())
+        beyond_floor += int((o["ncon"][ok] > 4 * n_objects).sum())
+        assert (g["obs"][:, 5 + 2 * n_objects:] == 0).all()  # unused block slots of the flat layout
+    assert sens.mean() < 0.5 and n_last >= N // 2 and beyond_floor > 0
+    # checkpoint / resume keeps the wider layout
+    st = venv.get_state()
+    assert st.shape == (venv.state_dim, N)
+    venv.set_state(st)
+    img = venv.render(32, 32).cpu().numpy()
+    ref = ob.render(32, 32)
+    ok_img = ~sens
+    assert (np.abs(img[ok_img].astype(int) - ref[ok_img].astype(int)) > 2).mean() < 0.01
+    venv.close()
+
+
 @pytest.mark.parametrize("task,kw", [("robot_push_button", {"action_type": "absolute_eef_action"}), ("robot_planar_push", {"max_episode_steps": 9})])
 def test_contact_tasks_shard_invariance(task, kw):
     """Multi-GPU sharding for the contact tasks: env i of one 64-env handle is bit-identical to env i of

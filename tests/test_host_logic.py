@@ -52,8 +52,9 @@ def test_contact_task_descriptions_mirror_reference_defaults():
     assert (c.physics_timestep, c.control_timestep, c.max_control_steps_per_episode, c.target_radius, c.nearest_object_reward_coefficient) == (0.005, 0.1, 500, 0.05, 0.1)
     spec = RobotPushTask(c).action_spec()
     assert spec.shape == (2,) and spec.dtype == np.float32 and np.allclose(spec.maximum, 1.0)
+    assert c.n_objects == 5  # robot_planar_push.py:61
     with pytest.raises(NotImplementedError):
-        RobotPushConfig(n_objects=5)  # the reference default; this build is limited to 2 blocks
+        RobotPushConfig(n_objects=6)  # MJS_PP_MAX_OBJECTS = 5 block slots
     with pytest.raises(AssertionError):
         RobotPushConfig(reward_type="nope")
 
