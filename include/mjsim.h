@@ -99,7 +99,8 @@ const char* mjs_version(void);
  * Robot-Reach {ur5e/tcp_position(3), ur5e/joint_configuration(6), target_position(3)}
  * (robot_reach.py:134-137, robot.py:292-298); Button-Push {ur5e/joint_configuration(6),
  * ur5e/tcp_position(3), switch/position(3), switch/active(1)} (robot_push_button.py:113-119, switch.py:99-108);
- * Planar-Push {ur5e/tcp_position(3), target_position(2), block_positions(2 per block, 2 slots)}
+ * Planar-Push {ur5e/tcp_position(3), target_position(2), block_positions(2 per block slot; 2 slots here,
+ * 5 for handles with n_objects 3..5: mjs_env_obs_dim)}
  * (robot_planar_push.py:120-126,134-138,178-179) */
 int mjs_obs_dim(int task);
 /* action width: 2 (point_reach.py:204-209) / 3 (robot_reach.py:187-201) / Button-Push default 7
