@@ -26,6 +26,19 @@ constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK
 constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
 constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
 constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
+// wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines; the 5-slot
+// instance's cooperative workspace (~113 KB) leaves room for one wavefront per CU
+constexpr int WAVES = NB <= 2 ? 4 : 1;
+// Envs per wavefront. The coupled constraint problems of a wavefront's envs are solved one after the other by the
+// whole wavefront, so the critical path of a launch is set by the wavefront with the most coupled envs; at 4096 envs
+// the chip has 16x more SIMDs than 64-env wavefronts would use, so fewer envs per wavefront (the other lanes only
+// help in the cooperative solves) shorten that path.
+#ifndef MJS_PP_ENVS_PER_WAVE
+#define MJS_PP_ENVS_PER_WAVE 4
+#endif
+constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
+static_assert(EPW >= 1 && EPW <= 16 && (EPW & (EPW - 1)) == 0, "quads of lanes per (env, block): 4 * EPW lanes per block");
+constexpr int QUAD_BLOCKS = 16 / EPW;  // blocks whose quads fit the wavefront in one pass
 
 struct Block {
   V3 p;          // body origin = centre of the bottom face (free joint qpos[0:3])
@@ -618,11 +631,194 @@ MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangl
   M[4][0] = M[0][4] = cy.x; M[4][1] = M[1][4] = cy.y; M[4][2] = M[2][4] = cy.z;
 }
 
+// ---- the decoupled case, lane-parallel -------------------------------------------------------------------------
+// Only EPW of the 64 lanes of a wavefront carry an env and FP64 has no lane skipping, so the per-block floor problems
+// are dealt to QUADS of lanes: quad (block, env), one floor corner per lane. A lane holds only its corner's four
+// contact-frame Jacobian rows (24 values instead of 96: no spills); the 6x6 Hessian, the constraint force, the cost
+// and the line-search sums are quad reductions (two DPP quad_perm butterflies: every lane of the quad gets the same
+// bits, so the quad's control flow stays uniform); the 6x6 factorisations are replicated. Inputs and results travel
+// through the wavefront's LDS workspace.
+template <int CTRL>
+MJS_DEV double dpp_f64(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+MJS_DEV double quad_sum(double x) {
+  x += dpp_f64<0xB1>(x);  // quad_perm [1, 0, 3, 2]
+  x += dpp_f64<0x4E>(x);  // quad_perm [2, 3, 0, 1]
+  return x;
+}
+MJS_DEV void quad_block_floor(const M3 R, const double* qvel, const double* f, bool on, double dist, V3 r, double meaninertia, int nv_total, double* f_out) {
+  const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  double Mb[6][6];
+  block_mass_matrix6(R, Mb);
+  double Jc[4][6], aref[6];  // this lane's corner: rows normal, t1, t2, torsion (frame of n = +z as in solve_block_floor)
+  const V3 axs[3] = {R.cx, R.cy, R.cz};
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    const V3 lin = cross(axs[d], r);
+    Jc[0][d] = d == 2 ? 1.0 : 0.0; Jc[0][3 + d] = lin.z;
+    Jc[1][d] = d == 1 ? 1.0 : 0.0; Jc[1][3 + d] = lin.y;
+    Jc[2][d] = d == 0 ? -1.0 : 0.0; Jc[2][3 + d] = -lin.x;
+    Jc[3][d] = 0.0; Jc[3][3 + d] = axs[d].z;
+  }
+  const double imp = impedance_default(dist);
+  const double tran = 1.0 / MJS_BLOCK_MASS;
+  const double D = 1 / (2 * mu[0] * mu[0] * fmax(MJS_MINVAL, (1 - imp) * (tran + mu[0] * mu[0] * tran) / imp));
+  auto edge_values = [&](const double* x, double* out6) {
+    double u[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int rw = 0; rw < 4; rw++) {
+#pragma unroll
+      for (int d = 0; d < 6; d++) u[rw] += Jc[rw][d] * x[d];
+    }
+#pragma unroll
+    for (int e = 0; e < 6; e++) out6[e] = u[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * u[1 + (e >> 1)];
+  };
+  {
+    double ev[6];
+    edge_values(qvel, ev);
+#pragma unroll
+    for (int e = 0; e < 6; e++) aref[e] = -B * ev[e] - K * imp * dist;
+  }
+  double L[6][6], a[6], a_s[6], Ma[6], jar[6], force[6];
+  bool act[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = Mb[i][j];
+    a_s[i] = f[i];
+  }
+  rr::chol6(L);
+  rr::chol6_solve(L, a_s);
+#pragma unroll
+  for (int i = 0; i < 6; i++) a[i] = a_s[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double m = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * a[k];
+    Ma[i] = m;
+  }
+  edge_values(a, jar);
+#pragma unroll
+  for (int e = 0; e < 6; e++) jar[e] -= aref[e];
+  auto update = [&]() {
+    double cost = 0;
+#pragma unroll
+    for (int e = 0; e < 6; e++) {
+      const bool o = on && jar[e] < 0;
+      act[e] = o;
+      force[e] = o ? -D * jar[e] : 0.0;
+      cost += o ? 0.5 * D * jar[e] * jar[e] : 0.0;
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) gauss += (Ma[i] - f[i]) * (a[i] - a_s[i]);
+    return quad_sum(cost) + 0.5 * gauss;
+  };
+  auto constraint_force = [&](double* fc) {
+    const double fn = force[0] + force[1] + force[2] + force[3] + force[4] + force[5];
+    const double f1 = mu[0] * (force[0] - force[1]), f2 = mu[1] * (force[2] - force[3]), f3 = mu[2] * (force[4] - force[5]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) fc[i] = quad_sum(fn * Jc[0][i] + f1 * Jc[1][i] + f2 * Jc[2][i] + f3 * Jc[3][i]);
+  };
+  double cost = update();
+  const double scale = 1 / (meaninertia * nv_total);
+#pragma unroll 1
+  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    double grad[6], search[6], Mv[6], H[6][6], fc[6];
+    constraint_force(fc);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      grad[i] = Ma[i] - f[i] - fc[i];
+      search[i] = -grad[i];
+    }
+    {  // this corner's share of J^T D J over its active edges, then the quad sum
+      double wn = 0, w[3], ww[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        const double np_ = act[2 * k], nm = act[2 * k + 1];
+        wn += np_ + nm;
+        w[k] = D * mu[k] * (np_ - nm);
+        ww[k] = D * mu[k] * mu[k] * (np_ + nm);
+      }
+      wn *= D;
+#pragma unroll
+      for (int i = 0; i < 6; i++) {
+        const double jn = Jc[0][i];
+        const double rn = wn * jn + w[0] * Jc[1][i] + w[1] * Jc[2][i] + w[2] * Jc[3][i];
+        const double r1 = w[0] * jn + ww[0] * Jc[1][i], r2 = w[1] * jn + ww[1] * Jc[2][i], r3 = w[2] * jn + ww[2] * Jc[3][i];
+#pragma unroll
+        for (int j = 0; j <= i; j++) H[i][j] = Mb[i][j] + quad_sum(rn * Jc[0][j] + r1 * Jc[1][j] + r2 * Jc[2][j] + r3 * Jc[3][j]);
+      }
+    }
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * search[k];
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { g1 += search[i] * (Ma[i] - f[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+    double jv[6];
+    edge_values(search, jv);
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double p1 = 0, p2 = 0;
+#pragma unroll
+      for (int e = 0; e < 6; e++) {
+        const double x = jar[e] + alpha * jv[e];
+        const bool o = on && x < 0;
+        p1 += o ? D * x * jv[e] : 0.0;
+        p2 += o ? D * jv[e] * jv[e] : 0.0;
+      }
+      const double d1 = g1 + alpha * g2 + quad_sum(p1), d2 = g2 + quad_sum(p2);
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha + (-d1 / d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < 6; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
+#pragma unroll
+    for (int e = 0; e < 6; e++) jar[e] += alpha * jv[e];
+    const double oldcost = cost;
+    cost = update();
+    constraint_force(fc);
+    double gn = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      const double g = Ma[i] - f[i] - fc[i];
+      gn += g * g;
+    }
+    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
+  }
+  double fc[6];
+  constraint_force(fc);
+#pragma unroll
+  for (int i = 0; i < 6; i++) f_out[i] = f[i] + fc[i];
+}
+
 struct StepInfo {
   bool bad, rows_active, unsupported;
   int ncon;
 #ifdef MJS_STAMPS
-  unsigned long long cyc[6];
+  unsigned long long cyc[16];  // 0..5 phase cycles, 6 = cooperative solves, 7 = their Newton iterations, 8..15 = phases inside them
 #endif
 };
 #ifndef PP_TIC
@@ -672,6 +868,18 @@ struct CoopLds {
 // to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
 extern __shared__ double pp_lds_raw[];
 MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
+// exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
+// cooperative solver, which runs after it
+struct QuadIn {
+  double R[9], qv[6], f[6], dist[4], r[4][3];
+  int on[4], need;
+};
+struct QuadLds {
+  QuadIn in[EPW][NB];
+  double out[EPW][NB][6];
+};
+static_assert(sizeof(QuadLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
+MJS_DEV QuadLds& quad_lds() { return *reinterpret_cast<QuadLds*>(&coop_lds()); }
 MJS_DEV double wave_sum(double x) {
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
@@ -727,8 +935,10 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
   return ok;
 }
 // cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
-MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
+MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepInfo& info) {
   const int nrow = sh.nrow;
+  unsigned long long tn = 0;
+  PP_TIC(tn);
   // qacc_smooth = M^-1 qfrc_smooth: M is block diagonal (arm, block 0, block 1), one lane per 6x6 block
   if (lane < nv / 6) {
     double L[6][6], x[6];
@@ -770,6 +980,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
     return wave_sum(cost);
   };
   double cost = update();
+  PP_ACC(info, 8, tn);
   const double scale = 1 / (meaninertia * nv);
   // this lane's (up to NHE) entries of the lower triangle of the Hessian
   constexpr int NHE = (NV * (NV + 1) / 2 + 63) / 64;
@@ -785,7 +996,9 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
     hi[q] = i;
     hj[q] = (he[q] ? e : 0) - i * (i + 1) / 2;
   }
+  int iters = 0;
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    iters++;
     // gradient -> search = -grad ; Hessian = M + J^T diag(D active) J
     if (lane < nv) {
       double g = sh.Ma[lane] - sh.qs[lane];
@@ -807,7 +1020,9 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
         if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
     }
     MJS_WAVE_SYNC();
+    PP_ACC(info, 9, tn);
     if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
+    PP_ACC(info, 10, tn);
     if (lane < nv) {
       double m = 0;
       for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
@@ -819,6 +1034,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
       sh.jv[r] = x;
     }
     MJS_WAVE_SYNC();
+    PP_ACC(info, 11, tn);
     double g1 = 0, g2 = 0, sn2 = 0;
     if (lane < nv) { g1 = sh.search[lane] * (sh.Ma[lane] - sh.qs[lane]); g2 = sh.search[lane] * sh.Mv[lane]; sn2 = sh.search[lane] * sh.search[lane]; }
     g1 = wave_sum(g1); g2 = wave_sum(g2); sn2 = wave_sum(sn2);
@@ -840,6 +1056,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
       if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
       alpha = next;
     }
+    PP_ACC(info, 12, tn);
     if (alpha == 0) break;
     if (lane < nv) { sh.a[lane] += alpha * sh.search[lane]; sh.Ma[lane] += alpha * sh.Mv[lane]; }
     for (int r = lane; r < nrow; r += 64) sh.jar[r] += alpha * sh.jv[r];
@@ -853,6 +1070,7 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
       gn = g * g;
     }
     gn = wave_sum(gn);
+    PP_ACC(info, 13, tn);
     if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
   }
   MJS_WAVE_SYNC();
@@ -862,6 +1080,8 @@ MJS_DEV void coop_newton(CoopLds& sh, int nv, double meaninertia, int lane) {
     sh.fc[lane] = f;
   }
   MJS_WAVE_SYNC();
+  PP_ACC(info, 14, tn);
+  return iters;
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
 MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
@@ -1027,9 +1247,16 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
     if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb);
     MJS_WAVE_SYNC();
     PP_ACC(info, 5, tp);
+    PP_TIC(tp);
     coop_build_rows(sh, nb, lane);
     MJS_WAVE_SYNC();
-    if (sh.nrow > 0) coop_newton(sh, nv, meaninertia, lane);
+    PP_ACC(info, 15, tp);
+    const int iters = sh.nrow > 0 ? coop_newton(sh, nv, meaninertia, lane, info) : 0;
+#ifdef MJS_STAMPS
+    info.cyc[6] += 1; info.cyc[7] += iters;
+#else
+    (void)iters;
+#endif
     if (lane == owner) {
       for (int i = 0; i < nv; i++) qacc[i] = sh.qs[i] + (sh.nrow > 0 ? sh.fc[i] : 0.0);
     }
@@ -1099,26 +1326,67 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   // which constraint problem?
 #pragma unroll
   for (int j = 0; j < NJ; j++) coupled = coupled || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
-  if (coupled) {
-    info.rows_active = true;
-  } else {
-    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+  if (coupled) info.rows_active = true;
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
-      if (b >= nb) continue;
-      const int o = NJ + 6 * b;
-      block_smooth_force(Rb[b], s.b[b].w, qacc + o);
-      const bool any = fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3];
-      if (any) {
-        double Mb[6][6];
-        block_mass_matrix6(Rb[b], Mb);
-        const double qv[6] = {s.b[b].v.x, s.b[b].v.y, s.b[b].v.z, s.b[b].w.x, s.b[b].w.y, s.b[b].w.z};
-        solve_block_floor(Mb, Rb[b], fs[b], qv, meaninertia, nv, qacc + o);
-        info.rows_active = true;
+  for (int b = 0; b < NB; b++)
+    if (b < nb) block_smooth_force(Rb[b], s.b[b].w, qacc + NJ + 6 * b);
+  }  // live
+  // decoupled case (nothing but floor contacts): every block with its corner contacts is an independent 6-dof problem,
+  // solved by a quad of lanes (quad_block_floor). Env lanes publish, all lanes solve, env lanes collect.
+  {
+    QuadLds& qx = quad_lds();
+    const int lane = threadIdx.x & 63;
+    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+    if (lane < EPW) {
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const bool need = live && !coupled && b < nb && (fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3]);
+        QuadIn& in = qx.in[lane][b];
+        in.need = need;
+        if (need) {
+          info.rows_active = true;
+          in.R[0] = Rb[b].cx.x; in.R[1] = Rb[b].cx.y; in.R[2] = Rb[b].cx.z; in.R[3] = Rb[b].cy.x; in.R[4] = Rb[b].cy.y; in.R[5] = Rb[b].cy.z;
+          in.R[6] = Rb[b].cz.x; in.R[7] = Rb[b].cz.y; in.R[8] = Rb[b].cz.z;
+          in.qv[0] = s.b[b].v.x; in.qv[1] = s.b[b].v.y; in.qv[2] = s.b[b].v.z; in.qv[3] = s.b[b].w.x; in.qv[4] = s.b[b].w.y; in.qv[5] = s.b[b].w.z;
+#pragma unroll
+          for (int k = 0; k < 6; k++) in.f[k] = qacc[NJ + 6 * b + k];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            in.on[k] = fs[b].on[k]; in.dist[k] = fs[b].dist[k];
+            in.r[k][0] = fs[b].r[k].x; in.r[k][1] = fs[b].r[k].y; in.r[k][2] = fs[b].r[k].z;
+          }
+        }
       }
     }
+    MJS_WAVE_SYNC();
+#pragma unroll 1
+    for (int b0 = 0; b0 < nb; b0 += QUAD_BLOCKS) {
+      const int c = lane & 3, e = (lane >> 2) & (EPW - 1), b = b0 + (lane >> 2) / EPW;
+      if (b < nb && qx.in[e][b].need) {  // quad-uniform
+        const QuadIn& in = qx.in[e][b];
+        M3 R;
+        R.cx = v3(in.R[0], in.R[1], in.R[2]); R.cy = v3(in.R[3], in.R[4], in.R[5]); R.cz = v3(in.R[6], in.R[7], in.R[8]);
+        double qv[6], f[6], out[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) { qv[k] = in.qv[k]; f[k] = in.f[k]; }
+        quad_block_floor(R, qv, f, in.on[c] != 0, in.dist[c], v3(in.r[c][0], in.r[c][1], in.r[c][2]), meaninertia, nv, out);
+        if (c == 0) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) qx.out[e][b][k] = out[k];
+        }
+      }
+    }
+    MJS_WAVE_SYNC();
+    if (lane < EPW) {
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+        if (qx.in[lane][b].need) {
+#pragma unroll
+          for (int k = 0; k < 6; k++) qacc[NJ + 6 * b + k] = qx.out[lane][b][k];
+        }
+    }
+    MJS_WAVE_SYNC();  // the cooperative solver reuses the area
   }
-  }  // live
   PP_ACC(info, 2, tt);
   coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb);  // all lanes
   PP_ACC(info, 3, tt);
@@ -1255,17 +1523,6 @@ __device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, 
 // constraint problems are solved cooperatively): every lane runs the same substep loop, with `live` masking lanes
 // that have nothing to do in an iteration (padding lanes of the last workgroup, lanes that step while their neighbours
 // run the 150 settle steps of a reset).
-// wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines; the 5-slot
-// instance's cooperative workspace (~113 KB) leaves room for one wavefront per CU
-constexpr int WAVES = NB <= 2 ? 4 : 1;
-// Envs per wavefront. The coupled constraint problems of a wavefront's envs are solved one after the other by the
-// whole wavefront, so the critical path of a launch is set by the wavefront with the most coupled envs; at 4096 envs
-// the chip has 16x more SIMDs than 64-env wavefronts would use, so fewer envs per wavefront (the other lanes only
-// help in the cooperative solves) shorten that path.
-#ifndef MJS_PP_ENVS_PER_WAVE
-#define MJS_PP_ENVS_PER_WAVE 4
-#endif
-constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
 template <bool IS_RESET>
 __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
   const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
@@ -1303,7 +1560,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
   if (!valid) nsub = 0;  // helper lanes only take part in the cooperative solves
   StepInfo info{false, false, false, 0};
 #ifdef MJS_STAMPS
-  for (int k = 0; k < 6; k++) info.cyc[k] = 0;
+  for (int k = 0; k < 16; k++) info.cyc[k] = 0;
 #endif
   int nmax = nsub;
 #pragma unroll
@@ -1321,7 +1578,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
   }
 #ifdef MJS_STAMPS
   if (p.stamps && threadIdx.x == 0 && !IS_RESET)
-    for (int k = 0; k < 6; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
+    for (int k = 0; k < 16; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
 #endif
   bool bad = info.bad, terminate = false;
   if (resetting) {
@@ -1373,7 +1630,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     }
     StepInfo info2{false, false, false, 0};
 #ifdef MJS_STAMPS
-    for (int k = 0; k < 6; k++) info2.cyc[k] = 0;
+    for (int k = 0; k < 16; k++) info2.cyc[k] = 0;
 #endif
 #pragma unroll 1
     for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid);

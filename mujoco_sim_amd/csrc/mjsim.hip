@@ -267,15 +267,20 @@ void mjs_destroy(mjs_handle* h) {
       for (int k = 0; k < 5; k++) e[k] += (double)(host[16 * w + 8 + k + 1] - host[16 * w + 8 + k]) / W;
     }
     if (h->cfg.task == MJS_TASK_PLANAR_PUSH) {
-      double c[6] = {0, 0, 0, 0, 0, 0}, worst[6] = {0, 0, 0, 0, 0, 0}, worst_total = 0;
+      double c[16] = {0}, worst[16] = {0}, worst_total = 0;
+      int hist[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
       const int WG = (h->cfg.num_envs + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES);
       for (int w = 0; w < WG; w++) {
         double tot = 0;
         for (int k = 0; k < 5; k++) tot += (double)host[16 * w + k];
-        for (int k = 0; k < 6; k++) c[k] += (double)host[16 * w + k] / WG;
-        if (tot > worst_total) { worst_total = tot; for (int k = 0; k < 6; k++) worst[k] = (double)host[16 * w + k]; }
+        for (int k = 0; k < 16; k++) c[k] += (double)host[16 * w + k] / WG;
+        if (tot > worst_total) { worst_total = tot; for (int k = 0; k < 16; k++) worst[k] = (double)host[16 * w + k]; }
+        const int ns = (int)host[16 * w + 6];
+        hist[ns == 0 ? 0 : ns <= 5 ? 1 : ns <= 10 ? 2 : ns <= 20 ? 3 : ns <= 30 ? 4 : ns <= 40 ? 5 : ns <= 60 ? 6 : ns <= 80 ? 7 : 8]++;
       }
       std::fprintf(stderr, "[MJS_STAMPS] planar-push, wave 0 of each workgroup, cycles per control step, MEAN: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (of which the owner lane's publish %.0f) | integrate %.0f\n", c[0], c[1], c[2], c[3], c[5], c[4]);
+      std::fprintf(stderr, "[MJS_STAMPS] cooperative solves per wavefront and control step: mean %.2f (%.2f Newton iterations each), slowest wavefront %.0f solves / %.0f iterations; wavefronts with 0 | 1-5 | 6-10 | 11-20 | 21-30 | 31-40 | 41-60 | 61-80 | >80 solves: %d %d %d %d %d %d %d %d %d\n", c[6], c[6] > 0 ? c[7] / c[6] : 0.0, worst[6], worst[7], hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7], hist[8]);
+      std::fprintf(stderr, "[MJS_STAMPS] slowest wavefront, inside its cooperative solves: rows %.0f | init (M^-1 f, J a, update) %.0f | gradient+Hessian %.0f | Cholesky+solves %.0f | M v, J v %.0f | line search %.0f | update+gradient norm %.0f | J^T f %.0f\n", worst[15], worst[8], worst[9], worst[10], worst[11], worst[12], worst[13], worst[14]);
       std::fprintf(stderr, "[MJS_STAMPS] SLOWEST workgroup: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (publish %.0f) | integrate %.0f\n", worst[0], worst[1], worst[2], worst[3], worst[5], worst[4]);
     }
     std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
