@@ -854,7 +854,7 @@ struct CoopLds {
   double J[MAXROW][LDP], D[MAXROW], aref[MAXROW], jar[MAXROW], jv[MAXROW], force[MAXROW];
   double M[NV][LDP], H[NV][LDP];
   double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
-  int active[MAXROW];
+  int arow[MAXROW], nact;  // indices of the active rows (ascending), rebuilt by every constraint update
   int nrow;
   // problem description written by the owner lane; the rows are then built by all lanes
   int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
@@ -880,15 +880,28 @@ struct QuadLds {
 };
 static_assert(sizeof(QuadLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
 MJS_DEV QuadLds& quad_lds() { return *reinterpret_cast<QuadLds*>(&coop_lds()); }
-MJS_DEV double wave_sum(double x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m);
-  return x;
-}
 // wave broadcast of a double from a compile-time lane
 MJS_DEV double bcast(double x, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
   return __hiloint2double(hi, lo);
+}
+// x + (x moved by the DPP control, 0 where the source lane does not exist or the row / bank mask disables the lane)
+template <int CTRL, int ROW_MASK>
+MJS_DEV double dpp_add(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, ROW_MASK, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, ROW_MASK, 0xF, false);
+  return x + __hiloint2double(hi, lo);
+}
+// Sum over the 64 lanes, the same bits in every lane: inclusive scan inside each row of 16 lanes (row_shr 1, 2, 4, 8),
+// row totals forwarded with row_bcast15 / row_bcast31, the total read from lane 63. Register-only: the ds_bpermute
+// butterfly (__shfl_xor) it replaces cost a round trip through the LDS crossbar per stage.
+MJS_DEV double wave_sum(double x) {
+  x = dpp_add<0x111, 0xF>(x);
+  x = dpp_add<0x112, 0xF>(x);
+  x = dpp_add<0x114, 0xF>(x);
+  x = dpp_add<0x118, 0xF>(x);
+  x = dpp_add<0x142, 0xA>(x);  // row_bcast15 into rows 1 and 3
+  x = dpp_add<0x143, 0xC>(x);  // row_bcast31 into rows 2 and 3
+  return bcast(x, 63);
 }
 // Solve H x = b (H = sh.H, lower triangle, SPD; b and x in `vec`, LDS) with the factorisation in REGISTERS: lane i owns
 // row i of H; the pivot, the column-j entries of the other rows and the right-hand side travel by v_readlane
@@ -912,7 +925,7 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
 #pragma unroll
     for (int k = j + 1; k < NV; k++) {
       const double lkj = bcast(row[j], k);
-      if (lane >= k) row[k] -= row[j] * lkj;
+      row[k] -= row[j] * lkj;  // entries above the diagonal (lane < k) are never read
     }
   }
   // rows of L to LDS, then each lane reads its column: L[k][lane], k > lane
@@ -935,11 +948,12 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
   return ok;
 }
 // cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
+constexpr int NCH = (MAXROW + 63) / 64;  // rows per lane when the rows are dealt to the 64 lanes
 MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepInfo& info) {
   const int nrow = sh.nrow;
   unsigned long long tn = 0;
   PP_TIC(tn);
-  // qacc_smooth = M^-1 qfrc_smooth: M is block diagonal (arm, block 0, block 1), one lane per 6x6 block
+  // qacc_smooth = M^-1 qfrc_smooth: M is block diagonal (arm, blocks), one lane per 6x6 block
   if (lane < nv / 6) {
     double L[6][6], x[6];
     const int o = 6 * lane;
@@ -955,29 +969,69 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
     for (int i = 0; i < 6; i++) { sh.a_s[o + i] = x[i]; sh.a[o + i] = x[i]; }
   }
   MJS_WAVE_SYNC();
-  if (lane < nv) {
+  const int col = lane < nv ? lane : 0;  // lanes >= nv shadow column 0 (uniform control flow), their results are dropped
+  auto m_times = [&](const double* x) {  // (M x)[col]; nv is a multiple of 6
     double m = 0;
-    for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.a[k];
-    sh.Ma[lane] = m;
+    for (int k = 0; k < nv; k += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) m += sh.M[col][k + u] * x[k + u];
+    }
+    return m;
+  };
+  auto j_times = [&](int r, const double* x) {  // (J x)[r]
+    double y = 0;
+    for (int k = 0; k < nv; k += 6) {
+#pragma unroll
+      for (int u = 0; u < 6; u++) y += sh.J[r][k + u] * x[k + u];
+    }
+    return y;
+  };
+  {
+    const double m = m_times(sh.a);
+    if (lane < nv) sh.Ma[lane] = m;
   }
-  for (int r = lane; r < nrow; r += 64) {
-    double x = -sh.aref[r];
-    for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.a[k];
-    sh.jar[r] = x;
+#pragma unroll
+  for (int q = 0; q < NCH; q++) {
+    const int r = lane + 64 * q;
+    if (r < nrow) sh.jar[r] = j_times(r, sh.a) - sh.aref[r];
   }
   MJS_WAVE_SYNC();
-  auto update = [&]() {  // forces / active set from jar; returns the total cost (all lanes)
+  // forces and the active set from jar: the active rows are compacted into sh.arow (ballot + prefix count) so that the
+  // sums over active rows below run over a dense list with their LDS reads in flight together. Returns the cost.
+  int nact = 0;
+  auto update = [&]() {
     double cost = 0;
-    for (int r = lane; r < nrow; r += 64) {
-      const double x = sh.jar[r];
-      const bool act = x < 0;
-      sh.active[r] = act;
-      sh.force[r] = act ? -sh.D[r] * x : 0.0;
-      if (act) cost += 0.5 * sh.D[r] * x * x;
+    int base = 0;
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int r = lane + 64 * q;
+      const bool in = r < nrow;
+      const double x = in ? sh.jar[r] : 0.0, d = in ? sh.D[r] : 0.0;
+      const bool act = in && x < 0;
+      if (in) sh.force[r] = act ? -d * x : 0.0;
+      cost += act ? 0.5 * d * x * x : 0.0;
+      const unsigned long long m = __ballot(act);
+      if (act) sh.arow[base + __popcll(m & ((1ull << lane) - 1ull))] = r;
+      base += __popcll(m);
     }
+    nact = base;
     if (lane < nv) cost += 0.5 * (sh.Ma[lane] - sh.qs[lane]) * (sh.a[lane] - sh.a_s[lane]);
     MJS_WAVE_SYNC();
     return wave_sum(cost);
+  };
+  auto jt_force = [&]() {  // (J^T force)[col] over the active rows
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    int k = 0;
+    for (; k + 4 <= nact; k += 4) {
+      const int r0 = sh.arow[k], r1 = sh.arow[k + 1], r2 = sh.arow[k + 2], r3 = sh.arow[k + 3];
+      s0 += sh.J[r0][col] * sh.force[r0]; s1 += sh.J[r1][col] * sh.force[r1];
+      s2 += sh.J[r2][col] * sh.force[r2]; s3 += sh.J[r3][col] * sh.force[r3];
+    }
+    for (; k < nact; k++) {
+      const int r = sh.arow[k];
+      s0 += sh.J[r][col] * sh.force[r];
+    }
+    return (s0 + s1) + (s2 + s3);
   };
   double cost = update();
   PP_ACC(info, 8, tn);
@@ -996,21 +1050,26 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
     hi[q] = i;
     hj[q] = (he[q] ? e : 0) - i * (i + 1) / 2;
   }
+  {  // search = -gradient
+    const double g = sh.Ma[col] - sh.qs[col] - jt_force();
+    if (lane < nv) sh.search[lane] = -g;
+  }
   int iters = 0;
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     iters++;
-    // gradient -> search = -grad ; Hessian = M + J^T diag(D active) J
-    if (lane < nv) {
-      double g = sh.Ma[lane] - sh.qs[lane];
-      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
-      sh.search[lane] = -g;
-    }
-    {
+    {  // Hessian = M + J^T diag(D active) J
       double h[NHE];
 #pragma unroll
-      for (int q = 0; q < NHE; q++) h[q] = he[q] ? sh.M[hi[q]][hj[q]] : 0.0;
-      for (int r = 0; r < nrow; r++) {
-        if (!sh.active[r]) continue;  // wave-uniform
+      for (int q = 0; q < NHE; q++) h[q] = sh.M[hi[q]][hj[q]];
+      int k = 0;
+      for (; k + 2 <= nact; k += 2) {
+        const int r0 = sh.arow[k], r1 = sh.arow[k + 1];
+        const double d0 = sh.D[r0], d1 = sh.D[r1];
+#pragma unroll
+        for (int q = 0; q < NHE; q++) h[q] += sh.J[r0][hi[q]] * d0 * sh.J[r0][hj[q]] + sh.J[r1][hi[q]] * d1 * sh.J[r1][hj[q]];
+      }
+      for (; k < nact; k++) {
+        const int r = sh.arow[k];
         const double d = sh.D[r];
 #pragma unroll
         for (int q = 0; q < NHE; q++) h[q] += sh.J[r][hi[q]] * d * sh.J[r][hj[q]];
@@ -1023,15 +1082,18 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
     PP_ACC(info, 9, tn);
     if (!coop_chol_solve(sh, nv, sh.search, lane)) break;
     PP_ACC(info, 10, tn);
-    if (lane < nv) {
-      double m = 0;
-      for (int k = 0; k < nv; k++) m += sh.M[lane][k] * sh.search[k];
-      sh.Mv[lane] = m;
+    {
+      const double m = m_times(sh.search);
+      if (lane < nv) sh.Mv[lane] = m;
     }
-    for (int r = lane; r < nrow; r += 64) {
-      double x = 0;
-      for (int k = 0; k < nv; k++) x += sh.J[r][k] * sh.search[k];
-      sh.jv[r] = x;
+    double jr[NCH], jvr[NCH], dr[NCH];  // this lane's rows, kept for the line search
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int r = lane + 64 * q;
+      const bool in = r < nrow;
+      jvr[q] = in ? j_times(r, sh.search) : 0.0;
+      jr[q] = in ? sh.jar[r] : 1.0;  // rows beyond nrow: never active
+      dr[q] = in ? sh.D[r] : 0.0;
     }
     MJS_WAVE_SYNC();
     PP_ACC(info, 11, tn);
@@ -1040,44 +1102,47 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
     g1 = wave_sum(g1); g2 = wave_sum(g2); sn2 = wave_sum(sn2);
     if (sqrt(sn2) < MJS_MINVAL) break;
     const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(sn2) / scale;
-    double alpha = 0, lo = 0, hi = INFINITY;
+    double alpha = 0, lo = 0, hi_ = INFINITY;
     for (int it = 0; it < 50; it++) {  // exact 1-D Newton; every lane follows the same alpha sequence
       double p1 = 0, p2 = 0;
-      for (int r = lane; r < nrow; r += 64) {
-        const double x = sh.jar[r] + alpha * sh.jv[r];
-        if (x < 0) { p1 += sh.D[r] * x * sh.jv[r]; p2 += sh.D[r] * sh.jv[r] * sh.jv[r]; }
+#pragma unroll
+      for (int q = 0; q < NCH; q++) {
+        const double x = jr[q] + alpha * jvr[q];
+        const bool o = x < 0;
+        p1 += o ? dr[q] * x * jvr[q] : 0.0;
+        p2 += o ? dr[q] * jvr[q] * jvr[q] : 0.0;
       }
       const double d1 = g1 + alpha * g2 + wave_sum(p1), d2 = g2 + wave_sum(p2);
       if (fabs(d1) < gtol) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d1 < 0) lo = alpha; else hi_ = alpha;
       if (d2 <= 0) break;
       double next = alpha + (-d1 / d2);
-      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (!(next > lo && next < hi_)) next = isfinite(hi_) ? 0.5 * (lo + hi_) : (alpha > 0 ? 2 * alpha : 1.0);
       if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
       alpha = next;
     }
     PP_ACC(info, 12, tn);
     if (alpha == 0) break;
     if (lane < nv) { sh.a[lane] += alpha * sh.search[lane]; sh.Ma[lane] += alpha * sh.Mv[lane]; }
-    for (int r = lane; r < nrow; r += 64) sh.jar[r] += alpha * sh.jv[r];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int r = lane + 64 * q;
+      if (r < nrow) sh.jar[r] = jr[q] + alpha * jvr[q];
+    }
     MJS_WAVE_SYNC();
     const double oldcost = cost;
     cost = update();
-    double gn = 0;
-    if (lane < nv) {
-      double g = sh.Ma[lane] - sh.qs[lane];
-      for (int r = 0; r < nrow; r++) g -= sh.J[r][lane] * sh.force[r];
-      gn = g * g;
-    }
-    gn = wave_sum(gn);
+    // gradient at the new point: its norm for the stopping rule, its negative as the next right-hand side
+    const double g = sh.Ma[col] - sh.qs[col] - jt_force();
+    const double gn = wave_sum(lane < nv ? g * g : 0.0);
+    if (lane < nv) sh.search[lane] = -g;
     PP_ACC(info, 13, tn);
     if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
   }
   MJS_WAVE_SYNC();
-  if (lane < nv) {
-    double f = 0;
-    for (int r = 0; r < nrow; r++) f += sh.J[r][lane] * sh.force[r];
-    sh.fc[lane] = f;
+  {
+    const double f = jt_force();
+    if (lane < nv) sh.fc[lane] = f;
   }
   MJS_WAVE_SYNC();
   PP_ACC(info, 14, tn);
@@ -1213,16 +1278,46 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
     }
     const int kk = e >> 1;  // 0: t1, 1: t2, 2: torsion
     const double sgn = (e & 1) ? -1.0 : 1.0;
-    const bool blocks_only = sh.c_ba[c] >= 2 && sh.c_bb[c] >= 2;
+    const int ba = sh.c_ba[c], bb = sh.c_bb[c];
+    const bool blocks_only = ba >= 2 && bb >= 2;
     const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
-    double Jn[NV], Jk[NV];
-    coop_frame_row(sh, c, n, false, nv, Jn);
-    coop_frame_row(sh, c, kk == 0 ? t1 : kk == 1 ? t2 : n, kk == 2, nv, Jk);
+    // row = Jn + sgn mu Jk with Jn / Jk the normal and the kk-th frame row of (body b - body a), written column by
+    // column straight into LDS (static column indices: nothing lives in indexed scratch). Only body a can be the arm.
+    const V3 pos = v3(sh.c_pos[c][0], sh.c_pos[c][1], sh.c_pos[c][2]);
+    const V3 Fk = kk == 0 ? t1 : kk == 1 ? t2 : n;
+    const bool rotk = kk == 2;
+    const double mu = sgn * fri[kk];
     double vel = 0;
-    for (int d = 0; d < nv; d++) {
-      const double j = Jn[d] + sgn * fri[kk] * Jk[d];
-      sh.J[row][d] = j;
-      vel += j * sh.qvel[d];
+    const double sa = ba == 1 ? -1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
+      const V3 lin = cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
+      const double v = sa * dot(n, lin) + mu * (sa * dot(Fk, rotk ? ax : lin));
+      sh.J[row][j] = v;
+      vel += v * sh.qvel[j];
+    }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      if (b >= nb) continue;
+      const int o = NJ + 6 * b;
+      const double sb = (bb == 2 + b ? 1.0 : 0.0) - (ba == 2 + b ? 1.0 : 0.0);
+      const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
+      const double nd[3] = {n.x, n.y, n.z}, fd[3] = {Fk.x, Fk.y, Fk.z};
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const double v = sb * nd[d] + mu * (rotk ? 0.0 : sb * fd[d]);
+        sh.J[row][o + d] = v;
+        vel += v * sh.qvel[o + d];
+      }
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const V3 axs = v3(sh.bR[b][3 * d], sh.bR[b][3 * d + 1], sh.bR[b][3 * d + 2]);
+        const V3 lin = cross(axs, rvec);
+        const double v = sb * dot(n, lin) + mu * (sb * dot(Fk, rotk ? axs : lin));
+        sh.J[row][o + 3 + d] = v;
+        vel += v * sh.qvel[o + 3 + d];
+      }
     }
     const double imp = impedance_default(sh.c_dist[c]);
     const double R0 = fmax(MJS_MINVAL, (1 - imp) * (sh.c_tran[c] + fri[0] * fri[0] * sh.c_tran[c]) / imp);
