@@ -851,7 +851,8 @@ constexpr int LDP = NV + 1;  // padded leading dimension in LDS
   } while (0)
 #endif
 struct CoopLds {
-  double J[MAXROW][LDP], D[MAXROW], aref[MAXROW], jar[MAXROW], jv[MAXROW], force[MAXROW];
+  // row MAXROW is the null row (J = 0, D = 0, force = 0): padding of the active-row list
+  double J[MAXROW + 1][LDP], D[MAXROW + 1], aref[MAXROW], jar[MAXROW], force[MAXROW + 1];
   double M[NV][LDP], H[NV][LDP];
   double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
   int arow[MAXROW], nact;  // indices of the active rows (ascending), rebuilt by every constraint update
@@ -998,7 +999,9 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
   MJS_WAVE_SYNC();
   // forces and the active set from jar: the active rows are compacted into sh.arow (ballot + prefix count) so that the
   // sums over active rows below run over a dense list with their LDS reads in flight together. Returns the cost.
-  int nact = 0;
+  // The list then lives in registers (entry k in lane k & 63 of myrow[k >> 6], padded with the null row): a sum over
+  // active rows fetches its row indices with v_readlane instead of a dependent LDS read.
+  int nact = 0, myrow[NCH];
   auto update = [&]() {
     double cost = 0;
     int base = 0;
@@ -1017,19 +1020,21 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
     nact = base;
     if (lane < nv) cost += 0.5 * (sh.Ma[lane] - sh.qs[lane]) * (sh.a[lane] - sh.a_s[lane]);
     MJS_WAVE_SYNC();
+#pragma unroll
+    for (int q = 0; q < NCH; q++) myrow[q] = lane + 64 * q < nact ? sh.arow[lane + 64 * q] : MAXROW;
     return wave_sum(cost);
   };
   auto jt_force = [&]() {  // (J^T force)[col] over the active rows
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    int k = 0;
-    for (; k + 4 <= nact; k += 4) {
-      const int r0 = sh.arow[k], r1 = sh.arow[k + 1], r2 = sh.arow[k + 2], r3 = sh.arow[k + 3];
-      s0 += sh.J[r0][col] * sh.force[r0]; s1 += sh.J[r1][col] * sh.force[r1];
-      s2 += sh.J[r2][col] * sh.force[r2]; s3 += sh.J[r3][col] * sh.force[r3];
-    }
-    for (; k < nact; k++) {
-      const int r = sh.arow[k];
-      s0 += sh.J[r][col] * sh.force[r];
+#pragma unroll
+    for (int q = 0; q < NCH; q++) {
+      const int nq = min(nact - 64 * q, 64);
+      for (int k = 0; k < nq; k += 4) {  // lanes past the list hold the null row
+        const int r0 = __builtin_amdgcn_readlane(myrow[q], k), r1 = __builtin_amdgcn_readlane(myrow[q], (k + 1) & 63);
+        const int r2 = __builtin_amdgcn_readlane(myrow[q], (k + 2) & 63), r3 = __builtin_amdgcn_readlane(myrow[q], (k + 3) & 63);
+        s0 += sh.J[r0][col] * sh.force[r0]; s1 += sh.J[r1][col] * sh.force[r1];
+        s2 += sh.J[r2][col] * sh.force[r2]; s3 += sh.J[r3][col] * sh.force[r3];
+      }
     }
     return (s0 + s1) + (s2 + s3);
   };
@@ -1061,18 +1066,21 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
       double h[NHE];
 #pragma unroll
       for (int q = 0; q < NHE; q++) h[q] = sh.M[hi[q]][hj[q]];
-      int k = 0;
-      for (; k + 2 <= nact; k += 2) {
-        const int r0 = sh.arow[k], r1 = sh.arow[k + 1];
-        const double d0 = sh.D[r0], d1 = sh.D[r1];
+      constexpr int HU = 2;  // rows per trip (4 measured slower: register pressure)
 #pragma unroll
-        for (int q = 0; q < NHE; q++) h[q] += sh.J[r0][hi[q]] * d0 * sh.J[r0][hj[q]] + sh.J[r1][hi[q]] * d1 * sh.J[r1][hj[q]];
-      }
-      for (; k < nact; k++) {
-        const int r = sh.arow[k];
-        const double d = sh.D[r];
+      for (int c = 0; c < NCH; c++) {
+        const int nq = min(nact - 64 * c, 64);
+        for (int k = 0; k < nq; k += HU) {  // lanes past the list hold the null row
+          int r[HU];
+          double d[HU];
 #pragma unroll
-        for (int q = 0; q < NHE; q++) h[q] += sh.J[r][hi[q]] * d * sh.J[r][hj[q]];
+          for (int u = 0; u < HU; u++) { r[u] = __builtin_amdgcn_readlane(myrow[c], (k + u) & 63); d[u] = sh.D[r[u]]; }
+#pragma unroll
+          for (int q = 0; q < NHE; q++) {
+#pragma unroll
+            for (int u = 0; u < HU; u++) h[q] += sh.J[r[u]][hi[q]] * d[u] * sh.J[r[u]][hj[q]];
+          }
+        }
       }
 #pragma unroll
       for (int q = 0; q < NHE; q++)
@@ -1324,7 +1332,8 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
     sh.D[row] = 1 / (2 * fri[0] * fri[0] * R0);
     sh.aref[row] = -B * vel - K * imp * sh.c_dist[c];
   }
-  if (lane == 0) sh.nrow = nlim + 6 * nact;
+  if (lane == 0) { sh.nrow = nlim + 6 * nact; sh.D[MAXROW] = 0; sh.force[MAXROW] = 0; }
+  if (lane < NV) sh.J[MAXROW][lane] = 0;
 }
 MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
                           const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
@@ -1335,7 +1344,7 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
   while (todo) {  // wave-uniform loop over the lanes whose env needs the coupled solve
     const int owner = __ffsll((long long)todo) - 1;
     todo &= todo - 1;
-    for (int e = lane; e < nv * nv; e += 64) sh.M[e / nv][e % nv] = 0;  // all lanes: clear M, the owner fills its diagonal blocks
+    for (int e = lane; e < NV * LDP; e += 64) (&sh.M[0][0])[e] = 0;  // all lanes: clear M, the owner fills its diagonal blocks
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
