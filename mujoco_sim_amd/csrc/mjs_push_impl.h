@@ -857,6 +857,9 @@ struct CoopLds {
   double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
   int arow[MAXROW], nact;  // indices of the active rows (ascending), rebuilt by every constraint update
   int nrow;
+  // the sub-system being solved: the bodies with an active arm-block / block-block contact or joint-limit row; its
+  // dofs are packed (arm first when present). off[0] = arm offset (0) or -1, off[1 + b] = offset of block b or -1.
+  int nv, off[NB + 1];
   // problem description written by the owner lane; the rows are then built by all lanes
   int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
   double c_dist[MAXCON], c_tran[MAXCON], c_pos[MAXCON][3], c_n[MAXCON][3];
@@ -909,7 +912,10 @@ MJS_DEV double wave_sum(double x) {
 // broadcasts (all lane indices are compile-time constants of the unrolled loops), so the 153 trailing updates and
 // the forward substitution touch no memory. The rows of L then go to LDS once and every lane fetches its column of
 // L for the backward substitution. Rows >= nv are identity padding (one block instead of two).
-MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
+template <int NVT>
+MJS_DEV bool coop_chol_solve_n(CoopLds& sh, double* vec, int lane) {
+  constexpr int NV = NVT;  // the unrolled loops below run over the sub-system's size
+  const int nv = NVT;
   double row[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) row[j] = (lane < nv && j <= lane) ? sh.H[lane < NV ? lane : 0][j] : (j == lane ? 1.0 : 0.0);
@@ -948,9 +954,20 @@ MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) {
   MJS_WAVE_SYNC();
   return ok;
 }
+template <int NVT>
+MJS_DEV bool coop_chol_dispatch(CoopLds& sh, int nv, double* vec, int lane) {  // nv is a multiple of 6, wave-uniform
+  if (nv == NVT) return coop_chol_solve_n<NVT>(sh, vec, lane);
+  if constexpr (NVT > 6) return coop_chol_dispatch<NVT - 6>(sh, nv, vec, lane);
+  return false;
+}
+MJS_DEV bool coop_chol_solve(CoopLds& sh, int nv, double* vec, int lane) { return coop_chol_dispatch<NV>(sh, nv, vec, lane); }
 // cooperative mj_solPrimal on the problem published in sh; result sh.fc = J^T force
 constexpr int NCH = (MAXROW + 63) / 64;  // rows per lane when the rows are dealt to the 64 lanes
-MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepInfo& info) {
+// Out of line ON PURPOSE: inlined into the substep its loops inherit the caller's register pressure (the env lane's world
+// state, contact slots and mass matrices are live across the call) and reload spilled values from scratch inside the
+// row loops; as a function it is allocated on its own. The workspace is reached through coop_lds() (address space 3).
+__device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo& info) {
+  CoopLds& sh = coop_lds();
   const int nrow = sh.nrow;
   unsigned long long tn = 0;
   PP_TIC(tn);
@@ -1040,7 +1057,6 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
   };
   double cost = update();
   PP_ACC(info, 8, tn);
-  const double scale = 1 / (meaninertia * nv);
   // this lane's (up to NHE) entries of the lower triangle of the Hessian
   constexpr int NHE = (NV * (NV + 1) / 2 + 63) / 64;
   int hi[NHE], hj[NHE];
@@ -1158,10 +1174,18 @@ MJS_DEV int coop_newton(CoopLds& sh, int nv, double meaninertia, int lane, StepI
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
 MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
-                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
+                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in) {
   CoopLds& sh = coop_lds();
-  rr::Chain ch;
-  rr::fk_cs(cs, sn, ch);
+  int off[NB + 1], nvs = arm_in ? NJ : 0;
+  off[0] = arm_in ? 0 : -1;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    off[1 + b] = (b < nb && blk_in[b]) ? nvs : -1;
+    if (b < nb && blk_in[b]) nvs += 6;
+  }
+#pragma unroll
+  for (int k = 0; k <= NB; k++) sh.off[k] = off[k];
+  sh.nv = nvs;
   // contact list in MuJoCo's pair order from the hot path's static slots (no second collision pass)
   int ncon = 0;
   auto put = [&](double dist, V3 pos, V3 n, int ba, int bb, double tran) {
@@ -1173,7 +1197,7 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
   };
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    if (b >= nb) continue;
+    if (b >= nb || !blk_in[b]) continue;
     const FloorSlots& f = fs[b];
 #pragma unroll
     for (int k = 0; k < 4; k++)  // only ACTIVE corners make rows (a corner exactly on the floor is detected but inactive)
@@ -1181,19 +1205,23 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
   }
 #pragma unroll
   for (int b = 0; b < NB; b++)
-    if (b < nb && cvx.hit[b]) put(cvx.dist[b], cvx.pos[b], cvx.n[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+    if (b < nb && blk_in[b] && cvx.hit[b]) put(cvx.dist[b], cvx.pos[b], cvx.n[b], 1, 2 + b, UR5E_PP_WRIST3_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
 #pragma unroll
   for (int b = 0; b < NB; b++)
-    if (b < nb && cvx.hit[NB + b]) put(cvx.dist[NB + b], cvx.pos[NB + b], cvx.n[NB + b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
+    if (b < nb && blk_in[b] && cvx.hit[NB + b]) put(cvx.dist[NB + b], cvx.pos[NB + b], cvx.n[NB + b], 1, 2 + b, UR5E_PP_EEF_BODY_INVWEIGHT0[0] + 1.0 / MJS_BLOCK_MASS);
 #pragma unroll
   for (int a = 0; a < NB; a++) {
 #pragma unroll
     for (int b = a + 1; b < NB; b++) {
       const int k = pair_slot(a, b);
-      if (b < nb && cvx.hit[k]) put(cvx.dist[k], cvx.pos[k], cvx.n[k], 2 + a, 2 + b, 2.0 / MJS_BLOCK_MASS);
+      if (b < nb && blk_in[a] && blk_in[b] && cvx.hit[k]) put(cvx.dist[k], cvx.pos[k], cvx.n[k], 2 + a, 2 + b, 2.0 / MJS_BLOCK_MASS);
     }
   }
   sh.ncon = ncon;
+  for (int k = 0; k < 2 * NJ; k++) sh.lim_act[k] = 0;
+  if (arm_in) {
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
   for (int j = 0; j < NJ; j++) {
     const V3 a = rr::joint_axis(ch, j), p = ch.p[j + 1];
     sh.ax[j][0] = a.x; sh.ax[j][1] = a.y; sh.ax[j][2] = a.z;
@@ -1206,10 +1234,11 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
     for (int k = 0; k <= j; k++) sh.M[j][k] = sh.M[k][j] = Marm[j * (j + 1) / 2 + k];
     sh.M[j][j] += MJS_UR_ARMATURE;
   }
+  }
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    if (b >= nb) continue;
-    const int o = NJ + 6 * b;
+    if (off[1 + b] < 0) continue;
+    const int o = off[1 + b];
     double Mb[6][6], f[6];
     block_mass_matrix6(Rb[b], Mb);
     block_smooth_force(Rb[b], s.b[b].w, f);
@@ -1250,8 +1279,9 @@ MJS_DEV void coop_frame_row(const CoopLds& sh, int c, V3 F, bool rotational, int
   }
 }
 // all lanes: limit rows + pyramid rows (6 per active contact, condim 4) in the oracle's order
-MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
-  const int nv = NJ + 6 * nb;
+MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
+  const int nv = sh.nv;
+  const bool arm_in = sh.off[0] >= 0;
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
   const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
   const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
@@ -1297,6 +1327,7 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
     const double mu = sgn * fri[kk];
     double vel = 0;
     const double sa = ba == 1 ? -1.0 : 0.0;
+    if (arm_in) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
       const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
@@ -1305,10 +1336,11 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
       sh.J[row][j] = v;
       vel += v * sh.qvel[j];
     }
+    }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
-      if (b >= nb) continue;
-      const int o = NJ + 6 * b;
+      const int o = sh.off[1 + b];
+      if (o < 0) continue;
       const double sb = (bb == 2 + b ? 1.0 : 0.0) - (ba == 2 + b ? 1.0 : 0.0);
       const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
       const double nd[3] = {n.x, n.y, n.z}, fd[3] = {Fk.x, Fk.y, Fk.z};
@@ -1336,10 +1368,12 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int nb, int lane) {
   if (lane < NV) sh.J[MAXROW][lane] = 0;
 }
 MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
-                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb) {
+                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in) {
   CoopLds& sh = coop_lds();
-  const int lane = threadIdx.x & 63, nv = NJ + 6 * nb;
-  const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
+  const int lane = threadIdx.x & 63, nv_all = NJ + 6 * nb;
+  // mj_solPrimal's stopping rules are scaled by the WHOLE model (meaninertia, nv), also when a sub-system is solved
+  const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv_all;
+  const double scale = 1 / (meaninertia * nv_all);
   unsigned long long todo = __ballot(need);
   while (todo) {  // wave-uniform loop over the lanes whose env needs the coupled solve
     const int owner = __ffsll((long long)todo) - 1;
@@ -1348,21 +1382,31 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
-    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb);
+    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in);
     MJS_WAVE_SYNC();
     PP_ACC(info, 5, tp);
     PP_TIC(tp);
-    coop_build_rows(sh, nb, lane);
+    coop_build_rows(sh, lane);
     MJS_WAVE_SYNC();
     PP_ACC(info, 15, tp);
-    const int iters = sh.nrow > 0 ? coop_newton(sh, nv, meaninertia, lane, info) : 0;
+    const int iters = sh.nrow > 0 ? coop_newton(sh.nv, scale, lane, info) : 0;
 #ifdef MJS_STAMPS
     info.cyc[6] += 1; info.cyc[7] += iters;
 #else
     (void)iters;
 #endif
-    if (lane == owner) {
-      for (int i = 0; i < nv; i++) qacc[i] = sh.qs[i] + (sh.nrow > 0 ? sh.fc[i] : 0.0);
+    if (lane == owner && sh.nrow > 0) {
+      if (arm_in) {
+#pragma unroll
+        for (int i = 0; i < NJ; i++) qacc[i] = sh.qs[i] + sh.fc[i];
+      }
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const int o = sh.off[1 + b];
+        if (o < 0) continue;
+#pragma unroll
+        for (int k = 0; k < 6; k++) qacc[NJ + 6 * b + k] = sh.qs[o + k] + sh.fc[o + k];
+      }
     }
     MJS_WAVE_SYNC();
   }
@@ -1376,7 +1420,9 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   const int nv = NJ + 6 * nb;
   double Marm[21], qacc[NV];
   int clamped = 0;
-  bool coupled = false;
+  bool coupled = false, arm_in = false, blk_in[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) blk_in[b] = false;
   ConvexHits cvx;
   FloorSlots fs[NB];
   M3 Rb[NB];
@@ -1415,8 +1461,24 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
       for (int b = a + 1; b < NB; b++)
         if (b < nb) convex_slot(bg[a], bg[b], cvx, pair_slot(a, b));
     }
+    // the coupled sub-system: the bodies joined by an ACTIVE arm-block / block-block contact; every other block only
+    // touches the floor and stays an independent 6-dof problem
 #pragma unroll
-    for (int k = 0; k < NCVX; k++) coupled = coupled || (cvx.hit[k] && cvx.dist[k] < 0.0);
+    for (int b = 0; b < NB; b++) {
+      const bool act = (cvx.hit[b] && cvx.dist[b] < 0.0) || (cvx.hit[NB + b] && cvx.dist[NB + b] < 0.0);
+      arm_in = arm_in || act;
+      blk_in[b] = blk_in[b] || act;
+    }
+#pragma unroll
+    for (int a = 0; a < NB; a++) {
+#pragma unroll
+      for (int b = a + 1; b < NB; b++) {
+        const int k = pair_slot(a, b);
+        const bool act = cvx.hit[k] && cvx.dist[k] < 0.0;
+        blk_in[a] = blk_in[a] || act;
+        blk_in[b] = blk_in[b] || act;
+      }
+    }
   }
   PP_ACC(info, 0, tt);
   // arm smooth dynamics
@@ -1429,7 +1491,10 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   PP_ACC(info, 1, tt);
   // which constraint problem?
 #pragma unroll
-  for (int j = 0; j < NJ; j++) coupled = coupled || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
+  for (int j = 0; j < NJ; j++) arm_in = arm_in || s.q[j] < MJS_UR_JNT_RANGE[j][0] || s.q[j] > MJS_UR_JNT_RANGE[j][1];
+  coupled = arm_in;
+#pragma unroll
+  for (int b = 0; b < NB; b++) coupled = coupled || blk_in[b];
   if (coupled) info.rows_active = true;
 #pragma unroll
   for (int b = 0; b < NB; b++)
@@ -1444,7 +1509,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (lane < EPW) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
-        const bool need = live && !coupled && b < nb && (fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3]);
+        const bool need = live && !blk_in[b] && b < nb && (fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3]);
         QuadIn& in = qx.in[lane][b];
         in.need = need;
         if (need) {
@@ -1492,7 +1557,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     MJS_WAVE_SYNC();  // the cooperative solver reuses the area
   }
   PP_ACC(info, 2, tt);
-  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb);  // all lanes
+  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb, arm_in, blk_in);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
