@@ -418,205 +418,12 @@ MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
   }
 }
 
-// Decoupled case (the common one): no active arm-block or block-block contact and no joint limit. The constraint
-// problem is then separable: each block with its floor contacts is an independent 6-dof problem with at most 4
-// corner contacts x 6 pyramid edges. Static slots, everything unrolled (no indexed memory). The floor frame is
-// constant (n = +z, t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)), so a row is (F, (axis_d x r) . F) for the three
-// frame vectors F and (0, axis_d . n) for the torsional row. `Mb`: the block's 6x6 mass matrix (lower triangle used),
-// `f`: qfrc_smooth of the block in, qfrc_smooth + qfrc_constraint out.
-MJS_DEV void solve_block_floor(const double (*Mb)[6], const M3 R, const FloorSlots fs, const double* qvel, double meaninertia, int nv_total,
-                                               double* f) {
-  const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};  // max(block, floor) per component
-  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
-  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
-  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
-  // contact-frame Jacobians: rows normal, t1, t2, torsion over the block's 6 dofs
-  double Jc[4][4][6], D[4], aref[4][6];
-  const V3 axs[3] = {R.cx, R.cy, R.cz};
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      const V3 lin = cross(axs[d], fs.r[c]);
-      Jc[c][0][d] = d == 2 ? 1.0 : 0.0; Jc[c][0][3 + d] = lin.z;    // n  = (0, 0, 1)
-      Jc[c][1][d] = d == 1 ? 1.0 : 0.0; Jc[c][1][3 + d] = lin.y;    // t1 = (0, 1, 0)
-      Jc[c][2][d] = d == 0 ? -1.0 : 0.0; Jc[c][2][3 + d] = -lin.x;  // t2 = (-1, 0, 0)
-      Jc[c][3][d] = 0.0; Jc[c][3][3 + d] = axs[d].z;                // torsion: rotation about n
-    }
-    const double imp = impedance_default(fs.dist[c]);
-    const double tran = 1.0 / MJS_BLOCK_MASS;
-    D[c] = 1 / (2 * mu[0] * mu[0] * fmax(MJS_MINVAL, (1 - imp) * (tran + mu[0] * mu[0] * tran) / imp));
-    double vel[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int rw = 0; rw < 4; rw++) {
-#pragma unroll
-      for (int d = 0; d < 6; d++) vel[rw] += Jc[c][rw][d] * qvel[d];
-    }
-#pragma unroll
-    for (int e = 0; e < 6; e++) aref[c][e] = -B * (vel[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * vel[1 + (e >> 1)]) - K * imp * fs.dist[c];
-  }
-  auto edge_values = [&](const double* x, int c, double* out6) {
-    double u[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int rw = 0; rw < 4; rw++) {
-#pragma unroll
-      for (int d = 0; d < 6; d++) u[rw] += Jc[c][rw][d] * x[d];
-    }
-#pragma unroll
-    for (int e = 0; e < 6; e++) out6[e] = u[0] + ((e & 1) ? -mu[e >> 1] : mu[e >> 1]) * u[1 + (e >> 1)];
-  };
-  double L[6][6], a[6], a_s[6], Ma[6], jar[4][6], force[4][6];
-  bool act[4][6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) L[i][j] = Mb[i][j];
-    a_s[i] = f[i];
-  }
-  rr::chol6(L);
-  rr::chol6_solve(L, a_s);
-#pragma unroll
-  for (int i = 0; i < 6; i++) a[i] = a_s[i];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-    double m = 0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * a[k];
-    Ma[i] = m;
-  }
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    double ja[6];
-    edge_values(a, c, ja);
-#pragma unroll
-    for (int e = 0; e < 6; e++) jar[c][e] = ja[e] - aref[c][e];
-  }
-  auto update = [&]() {
-    double cost = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-#pragma unroll
-      for (int e = 0; e < 6; e++) {
-        const bool on = fs.on[c] && jar[c][e] < 0;
-        act[c][e] = on;
-        force[c][e] = on ? -D[c] * jar[c][e] : 0.0;
-        if (on) cost += 0.5 * D[c] * jar[c][e] * jar[c][e];
-      }
-    }
-    double gauss = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) gauss += (Ma[i] - f[i]) * (a[i] - a_s[i]);
-    return cost + 0.5 * gauss;
-  };
-  auto constraint_force = [&](double* fc) {
-#pragma unroll
-    for (int i = 0; i < 6; i++) fc[i] = 0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const double fn = force[c][0] + force[c][1] + force[c][2] + force[c][3] + force[c][4] + force[c][5];
-      const double f1 = mu[0] * (force[c][0] - force[c][1]), f2 = mu[1] * (force[c][2] - force[c][3]), f3 = mu[2] * (force[c][4] - force[c][5]);
-#pragma unroll
-      for (int i = 0; i < 6; i++) fc[i] += fn * Jc[c][0][i] + f1 * Jc[c][1][i] + f2 * Jc[c][2][i] + f3 * Jc[c][3][i];
-    }
-  };
-  double cost = update();
-  const double scale = 1 / (meaninertia * nv_total);
-#pragma unroll 1
-  for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
-    double grad[6], search[6], Mv[6], H[6][6], fc[6];
-    constraint_force(fc);
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      grad[i] = Ma[i] - f[i] - fc[i];
-      search[i] = -grad[i];
-#pragma unroll
-      for (int j = 0; j <= i; j++) H[i][j] = Mb[i][j];
-    }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      // sum over active edges of D (Jn + s mu_k Jk)(Jn + s mu_k Jk)^T, k = t1, t2, torsion
-      double wn = 0, w[3], ww[3];
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        const double np_ = act[c][2 * k], nm = act[c][2 * k + 1];
-        wn += np_ + nm;
-        w[k] = D[c] * mu[k] * (np_ - nm);
-        ww[k] = D[c] * mu[k] * mu[k] * (np_ + nm);
-      }
-      wn *= D[c];
-      if (wn != 0.0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) {
-          const double jn = Jc[c][0][i];
-          const double rn = wn * jn + w[0] * Jc[c][1][i] + w[1] * Jc[c][2][i] + w[2] * Jc[c][3][i];
-          const double r1 = w[0] * jn + ww[0] * Jc[c][1][i], r2 = w[1] * jn + ww[1] * Jc[c][2][i], r3 = w[2] * jn + ww[2] * Jc[c][3][i];
-#pragma unroll
-          for (int j = 0; j <= i; j++) H[i][j] += rn * Jc[c][0][j] + r1 * Jc[c][1][j] + r2 * Jc[c][2][j] + r3 * Jc[c][3][j];
-        }
-      }
-    }
-    if (!rr::chol6(H)) break;
-    rr::chol6_solve(H, search);
-    double g1 = 0, g2 = 0, snorm = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      double m = 0;
-#pragma unroll
-      for (int k = 0; k < 6; k++) m += (i >= k ? Mb[i][k] : Mb[k][i]) * search[k];
-      Mv[i] = m;
-    }
-#pragma unroll
-    for (int i = 0; i < 6; i++) { g1 += search[i] * (Ma[i] - f[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
-    if (sqrt(snorm) < MJS_MINVAL) break;
-    double jv[4][6];
-#pragma unroll
-    for (int c = 0; c < 4; c++) edge_values(search, c, jv[c]);
-    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
-    double alpha = 0, lo = 0, hi = INFINITY;
-#pragma unroll 1
-    for (int it = 0; it < 50; it++) {
-      double d1 = g1 + alpha * g2, d2 = g2;
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-#pragma unroll
-        for (int e = 0; e < 6; e++) {
-          const double x = jar[c][e] + alpha * jv[c][e];
-          if (fs.on[c] && x < 0) { d1 += D[c] * x * jv[c][e]; d2 += D[c] * jv[c][e] * jv[c][e]; }
-        }
-      }
-      if (fabs(d1) < gtol) break;
-      if (d1 < 0) lo = alpha; else hi = alpha;
-      if (d2 <= 0) break;
-      double next = alpha + (-d1 / d2);
-      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
-      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
-      alpha = next;
-    }
-    if (alpha == 0) break;
-#pragma unroll
-    for (int i = 0; i < 6; i++) { a[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-#pragma unroll
-      for (int e = 0; e < 6; e++) jar[c][e] += alpha * jv[c][e];
-    }
-    const double oldcost = cost;
-    cost = update();
-    constraint_force(fc);
-    double gn = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-      const double g = Ma[i] - f[i] - fc[i];
-      gn += g * g;
-    }
-    if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
-  }
-  double fc[6];
-  constraint_force(fc);
-#pragma unroll
-  for (int i = 0; i < 6; i++) f[i] += fc[i];
-}
-
+// Decoupled case (the common one): a block without an active arm-block or block-block contact. With its floor contacts
+// it is an independent 6-dof problem with at most 4 corner contacts x 6 pyramid edges whose frame is constant (n = +z,
+// t1 = +y, t2 = -x: mju_makeFrame of (0, 0, 1)): a row is (F, (axis_d x r) . F) for the three frame vectors F and
+// (0, axis_d . n) for the torsional row. Solved by quad_block_floor below. Cold start at qacc_smooth: a warm start from
+// the previous substep's accelerations (mjData.qacc_warmstart; tried per component) needed MORE Newton iterations
+// (2.4 -> 3.8 per coupled solve) and moved hand-set scenarios by the solver tolerance (5e-10) instead of 1e-16.
 MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangle + the coupling block both ways
   const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
 #pragma unroll
@@ -1083,6 +890,7 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
 #pragma unroll
       for (int q = 0; q < NHE; q++) h[q] = sh.M[hi[q]][hj[q]];
       constexpr int HU = 2;  // rows per trip (4 measured slower: register pressure)
+      const int nent = nv * (nv + 1) / 2;
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const int nq = min(nact - 64 * c, 64);
@@ -1093,6 +901,7 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
           for (int u = 0; u < HU; u++) { r[u] = __builtin_amdgcn_readlane(myrow[c], (k + u) & 63); d[u] = sh.D[r[u]]; }
 #pragma unroll
           for (int q = 0; q < NHE; q++) {
+            if (64 * q >= nent) continue;  // wave-uniform: a sub-system of 12 dofs has 78 entries, 2 per lane
 #pragma unroll
             for (int u = 0; u < HU; u++) h[q] += sh.J[r[u]][hi[q]] * d[u] * sh.J[r[u]][hj[q]];
           }
