@@ -602,4 +602,134 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
   o[2] = to_u8(c.z);
 }
 
+
+// ---- primitive-major variant: one workgroup per band of rows of an env image --------------------------------------
+// The tile walk above makes every 8x8 tile test every primitive whose bound touches the tile's ray cone; at 64x64 a
+// tile is ~30 cm wide at the arm's distance, so most exact tests are for rays that miss. Here the loop is turned
+// inside out: each wavefront takes primitives, projects the primitive's bound to a pixel rectangle (exact tangent
+// extents of the end spheres, padded) and runs the exact test only on 8x8 blocks of that rectangle; the nearest hit
+// per pixel is an LDS ds_min_u64 on the key (float bits of t, primitive index) = "smallest t, first primitive
+// wins", which is what the sequential strict-< update of the tile walk / the oracle computes. A second pass shades:
+// floor hit, key lookup, the winner's exact test once more for its normal, Blinn-Phong, store. Same arithmetic per
+// ray and per test as the tile kernel: the image is identical.
+constexpr int RASTER_IMAGE_PIXELS = 64 * 64;  // 32 KB of depth keys: the launch uses one band = the whole image (see mjs_render in mjsim.hip)
+inline size_t raster_lds_bytes_host(int rows, int W) { return (size_t)rows * W * 8 + MAX_NPRIM * PRIM_FLOATS * 4 + MAX_NPRIM * 4 * 4; }
+extern __shared__ unsigned long long raster_lds[];
+MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
+  const int type = (int)pr[0];
+  const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+  const F3 rgb = f3(pr[14], pr[15], pr[16]);
+  if (type == PRIM_SPHERE) hit_sphere(eye, d, p0, pr[13], rgb, s);
+  else if (type == PRIM_CAPSULE) hit_capsule(eye, d, p0, p1, pr[13], rgb, s);
+  else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
+  else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
+}
+__global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p, const float* prims, int band_rows) {
+  const int env = blockIdx.y, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int band0 = blockIdx.x * band_rows, band1 = min(band0 + band_rows, p.H) - 1;  // rows [band0, band1] of the image
+  const int npix = (band1 - band0 + 1) * p.W;
+  unsigned long long* depth = raster_lds;
+  float* lds_prims = reinterpret_cast<float*>(raster_lds + npix);
+  int* bbox = reinterpret_cast<int*>(lds_prims + MAX_NPRIM * PRIM_FLOATS);  // r0, r1, c0, c1 per primitive
+  {
+    const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
+    for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
+    for (int k = tid; k < npix; k += 256) depth[k] = ~0ull;
+  }
+  F3 eye;
+  const float* right = p.cam.right;
+  const float* up = p.cam.up;
+  const float* back = p.cam.back;
+  if (p.env_cams) {
+    const float* cm = p.env_cams + (size_t)env * 12;
+    eye = f3(cm[0], cm[1], cm[2]);
+    right = cm + 3; up = cm + 6; back = cm + 9;
+  } else {
+    eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+  }
+  __syncthreads();
+  if (tid < nprim) {  // pixel rectangle of the primitive's bound: tangent extents of its bounding sphere(s), padded
+    const float* pr = lds_prims + tid * PRIM_FLOATS;
+    const int type = (int)pr[0];
+    const bool two = type == PRIM_CAPSULE || type == PRIM_CYLINDER;
+    const float rad = two ? bound_radius(pr[13]) : pr[17];
+    const float aspect = (float)p.W / (float)p.H, tx = p.cam.tan_half * aspect, ty = p.cam.tan_half;
+    float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+    bool everything = false;
+    for (int e = 0; e < (two ? 2 : 1); e++) {
+      const F3 v = sub(f3(pr[1 + 3 * e], pr[2 + 3 * e], pr[3 + 3 * e]), eye);
+      const float x = v.x * right[0] + v.y * right[1] + v.z * right[2], y = v.x * up[0] + v.y * up[1] + v.z * up[2];
+      const float z = -(v.x * back[0] + v.y * back[1] + v.z * back[2]);
+      if (!(z > rad * 1.05f + 1.0e-3f)) { everything = true; continue; }  // the bound reaches the camera plane
+      const float den = z * z - rad * rad;
+      const float sx = rad * sqrtf(x * x + den), sy = rad * sqrtf(y * y + den);
+      xlo = fminf(xlo, (x * z - sx) / den); xhi = fmaxf(xhi, (x * z + sx) / den);
+      ylo = fminf(ylo, (y * z - sy) / den); yhi = fmaxf(yhi, (y * z + sy) / den);
+    }
+    int r0 = 0, r1 = p.H - 1, c0 = 0, c1 = p.W - 1;
+    if (!everything) {
+      // px = (2 (col + 0.5) / W - 1) tx,  py = (1 - 2 (row + 0.5) / H) ty   (pixel_ray_axes)
+      const float cl = (xlo / tx + 1.0f) * 0.5f * (float)p.W - 0.5f, ch = (xhi / tx + 1.0f) * 0.5f * (float)p.W - 0.5f;
+      const float rl = (1.0f - yhi / ty) * 0.5f * (float)p.H - 0.5f, rh = (1.0f - ylo / ty) * 0.5f * (float)p.H - 0.5f;
+      // clamp in float first (the extents can be huge for bounds near the camera plane), then pad by a pixel
+      c0 = (int)floorf(fminf(fmaxf(cl, -1.0f), (float)p.W)) - 1; c1 = (int)ceilf(fminf(fmaxf(ch, -1.0f), (float)p.W)) + 1;
+      r0 = (int)floorf(fminf(fmaxf(rl, -1.0f), (float)p.H)) - 1; r1 = (int)ceilf(fminf(fmaxf(rh, -1.0f), (float)p.H)) + 1;
+      c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, p.W - 1); r1 = min(r1, p.H - 1);
+    }
+    r0 = max(r0, band0); r1 = min(r1, band1);  // this workgroup's band (possibly empty)
+    bbox[4 * tid] = r0; bbox[4 * tid + 1] = r1; bbox[4 * tid + 2] = c0; bbox[4 * tid + 3] = c1;
+  }
+  __syncthreads();
+  for (int k = wave; k < nprim; k += 4) {  // wave-uniform
+    const float* pr = lds_prims + k * PRIM_FLOATS;
+    const int type = (int)pr[0];
+    const int r0 = bbox[4 * k], r1 = bbox[4 * k + 1], c0 = bbox[4 * k + 2], c1 = bbox[4 * k + 3];
+    const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+    const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
+    const float ococ = dotf(oc, oc), br = pr[17];
+    for (int rb = r0; rb <= r1; rb += 8) {
+      for (int cb = c0; cb <= c1; cb += 8) {
+        const int row = rb + (lane >> 3), col = cb + (lane & 7);
+        const bool in = row <= r1 && col <= c1;
+        const F3 d = pixel_ray_axes(p, row, col, right, up, back);
+        const float along = dotf(oc, d), off2 = ococ - along * along;  // per-ray bounding-sphere reject (as in the tile kernel)
+        const bool pass = in && off2 <= br * br && along + br > 0.0f;
+        if (!__any(pass)) continue;
+        Surf s;
+        s.t = INFINITY;
+        s.n = f3(0, 0, 1);
+        s.rgb = f3(0, 0, 0);
+        if (pass) exact_test(pr, eye, d, s);
+        if (pass && s.t < INFINITY)
+          atomicMin(&depth[(row - band0) * p.W + col], ((unsigned long long)__float_as_uint(s.t) << 32) | (unsigned)k);
+      }
+    }
+  }
+  __syncthreads();
+  for (int px = tid; px < npix; px += 256) {
+    const int lrow = px / p.W, col = px - lrow * p.W, row = band0 + lrow;
+    const F3 d = pixel_ray_axes(p, row, col, right, up, back);
+    Surf s;
+    s.t = INFINITY;
+    s.n = f3(0, 0, 1);
+    s.rgb = f3(0, 0, 0);
+    hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+    const unsigned long long key = depth[px];
+    if (key != ~0ull && __uint_as_float((unsigned)(key >> 32)) < s.t) {
+      Surf w;
+      w.t = INFINITY;
+      w.n = f3(0, 0, 1);
+      w.rgb = f3(0, 0, 0);
+      exact_test(lds_prims + (int)(key & 0xffffffffu) * PRIM_FLOATS, eye, d, w);  // the winner once more, for its normal
+      s = w;
+    }
+    F3 c = f3(0, 0, 0);
+    if (s.t < INFINITY) c = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
+    uint8_t* o = p.out + ((size_t)env * p.H * p.W + (size_t)band0 * p.W + px) * 3;
+    o[0] = to_u8(c.x);
+    o[1] = to_u8(c.y);
+    o[2] = to_u8(c.z);
+  }
+}
+
 }  // namespace rend

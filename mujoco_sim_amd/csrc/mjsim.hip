@@ -375,22 +375,33 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
   const int tiles = ((height + 7) / 8) * ((width + 7) / 8);  // robot scenes: one wavefront per 8x8 tile
   dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
+  // robot scenes: the primitive-major kernel (one workgroup per env image, depth keys in LDS) for the fixed scene
+  // cameras up to 64x64 pixels. Measured (profiles/r01_j_render_ab.txt): 17-37 % faster there; slower than the tile walk
+  // for larger images (bands of rows repeat the per-primitive work, one workgroup per image starves the CUs of waves)
+  // and for the wrist camera (the gripper's bounds reach the camera plane: whole-image passes per primitive).
+  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && !wrist && h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
+  const int band_rows = height;
+  const size_t raster_lds = rend::raster_lds_bytes_host(band_rows, width);
+  auto robot_scene = [&]() {
+    if (raster) rend::robot_scene_raster_kernel<<<dim3((unsigned)((height + band_rows - 1) / band_rows), (unsigned)p.N), 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, band_rows);
+    else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+  };
   if (task == MJS_TASK_POINTMASS_REACH) {
     rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
   } else if (task == MJS_TASK_BUTTON_PUSH) {
     rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
     p.nprim = rend::BP_NPRIM;
     if (wrist) p.env_cams = h->cams;
-    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    robot_scene();
   } else if (task == MJS_TASK_PLANAR_PUSH) {  // robot_planar_push.py:45,66: the FRONT_TILTED camera of Robot-Reach
     const int nslots = MJS_PP_OBJECT_SLOTS(h->cfg.n_objects);
     rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects, nslots);
     p.nprim = rend::ARM_NREC + 1 + nslots;
-    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    robot_scene();
   } else {
     rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);
     p.nprim = rend::RR_NPRIM;
-    rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    robot_scene();
   }
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;

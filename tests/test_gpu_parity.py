@@ -848,6 +848,25 @@ def test_planar_push_camera_matches_oracle(oracle_mod):
     vis.close()
 
 
+@pytest.mark.parametrize("task", ["robot_reach", "robot_push_button", "robot_planar_push"])
+def test_scene_camera_kernels_agree_byte_for_byte(task):
+    """The primitive-major render kernel (default for scene cameras up to 64x64) only reorganises WHICH exact ray tests
+    run; its image must equal the 8x8-tile walk's (kernel_variant 1) byte for byte."""
+    import mujoco_sim_amd as m
+
+    N = 48
+    a = m.HipVectorEnv(task, N, seed=77)
+    b = m.HipVectorEnv(task, N, seed=77, kernel_variant=1)
+    a.reset()
+    b.reset()
+    for res in (32, 64):
+        ia, ib = a.render(res, res).cpu().numpy(), b.render(res, res).cpu().numpy()
+        assert np.array_equal(ia, ib), (task, res, int((ia != ib).sum()))
+        assert ia.std() > 10
+    a.close()
+    b.close()
+
+
 def test_every_registered_env_runs_a_random_policy_to_the_end():
     """test/test_gym_envs.py:7-18 (test_env_w_random_policy) and :21-36 (test_determinism_of_env) over every registered id:
     an episode under the task's own random policy ends (terminated or truncated) within the step limit; seeded resets
