@@ -42,7 +42,9 @@ enum { MJS_STEP_FIRST = 0, MJS_STEP_MID = 1, MJS_STEP_LAST = 2 };
  * action and returns the reset observation); SAME_STEP is what SB3 VecEnv expects
  * (scripts/sb3/reach_sac.py:93-96): reset immediately, expose `terminal_obs`. */
 enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_DISABLED = 2 };
-/* kernel variants (results identical up to rounding; used for A/B profiles) */
+/* kernel variants (results identical up to rounding; used for A/B profiles). Variant 1 = the first-generation kernels:
+ * the single-wavefront step kernels of Robot-Reach / Button-Push (default: two role-specialised wavefronts) and the
+ * 8x8-tile camera kernel for every image (default: the primitive-major kernel for scene cameras up to 64x64) */
 enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1 };
 /* mjs_outputs.fault bits */
 enum { MJS_FAULT_BAD_STATE = 1, MJS_FAULT_IK_FAILED = 2, MJS_FAULT_LIMIT_COLDSTART = 4, MJS_FAULT_UNSUPPORTED_CONTACT = 8 };
