@@ -615,6 +615,48 @@ def test_planar_push_controlled_scenarios(oracle_mod):
     assert q2[5, 6] - qp[5, 6] > 0.03 and q2[6, 13] - qp[6, 13] > 0.01  # the pushes really moved the blocks
 
 
+def test_planar_push_block_train_couples_all_bodies(oracle_mod):
+    """5-slot kernel, largest coupled sub-system: the EEF pushes a train of 5 blocks that overlap their neighbours by
+    0.05 mm (identical hand-set states): the four block-block contacts are active from the first substep (30 dofs), and
+    the arm joins when the EEF reaches the first block (36 dofs: EEF-block, 4 block-block and 20 floor contacts). In
+    env 0 the blocks stand 0.2 mm apart and nothing pushes (floor contacts only: quad solves)."""
+    import mujoco_sim_amd as m
+
+    N = 4
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=3, n_objects=5)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 3, n_objects=5, nthreads=4)
+    venv.reset()
+    o = ob.reset()
+    qp, qv, tm = ob.get_state()
+    tcp = o["obs"][:, :3].copy()
+    qv[:] = 0
+    width = 2 * 0.019826
+    for i in range(N):
+        for b in range(5):
+            x = tcp[i, 0] + 0.02 + 0.019826 + 0.004 + b * (width + (0.0002 if i == 0 else -0.00005 - 0.00001 * i))
+            qp[i, 6 + 7 * b: 13 + 7 * b] = [x, tcp[i, 1] + 0.002 * b * (i % 2), 0.0, 1, 0, 0, 0]
+    ob.set_state(qp, qv)
+    _push_state_to_gpu(venv, qp, qv, tm)
+    act = tcp[:, :2].copy()
+    most = 0
+    for t in range(8):
+        act[1:, 0] += 0.012
+        venv.step(torch.from_numpy(act))
+        r = ob.step(act)
+        g = venv.get_state().cpu().numpy()
+        q2, v2, _ = ob.get_state()
+        assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), (t, venv._buf["ncon"].cpu().numpy(), r["ncon"])
+        for b in range(5):
+            np.testing.assert_allclose(g[17 + 13 * b: 24 + 13 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-8, err_msg=f"block {b} pose, step {t}")
+            np.testing.assert_allclose(g[24 + 13 * b: 30 + 13 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-6, err_msg=f"block {b} velocity, step {t}")
+        np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-9)
+        np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-8)
+        most = max(most, int(r["ncon"].max()))
+    assert most >= 20 + 4                          # floor corners + the four block-block contacts of the train (+ EEF-block)
+    assert q2[1, 6 + 7 * 4] - qp[1, 6 + 7 * 4] > 0.01  # the LAST block of the train moved: the push went through all five
+    venv.close()
+
+
 def test_planar_push_parity_with_oracle(oracle_mod):
     """Seeded episodes with a noisy push-towards-the-block policy: device-side rejection-sampled resets + 150 settle
     steps, pushes, step-limit truncation and auto-resets. Contact-rich rigid-body motion amplifies rounding noise in a
