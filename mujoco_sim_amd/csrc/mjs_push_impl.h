@@ -36,7 +36,12 @@ constexpr int WAVES = NB <= 2 ? 4 : 1;
 #ifndef MJS_PP_ENVS_PER_WAVE
 #define MJS_PP_ENVS_PER_WAVE 4
 #endif
-constexpr int EPW = MJS_PP_ENVS_PER_WAVE;
+#ifndef MJS_PP5_ENVS_PER_WAVE
+#define MJS_PP5_ENVS_PER_WAVE 16
+#endif
+// the 5-slot instance has room for ONE wavefront per CU (LDS): more envs per wavefront keep all envs of a 4096-env launch
+// resident at once instead of in four rounds
+constexpr int EPW = NB <= 2 ? MJS_PP_ENVS_PER_WAVE : MJS_PP5_ENVS_PER_WAVE;
 static_assert(EPW >= 1 && EPW <= 16 && (EPW & (EPW - 1)) == 0, "quads of lanes per (env, block): 4 * EPW lanes per block");
 constexpr int QUAD_BLOCKS = 16 / EPW;  // blocks whose quads fit the wavefront in one pass
 
