@@ -680,7 +680,9 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     bbox[4 * tid] = r0; bbox[4 * tid + 1] = r1; bbox[4 * tid + 2] = c0; bbox[4 * tid + 3] = c1;
   }
   __syncthreads();
-  for (int k = wave; k < nprim; k += 4) {  // wave-uniform
+  int turn = 0;  // 8x8 blocks of all primitives are dealt round-robin to the 4 wavefronts (a primitive whose bound reaches
+                 // the camera plane covers the whole image: whole primitives per wavefront would leave three idle)
+  for (int k = 0; k < nprim; k++) {  // wave-uniform
     const float* pr = lds_prims + k * PRIM_FLOATS;
     const int type = (int)pr[0];
     const int r0 = bbox[4 * k], r1 = bbox[4 * k + 1], c0 = bbox[4 * k + 2], c1 = bbox[4 * k + 3];
@@ -689,6 +691,7 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     const float ococ = dotf(oc, oc), br = pr[17];
     for (int rb = r0; rb <= r1; rb += 8) {
       for (int cb = c0; cb <= c1; cb += 8) {
+        if (((turn++) & 3) != wave) continue;
         const int row = rb + (lane >> 3), col = cb + (lane & 7);
         const bool in = row <= r1 && col <= c1;
         const F3 d = pixel_ray_axes(p, row, col, right, up, back);
