@@ -938,6 +938,32 @@ def test_every_registered_env_runs_a_random_policy_to_the_end():
         env.close()
 
 
+def test_planar_push_reference_default_config_through_the_adapter():
+    """RobotPushConfig() = the reference's defaults (robot_planar_push.py:29-73: 5 objects, 500 steps, dense reward)
+    through the dm_env -> gymnasium adapter: spaces, a short episode, info keys (no is_success: the task defines no
+    is_goal_reached, dmc2gym.py:149-150)."""
+    import mujoco_sim_amd as m
+
+    task = m.RobotPushTask(m.RobotPushConfig(max_control_steps_per_episode=6))
+    assert task.config.n_objects == 5
+    env = m.DMCEnvironmentAdapter(m.HipEnvironment(task), flatten_observation_space=False)
+    env.seed(11)
+    obs, _ = env.reset()
+    assert list(obs) == ["ur5e/tcp_position", "target_position", "block_positions"]
+    assert obs["block_positions"].shape == (10,) and env.observation_space["block_positions"].shape == (10,)
+    assert env.action_space.shape == (2,)
+    done, n = False, 0
+    while not done:
+        a = obs["ur5e/tcp_position"][:2] + np.clip(obs["block_positions"][:2] - obs["ur5e/tcp_position"][:2], -0.02, 0.02)
+        obs, reward, term, trunc, info = env.step(a.astype(np.float32))
+        done, n = bool(term or trunc), n + 1
+        assert reward < 0 and "is_success" not in info and info["discount"] in (0.0, 1.0)
+    assert n == 6 and trunc and not term
+    img = env.render()
+    assert img.shape == (256, 256, 3) and img.std() > 10
+    env.close()
+
+
 def test_pointmass_demonstration_policy_and_video_wrapper(tmp_path):
     """point_reach.py:227-240: the scripted policy steps straight at the goal with the largest component at MAX_STEP_SIZE
     (it never shortens the last step, so a few episodes orbit the 2 cm goal disc) and solves most episodes (terminated,
