@@ -1226,6 +1226,17 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
   }
 }
 
+// sin / cos of the half rotation angle of one substep (0.5 |w| dt: < 0.125 rad unless a block spins faster than 50 rad/s):
+// Taylor kernels (truncation error < 3e-20 there) instead of ocml's range-reducing sincos
+MJS_DEV void sincos_small(double x, double* s, double* c) {
+  if (fabs(x) < 0.125) {
+    const double x2 = x * x;
+    *s = x * (1.0 - x2 * (1.0 / 6) * (1.0 - x2 * (1.0 / 20) * (1.0 - x2 * (1.0 / 42) * (1.0 - x2 * (1.0 / 72) * (1.0 - x2 * (1.0 / 110) * (1.0 - x2 * (1.0 / 156)))))));
+    *c = 1.0 - x2 * 0.5 * (1.0 - x2 * (1.0 / 12) * (1.0 - x2 * (1.0 / 30) * (1.0 - x2 * (1.0 / 56) * (1.0 - x2 * (1.0 / 90) * (1.0 - x2 * (1.0 / 132))))));
+  } else
+    sincos(x, s, c);
+}
+
 // One Physics.step() (mj_step2 of the current state; the next mj_step1 is the start of the next call): smooth
 // dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
 // `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
@@ -1250,7 +1261,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     double qn[4];
     const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] * (1.0 / nrm);
     Rb[b] = quat_to_m3(qn);
   }
   // contacts (static slots): floor corners per block; is any arm-block / block-block pair penetrating?
@@ -1429,8 +1440,9 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (ang >= MJS_MINVAL) {
       const V3 ax = (1.0 / ang) * k.w;
       double sh, chf;
-      sincos(0.5 * ang * MJS_RR_PHYSICS_DT, &sh, &chf);
-      const double q0 = k.q[0] / nrm, q1 = k.q[1] / nrm, q2 = k.q[2] / nrm, q3 = k.q[3] / nrm;
+      sincos_small(0.5 * ang * MJS_RR_PHYSICS_DT, &sh, &chf);
+      const double inrm = 1.0 / nrm;
+      const double q0 = k.q[0] * inrm, q1 = k.q[1] * inrm, q2 = k.q[2] * inrm, q3 = k.q[3] * inrm;
       const double r0 = chf, r1 = ax.x * sh, r2 = ax.y * sh, r3 = ax.z * sh;
       k.q[0] = q0 * r0 - q1 * r1 - q2 * r2 - q3 * r3;
       k.q[1] = q0 * r1 + q1 * r0 + q2 * r3 - q3 * r2;
@@ -1439,7 +1451,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
       nrm = sqrt(k.q[0] * k.q[0] + k.q[1] * k.q[1] + k.q[2] * k.q[2] + k.q[3] * k.q[3]);
     }
 #pragma unroll
-    for (int i = 0; i < 4; i++) k.q[i] /= nrm;
+    for (int i = 0; i < 4; i++) k.q[i] *= 1.0 / nrm;
   }
   info.bad = info.bad || !(acc2 <= 1e20);
   s.time += MJS_RR_PHYSICS_DT;
@@ -1454,7 +1466,7 @@ __device__ __noinline__ int count_contacts(const World& s, const double* cs, con
   for (int b = 0; b < nb; b++) {
     double qn[4];
     const double nrm = sqrt(s.b[b].q[0] * s.b[b].q[0] + s.b[b].q[1] * s.b[b].q[1] + s.b[b].q[2] * s.b[b].q[2] + s.b[b].q[3] * s.b[b].q[3]);
-    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] / nrm;
+    for (int k = 0; k < 4; k++) qn[k] = s.b[b].q[k] * (1.0 / nrm);
     Rb[b] = quat_to_m3(qn);
   }
   Contact con[MAXCON];
