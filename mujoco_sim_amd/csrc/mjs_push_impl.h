@@ -429,6 +429,15 @@ MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
 // (0, axis_d . n) for the torsional row. Solved by quad_block_floor below. Cold start at qacc_smooth: a warm start from
 // the previous substep's accelerations (mjData.qacc_warmstart; tried per component) needed MORE Newton iterations
 // (2.4 -> 3.8 per coupled solve) and moved hand-set scenarios by the solver tolerance (5e-10) instead of 1e-16.
+// x = M^-1 f for a block in closed form: with the 3x3 blocks M = [[m I, B], [B^T, D]], B = m g (-R.cy, R.cx, 0) and
+// D = diag(Ixx + m g^2, Iyy + m g^2, Izz), the Schur complement D - B^T B / m is diag(Ixx, Iyy, Izz): no factorisation
+MJS_DEV void block_minv(const M3& R, const double* f, double* x) {
+  const double g = MJS_BLOCK_GEOM_Z;
+  const V3 fl = v3(f[0], f[1], f[2]);
+  const double ax = (f[3] + g * dot(R.cy, fl)) * (1.0 / BLK_IXX), ay = (f[4] - g * dot(R.cx, fl)) * (1.0 / BLK_IYY), az = f[5] * (1.0 / BLK_IZZ);
+  const V3 a = madd(madd((1.0 / MJS_BLOCK_MASS) * fl, g * ax, R.cy), -g * ay, R.cx);
+  x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = ax; x[4] = ay; x[5] = az;
+}
 MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangle + the coupling block both ways
   const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
 #pragma unroll
@@ -496,16 +505,9 @@ MJS_DEV void quad_block_floor(const M3 R, const double* qvel, const double* f, b
 #pragma unroll
     for (int e = 0; e < 6; e++) aref[e] = -B * ev[e] - K * imp * dist;
   }
-  double L[6][6], a[6], a_s[6], Ma[6], jar[6], force[6];
+  double a[6], a_s[6], Ma[6], jar[6], force[6];
   bool act[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) L[i][j] = Mb[i][j];
-    a_s[i] = f[i];
-  }
-  rr::chol6(L);
-  rr::chol6_solve(L, a_s);
+  block_minv(R, f, a_s);
 #pragma unroll
   for (int i = 0; i < 6; i++) a[i] = a_s[i];
 #pragma unroll
@@ -1404,12 +1406,8 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   for (int b = 0; b < NB; b++) {
     if (b >= nb) continue;
     const int o = NJ + 6 * b;
-    double Lb[6][6], x[6];
-    block_mass_matrix6(Rb[b], Lb);
-#pragma unroll
-    for (int i = 0; i < 6; i++) x[i] = qacc[o + i];
-    rr::chol6(Lb);
-    rr::chol6_solve(Lb, x);
+    double x[6];
+    block_minv(Rb[b], qacc + o, x);
 #pragma unroll
     for (int i = 0; i < 6; i++) { qacc[o + i] = x[i]; acc2 = fma(x[i], x[i], acc2); }
   }
