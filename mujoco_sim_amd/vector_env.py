@@ -93,6 +93,9 @@ def _as_uint8_ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 class HipVectorEnv:
     """Batched environment on one GPU. One handle = one process = one device."""
 
@@ -119,6 +122,7 @@ class HipVectorEnv:
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise nat.MjsError("HipVectorEnv needs a HIP device (torch device 'cuda:N'); there is no CPU path")
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.num_envs = int(num_envs)
         self.autoreset = autoreset
         self.env_index_offset = int(env_index_offset)
@@ -206,6 +210,9 @@ class HipVectorEnv:
         return nat.MjsOutputs(**{k: C.c_void_p(v.data_ptr()) if v is not None else None for k, v in buf.items()})
 
     def _stream(self):
+        # the caller's current stream, by its raw handle (the Stream-object route costs ~4 us per step on the host)
+        if _RAW_STREAM is not None:
+            return C.c_void_p(_RAW_STREAM(self._dev_index))
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def _obs_dict(self, flat):
