@@ -27,8 +27,8 @@ constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
 constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
 constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
 // wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines; the 5-slot
-// instance's cooperative workspace (~113 KB) leaves room for one wavefront per CU
-constexpr int WAVES = NB <= 2 ? 4 : 1;
+// instance's cooperative workspace (~62 KB with compact rows, 113 KB dense) leaves room for two wavefronts per CU
+constexpr int WAVES = NB <= 2 ? 4 : 2;
 // Envs per wavefront. The coupled constraint problems of a wavefront's envs are solved one after the other by the
 // whole wavefront, so the critical path of a launch is set by the wavefront with the most coupled envs; at 4096 envs
 // the chip has 16x more SIMDs than 64-env wavefronts would use, so fewer envs per wavefront (the other lanes only
@@ -37,10 +37,10 @@ constexpr int WAVES = NB <= 2 ? 4 : 1;
 #define MJS_PP_ENVS_PER_WAVE 4
 #endif
 #ifndef MJS_PP5_ENVS_PER_WAVE
-#define MJS_PP5_ENVS_PER_WAVE 16
+#define MJS_PP5_ENVS_PER_WAVE 8
 #endif
-// the 5-slot instance has room for ONE wavefront per CU (LDS): more envs per wavefront keep all envs of a 4096-env launch
-// resident at once instead of in four rounds
+// the 5-slot instance has room for TWO wavefronts per CU (LDS, compact rows): 8 envs per wavefront keep all envs of a
+// 4096-env launch resident at once (measured: 4 / 8 / 16 envs per wavefront = 297 / 403 / 308 k env-steps/s)
 constexpr int EPW = NB <= 2 ? MJS_PP_ENVS_PER_WAVE : MJS_PP5_ENVS_PER_WAVE;
 static_assert(EPW >= 1 && EPW <= 16 && (EPW & (EPW - 1)) == 0, "quads of lanes per (env, block): 4 * EPW lanes per block");
 constexpr int QUAD_BLOCKS = 16 / EPW;  // blocks whose quads fit the wavefront in one pass
@@ -652,6 +652,8 @@ struct StepInfo {
 // entries are dealt to lanes, the 18 x 18 Cholesky and the triangular solves run column by column in LDS.
 // The function must be called by all 64 lanes of the workgroup (uniform control flow).
 constexpr int LDP = NV + 1;  // padded leading dimension in LDS
+constexpr bool COMPACT = NB > 2;
+constexpr int COL_NONE = 1 << 20;
 // The cooperating lanes are ONE wavefront (several wavefronts share a workgroup only to share the instruction
 // cache). A wavefront's LDS instructions execute in program order, so the only things a "sync" has to do are (1) keep
 // the COMPILER from moving one lane's LDS load above another lane's earlier store and (2) drain the LDS queue. A
@@ -665,8 +667,12 @@ constexpr int LDP = NV + 1;  // padded leading dimension in LDS
   } while (0)
 #endif
 struct CoopLds {
-  // row MAXROW is the null row (J = 0, D = 0, force = 0): padding of the active-row list
-  double J[MAXROW + 1][LDP], D[MAXROW + 1], aref[MAXROW], jar[MAXROW], force[MAXROW + 1];
+  // row MAXROW is the null row (J = 0, D = 0, force = 0): padding of the active-row list.
+  // Rows are dense (LDP columns) in the 2-slot instance. In the 5-slot instance they are COMPACT: a row touches at most
+  // two bodies, so it stores [6 columns of group 0 | 6 of group 1] and cb = the first dense column of each group
+  // (COL_NONE: no such group) - 26 KB instead of 75 KB, which is what lets two wavefronts share a CU.
+  double J[MAXROW + 1][COMPACT ? 12 : LDP], D[MAXROW + 1], aref[MAXROW], jar[MAXROW], force[MAXROW + 1];
+  int cb[COMPACT ? MAXROW + 1 : 1][2];
   double M[NV][LDP], H[NV][LDP];
   double qs[NV], a[NV], a_s[NV], Ma[NV], search[NV], Mv[NV], fc[NV];
   int arow[MAXROW], nact;  // indices of the active rows (ascending), rebuilt by every constraint update
@@ -674,6 +680,7 @@ struct CoopLds {
   // the sub-system being solved: the bodies with an active arm-block / block-block contact or joint-limit row; its
   // dofs are packed (arm first when present). off[0] = arm offset (0) or -1, off[1 + b] = offset of block b or -1.
   int nv, off[NB + 1];
+  double jtf[NV];  // J^T force accumulator of the compact-row instance
   // problem description written by the owner lane; the rows are then built by all lanes
   int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
   double c_dist[MAXCON], c_tran[MAXCON], c_pos[MAXCON][3], c_n[MAXCON][3];
@@ -686,6 +693,15 @@ struct CoopLds {
 // to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
 extern __shared__ double pp_lds_raw[];
 MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
+MJS_DEV double jat(const CoopLds& sh, int r, int c) {  // J[r][c] of the dense matrix
+  if constexpr (!COMPACT) return sh.J[r][c];
+  else {
+    const int d0 = c - sh.cb[r][0], d1 = c - sh.cb[r][1];
+    const bool in0 = (unsigned)d0 < 6u, in1 = (unsigned)d1 < 6u;
+    const double v = sh.J[r][in0 ? d0 : in1 ? 6 + d1 : 0];
+    return (in0 || in1) ? v : 0.0;
+  }
+}
 // exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
 // cooperative solver, which runs after it
 struct QuadIn {
@@ -812,9 +828,19 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
   };
   auto j_times = [&](int r, const double* x) {  // (J x)[r]
     double y = 0;
-    for (int k = 0; k < nv; k += 6) {
+    if constexpr (!COMPACT) {
+      for (int k = 0; k < nv; k += 6) {
 #pragma unroll
-      for (int u = 0; u < 6; u++) y += sh.J[r][k + u] * x[k + u];
+        for (int u = 0; u < 6; u++) y += sh.J[r][k + u] * x[k + u];
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 2; g++) {
+        const int c0 = sh.cb[r][g];
+        if (c0 == COL_NONE) continue;
+#pragma unroll
+        for (int u = 0; u < 6; u++) y += sh.J[r][6 * g + u] * x[c0 + u];
+      }
     }
     return y;
   };
@@ -857,17 +883,39 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
   };
   auto jt_force = [&]() {  // (J^T force)[col] over the active rows
     double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if constexpr (!COMPACT) {
 #pragma unroll
-    for (int q = 0; q < NCH; q++) {
-      const int nq = min(nact - 64 * q, 64);
-      for (int k = 0; k < nq; k += 4) {  // lanes past the list hold the null row
-        const int r0 = __builtin_amdgcn_readlane(myrow[q], k), r1 = __builtin_amdgcn_readlane(myrow[q], (k + 1) & 63);
-        const int r2 = __builtin_amdgcn_readlane(myrow[q], (k + 2) & 63), r3 = __builtin_amdgcn_readlane(myrow[q], (k + 3) & 63);
-        s0 += sh.J[r0][col] * sh.force[r0]; s1 += sh.J[r1][col] * sh.force[r1];
-        s2 += sh.J[r2][col] * sh.force[r2]; s3 += sh.J[r3][col] * sh.force[r3];
+      for (int q = 0; q < NCH; q++) {
+        const int nq = min(nact - 64 * q, 64);
+        for (int k = 0; k < nq; k += 4) {  // lanes past the list hold the null row
+          const int r0 = __builtin_amdgcn_readlane(myrow[q], k), r1 = __builtin_amdgcn_readlane(myrow[q], (k + 1) & 63);
+          const int r2 = __builtin_amdgcn_readlane(myrow[q], (k + 2) & 63), r3 = __builtin_amdgcn_readlane(myrow[q], (k + 3) & 63);
+          s0 += sh.J[r0][col] * sh.force[r0]; s1 += sh.J[r1][col] * sh.force[r1];
+          s2 += sh.J[r2][col] * sh.force[r2]; s3 += sh.J[r3][col] * sh.force[r3];
+        }
       }
+      return (s0 + s1) + (s2 + s3);
+    } else {
+      // compact rows, row-major: every active row scatters force * J into the <= 12 columns it touches (ds_add_f64,
+      // rows one after the other = deterministic order); lanes 0..11 of a trip serve one row, 5 rows per trip
+      if (lane < NV) sh.jtf[lane] = 0;
+      MJS_WAVE_SYNC();
+      const int slot = lane / 12, u = lane - 12 * slot;  // 5 rows x 12 columns per trip (lanes 60..63 idle)
+#pragma unroll
+      for (int q = 0; q < NCH; q++) {
+        const int nq = min(nact - 64 * q, 64);
+        for (int k = 0; k < nq; k += 5) {
+          const int kk = k + slot;
+          const int r = __shfl(myrow[q], kk < 64 ? kk : 63);
+          if (slot < 5 && kk < nq) {
+            const int c0 = sh.cb[r][u < 6 ? 0 : 1];
+            if (c0 != COL_NONE) atomicAdd(&sh.jtf[c0 + (u < 6 ? u : u - 6)], sh.J[r][u] * sh.force[r]);
+          }
+        }
+      }
+      MJS_WAVE_SYNC();
+      return sh.jtf[col];
     }
-    return (s0 + s1) + (s2 + s3);
   };
   double cost = update();
   PP_ACC(info, 8, tn);
@@ -892,7 +940,7 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
   int iters = 0;
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     iters++;
-    {  // Hessian = M + J^T diag(D active) J
+    if constexpr (!COMPACT) {  // Hessian = M + J^T diag(D active) J, entry-major: each lane sums its entries over the active rows
       double h[NHE];
 #pragma unroll
       for (int q = 0; q < NHE; q++) h[q] = sh.M[hi[q]][hj[q]];
@@ -917,6 +965,42 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
 #pragma unroll
       for (int q = 0; q < NHE; q++)
         if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
+    } else {
+      // row-major for the compact rows: a row touches <= 12 columns, i.e. <= 78 of the up to 666 entries. H starts as M;
+      // every active row then adds D J_a J_b for its local column pairs (a >= b, one or two pairs per lane) with LDS
+      // ds_add_f64. Rows are processed one after the other (LDS operations of a wavefront execute in order), so every
+      // entry sees its contributions in row order: deterministic.
+#pragma unroll
+      for (int q = 0; q < NHE; q++)
+        if (he[q]) sh.H[hi[q]][hj[q]] = sh.M[hi[q]][hj[q]];
+      int pa[2], pb[2];
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int e = min(lane + 64 * q, 77);
+        int a = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((a + 1) * (a + 2) / 2 <= e) a++;
+        while (a * (a + 1) / 2 > e) a--;
+        pa[q] = a; pb[q] = e - a * (a + 1) / 2;
+      }
+      MJS_WAVE_SYNC();
+#pragma unroll
+      for (int c = 0; c < NCH; c++) {
+        const int nq = min(nact - 64 * c, 64);
+        for (int k = 0; k < nq; k++) {
+          const int r = __builtin_amdgcn_readlane(myrow[c], k);
+          const double d = sh.D[r];
+          const int c0 = sh.cb[r][0], c1 = sh.cb[r][1];
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            if (q == 1 && lane >= 78 - 64) continue;
+            const int ca = pa[q] < 6 ? c0 : c1, cbq = pb[q] < 6 ? c0 : c1;
+            if (ca == COL_NONE || cbq == COL_NONE) continue;  // wave-uniform per pair class only when both groups exist; per-lane otherwise
+            const int ia = ca + (pa[q] < 6 ? pa[q] : pa[q] - 6), ib = cbq + (pb[q] < 6 ? pb[q] : pb[q] - 6);
+            const double v = sh.J[r][pa[q]] * d * sh.J[r][pb[q]];
+            atomicAdd(&sh.H[ia > ib ? ia : ib][ia > ib ? ib : ia], v);
+          }
+        }
+      }
     }
     MJS_WAVE_SYNC();
     PP_ACC(info, 9, tn);
@@ -1109,7 +1193,12 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
     const int j = lane >> 1;
     const double sgn = (lane & 1) ? -1.0 : 1.0;
     const double dist = (lane & 1) ? MJS_UR_JNT_RANGE[j][1] - sh.q[j] : sh.q[j] - MJS_UR_JNT_RANGE[j][0];
-    for (int d = 0; d < nv; d++) sh.J[row][d] = d == j ? sgn : 0.0;
+    if constexpr (!COMPACT) {
+      for (int d = 0; d < nv; d++) sh.J[row][d] = d == j ? sgn : 0.0;
+    } else {
+      for (int d = 0; d < 12; d++) sh.J[row][d] = d == j ? sgn : 0.0;
+      sh.cb[row][0] = 0; sh.cb[row][1] = COL_NONE;
+    }
     const double imp = impedance_default(dist);
     sh.D[row] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
     sh.aref[row] = -B * (sgn * sh.qvel[j]) - K * imp * dist;
@@ -1142,28 +1231,14 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
     const bool rotk = kk == 2;
     const double mu = sgn * fri[kk];
     double vel = 0;
-    const double sa = ba == 1 ? -1.0 : 0.0;
-    if (arm_in) {
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-      const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
-      const V3 lin = cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
-      const double v = sa * dot(n, lin) + mu * (sa * dot(Fk, rotk ? ax : lin));
-      sh.J[row][j] = v;
-      vel += v * sh.qvel[j];
-    }
-    }
-#pragma unroll
-    for (int b = 0; b < NB; b++) {
-      const int o = sh.off[1 + b];
-      if (o < 0) continue;
-      const double sb = (bb == 2 + b ? 1.0 : 0.0) - (ba == 2 + b ? 1.0 : 0.0);
+    const double nd[3] = {n.x, n.y, n.z}, fd[3] = {Fk.x, Fk.y, Fk.z};
+    // the six columns of block b (sign sb) at row offset `base`, dense offset o
+    auto block_cols = [&](int b, double sb, int base, int o) {
       const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
-      const double nd[3] = {n.x, n.y, n.z}, fd[3] = {Fk.x, Fk.y, Fk.z};
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         const double v = sb * nd[d] + mu * (rotk ? 0.0 : sb * fd[d]);
-        sh.J[row][o + d] = v;
+        sh.J[row][base + d] = v;
         vel += v * sh.qvel[o + d];
       }
 #pragma unroll
@@ -1171,9 +1246,39 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
         const V3 axs = v3(sh.bR[b][3 * d], sh.bR[b][3 * d + 1], sh.bR[b][3 * d + 2]);
         const V3 lin = cross(axs, rvec);
         const double v = sb * dot(n, lin) + mu * (sb * dot(Fk, rotk ? axs : lin));
-        sh.J[row][o + 3 + d] = v;
+        sh.J[row][base + 3 + d] = v;
         vel += v * sh.qvel[o + 3 + d];
       }
+    };
+    auto arm_cols = [&](double sa) {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
+        const V3 lin = cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
+        const double v = sa * dot(n, lin) + mu * (sa * dot(Fk, rotk ? ax : lin));
+        sh.J[row][j] = v;
+        vel += v * sh.qvel[j];
+      }
+    };
+    if constexpr (!COMPACT) {
+      if (arm_in) arm_cols(ba == 1 ? -1.0 : 0.0);
+#pragma unroll
+      for (int b = 0; b < NB; b++) {
+        const int o = sh.off[1 + b];
+        if (o < 0) continue;
+        block_cols(b, (bb == 2 + b ? 1.0 : 0.0) - (ba == 2 + b ? 1.0 : 0.0), o, o);
+      }
+    } else {
+      // group 0 = body a (arm, a block or the world), group 1 = body b (always a block)
+      if (ba == 1) { arm_cols(-1.0); sh.cb[row][0] = 0; }
+      else if (ba >= 2) { block_cols(ba - 2, -1.0, 0, sh.off[1 + ba - 2]); sh.cb[row][0] = sh.off[1 + ba - 2]; }
+      else {
+#pragma unroll
+        for (int d = 0; d < 6; d++) sh.J[row][d] = 0.0;
+        sh.cb[row][0] = COL_NONE;
+      }
+      block_cols(bb - 2, 1.0, 6, sh.off[1 + bb - 2]);
+      sh.cb[row][1] = sh.off[1 + bb - 2];
     }
     const double imp = impedance_default(sh.c_dist[c]);
     const double R0 = fmax(MJS_MINVAL, (1 - imp) * (sh.c_tran[c] + fri[0] * fri[0] * sh.c_tran[c]) / imp);
@@ -1181,7 +1286,10 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
     sh.aref[row] = -B * vel - K * imp * sh.c_dist[c];
   }
   if (lane == 0) { sh.nrow = nlim + 6 * nact; sh.D[MAXROW] = 0; sh.force[MAXROW] = 0; }
-  if (lane < NV) sh.J[MAXROW][lane] = 0;
+  if (lane < (COMPACT ? 12 : NV)) sh.J[MAXROW][lane] = 0;
+  if constexpr (COMPACT) {
+    if (lane < 2) sh.cb[MAXROW][lane] = COL_NONE;
+  }
 }
 MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
                           const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in) {
