@@ -940,31 +940,43 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
   int iters = 0;
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     iters++;
-    if constexpr (!COMPACT) {  // Hessian = M + J^T diag(D active) J, entry-major: each lane sums its entries over the active rows
-      double h[NHE];
-#pragma unroll
-      for (int q = 0; q < NHE; q++) h[q] = sh.M[hi[q]][hj[q]];
-      constexpr int HU = 2;  // rows per trip (4 measured slower: register pressure)
-      const int nent = nv * (nv + 1) / 2;
+    if constexpr (!COMPACT) {
+      // Hessian = M + J^T diag(D active) J on the matrix cores: v_mfma_f64_16x16x4_f64 takes A[i][k] = J[r_k][i] and
+      // B[k][j] = D[r_k] J[r_k][j] for four active rows r_k per instruction (lane l: i = j = l & 15, k = l >> 4), so a lane
+      // reads ONE J value and one D per four rows - the entry-major VALU version read 14 values per two rows and was
+      // bound by LDS latency (7.4 k cycles per Newton iteration at 12 dofs). nv <= 16: one 16x16 tile; nv = 18: the
+      // three lower tiles of a 32x32 product. The FP64 MFMA rate equals the vector rate on gfx950: the gain is operand
+      // sharing, not FLOPs. C/D layout (guide): col = lane & 15, row = (lane >> 4) + 4 * reg.
+      typedef double d4 __attribute__((ext_vector_type(4)));
+      d4 c00 = {0, 0, 0, 0}, c10 = {0, 0, 0, 0}, c11 = {0, 0, 0, 0};
+      const int li = lane & 15, lk = lane >> 4;
+      const bool two = nv > 16;  // wave-uniform
 #pragma unroll
       for (int c = 0; c < NCH; c++) {
         const int nq = min(nact - 64 * c, 64);
-        for (int k = 0; k < nq; k += HU) {  // lanes past the list hold the null row
-          int r[HU];
-          double d[HU];
-#pragma unroll
-          for (int u = 0; u < HU; u++) { r[u] = __builtin_amdgcn_readlane(myrow[c], (k + u) & 63); d[u] = sh.D[r[u]]; }
-#pragma unroll
-          for (int q = 0; q < NHE; q++) {
-            if (64 * q >= nent) continue;  // wave-uniform: a sub-system of 12 dofs has 78 entries, 2 per lane
-#pragma unroll
-            for (int u = 0; u < HU; u++) h[q] += sh.J[r[u]][hi[q]] * d[u] * sh.J[r[u]][hj[q]];
+        for (int k = 0; k < nq; k += 4) {  // lanes past the list hold the null row (J = 0, D = 0)
+          const int r0 = __builtin_amdgcn_readlane(myrow[c], k), r1 = __builtin_amdgcn_readlane(myrow[c], (k + 1) & 63);
+          const int r2 = __builtin_amdgcn_readlane(myrow[c], (k + 2) & 63), r3 = __builtin_amdgcn_readlane(myrow[c], (k + 3) & 63);
+          const int r = lk == 0 ? r0 : lk == 1 ? r1 : lk == 2 ? r2 : r3;
+          const double d = sh.D[r];
+          const double a0 = li < nv ? sh.J[r][li] : 0.0;
+          c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, d * a0, c00, 0, 0, 0);
+          if (two) {
+            const double a1 = 16 + li < nv ? sh.J[r][16 + li] : 0.0;
+            c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d * a0, c10, 0, 0, 0);
+            c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, d * a1, c11, 0, 0, 0);
           }
         }
       }
 #pragma unroll
-      for (int q = 0; q < NHE; q++)
-        if (he[q]) sh.H[hi[q]][hj[q]] = h[q];
+      for (int g = 0; g < 4; g++) {
+        const int row = lk + 4 * g;
+        if (row < nv && li <= row) sh.H[row][li] = sh.M[row][li] + c00[g];
+        if (two) {
+          if (16 + row < nv) sh.H[16 + row][li] = sh.M[16 + row][li] + c10[g];
+          if (16 + row < nv && li <= row) sh.H[16 + row][16 + li] = sh.M[16 + row][16 + li] + c11[g];
+        }
+      }
     } else {
       // row-major for the compact rows: a row touches <= 12 columns, i.e. <= 78 of the up to 666 entries. H starts as M;
       // every active row then adds D J_a J_b for its local column pairs (a >= b, one or two pairs per lane) with LDS
