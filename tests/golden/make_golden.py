@@ -76,7 +76,7 @@ def run_button(N, T, base_seed):
     return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
 
 
-def run_push(N, T, base_seed, limit):
+def run_push(N, T, base_seed, limit, n_objects=2):
     """Planar-Push: noisy push-towards-block-0 policy, closed loop on the oracle, step limit `limit` so that
     truncations + device-side resets (rejection-sampled draws, 150 settle steps) are inside the fixture. Returns None
     when some env of the batch is ill-conditioned (a second oracle perturbed by 1e-13 m at every reset disagrees by
@@ -84,8 +84,8 @@ def run_push(N, T, base_seed, limit):
     import ctypes as C
 
     knob = C.c_double.in_dll(oracle.lib(), "om_dbg_perturb")
-    b = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit)
-    b2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit)
+    b = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8)
+    b2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8)
     r = b.reset()
     knob.value = 1e-13
     r2 = b2.reset()
@@ -97,8 +97,9 @@ def run_push(N, T, base_seed, limit):
     rs = np.random.RandomState(99)
     worst = np.abs(r["obs"] - r2["obs"]).max()
     for t in range(T):
-        tcp, blk = r["obs"][:, :2], r["obs"][:, 5:7]
-        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        k = 5 if n_objects <= 2 else 5 + 2 * ((t // 5) % n_objects)  # 5 blocks: chase one block for a few steps, then the next
+        tcp, blk = r["obs"][:, :2], r["obs"][:, k:k + 2]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) * (1.0 if n_objects <= 2 else 1.5) + rs.uniform(-0.004, 0.004, (N, 2))
         acts.append(a)
         r = b.step(a)
         knob.value = 1e-13
@@ -118,6 +119,12 @@ if __name__ == "__main__":
         if fx is not None:
             np.savez_compressed(OUT / "planar_push_n8_t70.npz", base_seed=seed, **fx)
             print("planar push fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 8).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
+            break
+    for seed in range(3025, 3125):  # the reference's default of 5 blocks (5-slot kernel instance), 4 well-conditioned envs
+        fx = run_push(4, 36, seed, 14, n_objects=5)
+        if fx is not None and int((fx["ncon"] > 20).sum()) >= 8:
+            np.savez_compressed(OUT / "planar_push5_n4_t36.npz", base_seed=seed, **fx)
+            print("planar push (5 blocks) fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 20).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
             break
     np.savez_compressed(OUT / "button_push_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025))
     np.savez_compressed(OUT / "pointmass_n8_t70_seed2025.npz", **run(oracle.TASK_POINTMASS, 8, 70, 2025, oracle.AUTORESET_NEXT_STEP))

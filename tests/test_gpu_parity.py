@@ -87,13 +87,16 @@ def test_pointmass_wall_contacts_parity(oracle_mod):
 
 
 @pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", "point_mass_reach"), ("robot_reach_n8_t110_seed2025", "robot_reach"),
-                                       ("button_push_eef_n8_t80_seed2025", "robot_push_button"), ("planar_push_n8_t70", "robot_planar_push")])
+                                       ("button_push_eef_n8_t80_seed2025", "robot_push_button"), ("planar_push_n8_t70", "robot_planar_push"),
+                                       ("planar_push5_n4_t36", "robot_planar_push")])
 def test_gpu_matches_committed_golden(name, task):
     import mujoco_sim_amd as m
 
     g = np.load(GOLDEN / f"{name}.npz")
     T, N = g["actions"].shape[:2]
     kw = {"action_type": "absolute_eef_action"} if task == "robot_push_button" else {"max_episode_steps": 25} if task == "robot_planar_push" else {}
+    if name.startswith("planar_push5"):
+        kw = {"max_episode_steps": 14, "n_objects": 5}
     venv = m.HipVectorEnv(task, N, seed=int(g["base_seed"]) if "base_seed" in g else 2025, **kw)
     venv.reset()
     atol = 1e-8 if task == "robot_planar_push" else ATOL  # contact-rich free bodies (fixture envs are well-conditioned, see make_golden.py)

@@ -205,12 +205,14 @@ def test_pointmass_wall_contacts_detected(oracle_mod):
 
 # ------------------------------------------------------------------------- golden regression
 @pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", 0), ("robot_reach_n8_t110_seed2025", 1), ("button_push_eef_n8_t80_seed2025", 3),
-                                       ("planar_push_n8_t70", 2)])
+                                       ("planar_push_n8_t70", 2), ("planar_push5_n4_t36", 2)])
 def test_oracle_matches_golden(oracle_mod, name, task):
     g = np.load(GOLDEN / f"{name}.npz")
     N, T = g["actions"].shape[1], g["actions"].shape[0]
     seed = int(g["base_seed"]) if "base_seed" in g else 2025
-    b = oracle_mod.OracleBatch(task, N, seed, action_type=1 if task == 3 else None, max_episode_steps=25 if task == 2 else None)
+    five = name.startswith("planar_push5")  # the reference's default of 5 blocks
+    b = oracle_mod.OracleBatch(task, N, seed, action_type=1 if task == 3 else None, max_episode_steps=(14 if five else 25) if task == 2 else None,
+                               n_objects=5 if five else None, nthreads=4)
     r0 = b.reset()
     assert np.array_equal(r0["obs"], g["reset_obs"])
     for t in range(T):
