@@ -17,6 +17,10 @@
 
 struct mjs_handle {
   mjs_config cfg;
+  // render primitive list of the CURRENT state already built on this stream? (the visual configs render two cameras per
+  // control step; reset / step / rollout / set_state invalidate)
+  bool prims_valid = false;
+  void* prims_stream = nullptr;
   int state_dim, obs_dim, act_dim;
   double* state;     // [state_dim][N]
   uint8_t* flags;    // [N]
@@ -310,6 +314,7 @@ int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream) {
 int mjs_reset(mjs_handle* h, const uint8_t* mask_dev, const mjs_outputs* out, void* stream) {
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_reset: null handle");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->prims_valid = false;
   return launch<true>(h, make_params(h, nullptr, mask_dev, out), (hipStream_t)stream);
 }
 
@@ -317,6 +322,7 @@ int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, v
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_step: null handle");
   if (!actions_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_step: actions_dev is null");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->prims_valid = false;
   return launch<false>(h, make_params(h, actions_dev, nullptr, out), (hipStream_t)stream);
 }
 
@@ -324,6 +330,7 @@ int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_o
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_rollout: null handle");
   if (!actions_dev || T < 0) return fail(h, MJS_ERR_INVALID_ARG, "mjs_rollout: bad arguments");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->prims_valid = false;
   const size_t N = (size_t)h->cfg.num_envs;
   for (int32_t t = 0; t < T; t++) {
     mjs_outputs o;
@@ -386,20 +393,23 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
     if (raster) rend::robot_scene_raster_kernel<<<dim3((unsigned)((height + band_rows - 1) / band_rows), (unsigned)p.N), 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, band_rows);
     else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   };
+  const bool fresh = h->prims_valid && h->prims_stream == stream;  // same state, same stream: the list is still good
+  h->prims_valid = true;
+  h->prims_stream = stream;
   if (task == MJS_TASK_POINTMASS_REACH) {
     rend::pointmass_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(p);
   } else if (task == MJS_TASK_BUTTON_PUSH) {
-    rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
+    if (!fresh) rend::button_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, h->prims, h->cams, p.N);
     p.nprim = rend::BP_NPRIM;
     if (wrist) p.env_cams = h->cams;
     robot_scene();
   } else if (task == MJS_TASK_PLANAR_PUSH) {  // robot_planar_push.py:45,66: the FRONT_TILTED camera of Robot-Reach
     const int nslots = MJS_PP_OBJECT_SLOTS(h->cfg.n_objects);
-    rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects, nslots);
+    if (!fresh) rend::push_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N, h->cfg.n_objects, nslots);
     p.nprim = rend::ARM_NREC + 1 + nslots;
     robot_scene();
   } else {
-    rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);
+    if (!fresh) rend::reach_prims_kernel<<<grid_for(p.N), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->prims, p.N);
     p.nprim = rend::RR_NPRIM;
     robot_scene();
   }
@@ -432,6 +442,7 @@ int mjs_get_state(mjs_handle* h, double* state_dev, void* stream) {
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
   if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_set_state: null argument");
   HIP_TRY(h, hipSetDevice(h->cfg.device));
+  h->prims_valid = false;
   set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
