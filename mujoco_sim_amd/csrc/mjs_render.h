@@ -655,11 +655,12 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     const float rad = two ? bound_radius(pr[13]) : pr[17];
     const float aspect = (float)p.W / (float)p.H, tx = p.cam.tan_half * aspect, ty = p.cam.tan_half;
     float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    bool everything = false;
+    bool everything = false, behind = true;  // behind: the whole bound lies behind the camera plane (most of the arm for the wrist camera)
     for (int e = 0; e < (two ? 2 : 1); e++) {
       const F3 v = sub(f3(pr[1 + 3 * e], pr[2 + 3 * e], pr[3 + 3 * e]), eye);
       const float x = v.x * right[0] + v.y * right[1] + v.z * right[2], y = v.x * up[0] + v.y * up[1] + v.z * up[2];
       const float z = -(v.x * back[0] + v.y * back[1] + v.z * back[2]);
+      if (z + rad * 1.05f + 1.0e-3f > 0.0f) behind = false;
       if (!(z > rad * 1.05f + 1.0e-3f)) { everything = true; continue; }  // the bound reaches the camera plane
       const float den = z * z - rad * rad;
       const float sx = rad * sqrtf(x * x + den), sy = rad * sqrtf(y * y + den);
@@ -677,6 +678,7 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
       c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, p.W - 1); r1 = min(r1, p.H - 1);
     }
     r0 = max(r0, band0); r1 = min(r1, band1);  // this workgroup's band (possibly empty)
+    if (behind) r1 = r0 - 1;                   // nothing of it can be seen: empty rectangle
     bbox[4 * tid] = r0; bbox[4 * tid + 1] = r1; bbox[4 * tid + 2] = c0; bbox[4 * tid + 3] = c1;
   }
   __syncthreads();
