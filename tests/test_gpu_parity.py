@@ -904,9 +904,9 @@ def test_scene_camera_kernels_agree_byte_for_byte(task):
     b = m.HipVectorEnv(task, N, seed=77, kernel_variant=1)
     a.reset()
     b.reset()
-    for res in (32, 64):
-        ia, ib = a.render(res, res).cpu().numpy(), b.render(res, res).cpu().numpy()
-        assert np.array_equal(ia, ib), (task, res, int((ia != ib).sum()))
+    for hh, ww in ((32, 32), (64, 64), (48, 64), (40, 24)):  # square and non-square, all within the primitive-major kernel's 4096-pixel limit
+        ia, ib = a.render(hh, ww).cpu().numpy(), b.render(hh, ww).cpu().numpy()
+        assert np.array_equal(ia, ib), (task, hh, ww, int((ia != ib).sum()))
         assert ia.std() > 10
     a.close()
     b.close()
