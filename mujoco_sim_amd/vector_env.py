@@ -157,6 +157,8 @@ class HipVectorEnv:
             "ncon": torch.zeros(N, dtype=torch.int32, device=dev),
         }
         self._out = self._make_outputs(self._buf)
+        self._out_ref = C.byref(self._out)  # step_flat's hot path: no per-call ctypes object construction
+        self._mjs_step = self._lib.mjs_step
         # enabled observables: everything the kernel writes, except that Button-Push enables only the robot
         # observable matching its action type (robot_push_button.py:113-117)
         self.action_low, self.action_high = self.spec.action_low, self.spec.action_high
@@ -254,7 +256,11 @@ class HipVectorEnv:
 
     def step_flat(self, actions_f64: torch.Tensor):
         """Zero-overhead variant: float64 CUDA actions in, raw output buffers out (no copies)."""
-        nat.check(self._lib.mjs_step(self._h, C.c_void_p(actions_f64.data_ptr()), C.byref(self._out), self._stream()), self._h)
+        # argtypes are declared (c_void_p): plain ints convert without building ctypes objects
+        stream = _RAW_STREAM(self._dev_index) if _RAW_STREAM is not None else torch.cuda.current_stream(self.device).cuda_stream
+        rc = self._mjs_step(self._h, actions_f64.data_ptr(), self._out_ref, stream)
+        if rc != 0:
+            nat.check(rc, self._h)
         return self._buf
 
     def rollout(self, actions: torch.Tensor, keep: tuple = ("obs", "reward", "terminated", "truncated", "is_success", "step_type", "fault", "ncon", "discount")):
