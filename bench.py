@@ -194,6 +194,12 @@ def main():
             tf = flops * value / 1e12
             line["roofline"]["valu_fp64"] = {"flops_per_env_step": flops, "achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
                                              "simds_occupied_frac": min(1.0, 2 * (n_local / 64) / 1024)}
+            try:  # PMC view of this very launch shape (profiles/r01_reach_valu.json): VALU busy share of a wavefront's lifetime
+                v = json.load(open(ROOT / "profiles" / "r01_reach_valu.json"))
+                if v["envs"] == n_local:
+                    line["roofline"]["valu_fp64"]["valu_busy_frac_on_occupied_simds_pmc"] = v["valu_busy_frac_of_wave_lifetime"]
+            except Exception:  # noqa: BLE001
+                pass
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects)
         print(json.dumps(line))
