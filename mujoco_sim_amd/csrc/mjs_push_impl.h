@@ -328,15 +328,6 @@ MJS_DEV void convex_slot(const Geom& g1, const Geom& g2, ConvexHits& h, int k) {
   if (!mpr_penetration(g1, g2, depth, nn, pp_)) return;
   h.hit[k] = true; h.dist[k] = -depth; h.pos[k] = pp_; h.n[k] = nn;
 }
-MJS_DEV bool convex_penetrating(const Geom& g1, const Geom& g2) {  // an ACTIVE contact (dist < 0) between two convex geoms?
-  const V3 diff = sub_nc(g2.c, g1.c);
-  const double bound = rbound(g1) + rbound(g2);
-  if (dot_nc(diff, diff) > bound * bound) return false;
-  double depth;
-  V3 n, pos;
-  if (!mpr_penetration(g1, g2, depth, n, pos)) return false;
-  return -depth < 0.0;
-}
 #pragma clang fp contract(on)
 
 // all contacts of the scene in MuJoCo's pair order (geom ids: floor, arm capsules, EEF cylinder, blocks): floor-block i
@@ -375,17 +366,6 @@ constexpr double BLK_IXX = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[
 constexpr double BLK_IYY = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
 constexpr double BLK_IZZ = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1]) / 3;
 constexpr double BLK_INVW_TRAN = 1.0 / MJS_BLOCK_MASS, BLK_INVW_ROT = (1.0 / BLK_IXX + 1.0 / BLK_IYY + 1.0 / BLK_IZZ) / 3;
-MJS_DEV void block_mass_matrix(const M3& R, double (*M)[NV], int o) {  // writes the 6x6 block at offset o (both triangles)
-  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) M[o + i][o + j] = 0;
-  for (int k = 0; k < 3; k++) M[o + k][o + k] = m;
-  M[o + 3][o + 3] = BLK_IXX + m * g * g; M[o + 4][o + 4] = BLK_IYY + m * g * g; M[o + 5][o + 5] = BLK_IZZ;
-  // -m R C: column for w_x is -m g R.cy, for w_y is +m g R.cx, for w_z is 0
-  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
-  const double colx[3] = {cx.x, cx.y, cx.z}, coly[3] = {cy.x, cy.y, cy.z};
-  for (int k = 0; k < 3; k++) { M[o + k][o + 3] = M[o + 3][o + k] = colx[k]; M[o + k][o + 4] = M[o + 4][o + k] = coly[k]; }
-}
 MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
   const double m = MJS_BLOCK_MASS;
   const V3 c = v3(0, 0, MJS_BLOCK_GEOM_Z), grav = v3(0, 0, MJS_GRAVITY_Z);
@@ -394,33 +374,6 @@ MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
   const V3 Iw = v3(BLK_IXX * w.x, BLK_IYY * w.y, BLK_IZZ * w.z);
   const V3 ang = cross(w, Iw) + m * cross(c, wwc) - m * cross(c, rot_t(R, grav));
   f[0] = -lin.x; f[1] = -lin.y; f[2] = -lin.z; f[3] = -ang.x; f[4] = -ang.y; f[5] = -ang.z;
-}
-
-// dense symmetric positive definite solve helpers on [NV][NV] scratch arrays, n <= NV
-MJS_DEV bool chol_n(int n, double (*A)[NV]) {  // in place, lower triangle
-  for (int i = 0; i < n; i++)
-    for (int j = 0; j <= i; j++) {
-      double s = A[i][j];
-      for (int k = 0; k < j; k++) s -= A[i][k] * A[j][k];
-      if (i == j) {
-        if (s < MJS_MINVAL) return false;
-        A[i][i] = sqrt(s);
-      } else
-        A[i][j] = s / A[j][j];
-    }
-  return true;
-}
-MJS_DEV void chol_solve_n(int n, const double (*L)[NV], double* x) {
-  for (int i = 0; i < n; i++) {
-    double s = x[i];
-    for (int k = 0; k < i; k++) s -= L[i][k] * x[k];
-    x[i] = s / L[i][i];
-  }
-  for (int i = n - 1; i >= 0; i--) {
-    double s = x[i];
-    for (int k = i + 1; k < n; k++) s -= L[k][i] * x[k];
-    x[i] = s / L[i][i];
-  }
 }
 
 // Decoupled case (the common one): a block without an active arm-block or block-block contact. With its floor contacts
@@ -693,15 +646,6 @@ struct CoopLds {
 // to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
 extern __shared__ double pp_lds_raw[];
 MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
-MJS_DEV double jat(const CoopLds& sh, int r, int c) {  // J[r][c] of the dense matrix
-  if constexpr (!COMPACT) return sh.J[r][c];
-  else {
-    const int d0 = c - sh.cb[r][0], d1 = c - sh.cb[r][1];
-    const bool in0 = (unsigned)d0 < 6u, in1 = (unsigned)d1 < 6u;
-    const double v = sh.J[r][in0 ? d0 : in1 ? 6 + d1 : 0];
-    return (in0 || in1) ? v : 0.0;
-  }
-}
 // exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
 // cooperative solver, which runs after it
 struct QuadIn {
@@ -1164,30 +1108,6 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
     sh.bR[b][0] = Rb[b].cx.x; sh.bR[b][1] = Rb[b].cx.y; sh.bR[b][2] = Rb[b].cx.z;
     sh.bR[b][3] = Rb[b].cy.x; sh.bR[b][4] = Rb[b].cy.y; sh.bR[b][5] = Rb[b].cy.z;
     sh.bR[b][6] = Rb[b].cz.x; sh.bR[b][7] = Rb[b].cz.y; sh.bR[b][8] = Rb[b].cz.z;
-  }
-}
-// one frame row (F . translational or rotational Jacobian of (body b - body a)) of a published contact, all nv columns
-MJS_DEV void coop_frame_row(const CoopLds& sh, int c, V3 F, bool rotational, int nv, double* out) {
-  for (int d = 0; d < nv; d++) out[d] = 0;
-  const V3 pos = v3(sh.c_pos[c][0], sh.c_pos[c][1], sh.c_pos[c][2]);
-  for (int side = 0; side < 2; side++) {
-    const int body = side == 0 ? sh.c_ba[c] : sh.c_bb[c];
-    const double sg = side == 0 ? -1.0 : 1.0;
-    if (body == 1) {
-      for (int j = 0; j < NJ; j++) {
-        const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
-        const V3 col = rotational ? ax : cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
-        out[j] += sg * dot(F, col);
-      }
-    } else if (body >= 2) {
-      const int b = body - 2, o = NJ + 6 * b;
-      const V3 rvec = pos - v3(sh.bp[b][0], sh.bp[b][1], sh.bp[b][2]);
-      for (int d = 0; d < 3; d++) {
-        const V3 axs = v3(sh.bR[b][3 * d], sh.bR[b][3 * d + 1], sh.bR[b][3 * d + 2]);
-        if (!rotational) out[o + d] += sg * (d == 0 ? F.x : d == 1 ? F.y : F.z);
-        out[o + 3 + d] += sg * dot(F, rotational ? axs : cross(axs, rvec));
-      }
-    }
   }
 }
 // all lanes: limit rows + pyramid rows (6 per active contact, condim 4) in the oracle's order
