@@ -618,6 +618,37 @@ def test_planar_push_controlled_scenarios(oracle_mod):
     assert q2[5, 6] - qp[5, 6] > 0.03 and q2[6, 13] - qp[6, 13] > 0.01  # the pushes really moved the blocks
 
 
+def test_planar_push_full_size_shard_invariance_and_determinism():
+    """BASELINE config 4 size (4096 envs per GPU): env i of one 4096-env handle is bit-identical to env i of two
+    2048-env handles with env_index_offset 0 / 2048 (wavefront placement, helper lanes, cooperative solves and quad
+    solves of OTHER envs must not leak into an env), and a second identical run repeats the first bit for bit."""
+    import mujoco_sim_amd as m
+
+    N, T = 4096, 5
+    def run(parts):
+        envs = [m.HipVectorEnv("robot_planar_push", N // parts, seed=99, env_index_offset=k * (N // parts), max_episode_steps=3) for k in range(parts)]
+        for e in envs:
+            e.reset()
+        outs = []
+        for t in range(T):
+            obs = torch.cat([e.flat_obs for e in envs])
+            a = obs[:, :2] + torch.clamp(obs[:, 5:7] - obs[:, :2], -0.02, 0.02)  # push block 0; step limit 3 => resets inside
+            for k, e in enumerate(envs):
+                e.step_flat(a[k * (N // parts):(k + 1) * (N // parts)].contiguous())
+            outs.append({key: torch.cat([e._buf[key] for e in envs]).cpu().numpy().copy() for key in ("obs", "reward", "step_type", "ncon", "fault")})
+        for e in envs:
+            e.close()
+        return outs
+
+    whole, again, halves = run(1), run(1), run(2)
+    for t in range(T):
+        for key in whole[t]:
+            assert np.array_equal(whole[t][key], again[t][key]), ("determinism", key, t)
+            assert np.array_equal(whole[t][key], halves[t][key]), ("shards", key, t)
+    assert (whole[-1]["ncon"] > 8).any() and (np.concatenate([w["step_type"] for w in whole]) == 2).any()
+    assert not (np.concatenate([w["fault"] for w in whole]) & 1).any()
+
+
 def test_planar_push_block_train_couples_all_bodies(oracle_mod):
     """5-slot kernel, largest coupled sub-system: the EEF pushes a train of 5 blocks that overlap their neighbours by
     0.05 mm (identical hand-set states): the four block-block contacts are active from the first substep (30 dofs), and
