@@ -7,14 +7,21 @@ from here.
 from __future__ import annotations
 
 import ctypes as C
+import hashlib
 import os
+import re
 import subprocess
 from pathlib import Path
 
 _PKG = Path(__file__).resolve().parent
 _ROOT = _PKG.parent
 LIB_PATH = Path(os.environ["MJS_LIB"]) if os.environ.get("MJS_LIB") else _PKG / "lib" / "libmjsim.so"  # MJS_LIB: diagnostic builds
-_SOURCES = [*sorted((_PKG / "csrc").glob("*")), _ROOT / "include" / "mjsim.h", _ROOT / "include" / "mjs_scene_spec.h"]
+
+
+def _sources() -> list[Path]:
+    """Every file the library is compiled from: csrc/*.{h,hip} and include/*.h."""
+    return [*sorted(p for p in (_PKG / "csrc").glob("*") if p.suffix in (".h", ".hip")), *sorted((_ROOT / "include").glob("*.h"))]
+
 
 TASK_POINTMASS_REACH, TASK_ROBOT_REACH, TASK_PLANAR_PUSH, TASK_BUTTON_PUSH = 0, 1, 2, 3
 ACTION_ABS_JOINT, ACTION_ABS_EEF = 0, 1
@@ -50,15 +57,36 @@ class MjsError(RuntimeError):
     pass
 
 
+def source_hash() -> str:
+    """sha256 over the names and bytes of every file the library is compiled from (csrc/ + the two headers). The build
+    embeds it (``-DMJS_SOURCE_HASH``) and ``mjs_version()`` reports it, so a binary that does not belong to the sources
+    next to it is detected whatever the file times say (a copied tree, a git checkout, the gpurun snapshot)."""
+    h = hashlib.sha256()
+    for s in _sources():
+        h.update(s.name.encode() + b"\0" + s.read_bytes() + b"\0")
+    return h.hexdigest()[:16]
+
+
+def built_hash(path: Path | None = None) -> str | None:
+    """The source hash embedded in an existing library (None if the file is absent or carries none)."""
+    path = Path(path or LIB_PATH)
+    if not path.exists():
+        return None
+    m = re.search(rb"mjsim-hip [^\0]* src=([0-9a-f]{16}|unhashed)", path.read_bytes())
+    return m.group(1).decode() if m else None
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile mujoco_sim_amd/csrc/mjsim.hip for gfx950 into mujoco_sim_amd/lib/libmjsim.so."""
-    if not force and LIB_PATH.exists() and all(s.stat().st_mtime <= LIB_PATH.stat().st_mtime for s in _SOURCES):
+    """Compile mujoco_sim_amd/csrc/mjsim.hip for gfx950 into mujoco_sim_amd/lib/libmjsim.so (skipped when the existing
+    library already embeds the hash of the current sources)."""
+    want = source_hash()
+    if not force and built_hash() == want:
         return LIB_PATH
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # max-ilp: the kernels run one wavefront per SIMD, so schedule for ILP, not occupancy (+2% measured)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp",
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", f'-DMJS_SOURCE_HASH="{want}"',
            "-o", str(LIB_PATH), str(_PKG / "csrc" / "mjsim.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
@@ -72,17 +100,22 @@ _lib = None
 
 
 def lib() -> C.CDLL:
-    """Load libmjsim.so (building it first if the sources are newer). Fails loudly."""
+    """Load libmjsim.so. On the first load the hash embedded in the binary is compared with the hash of the sources
+    next to it: a missing or stale library is rebuilt, and if that is impossible the load FAILS (no stale binary is
+    ever used silently, and there is no CPU fallback). MJS_LIB (diagnostic builds) bypasses the check."""
     global _lib
     if _lib is not None:
         return _lib
-    if not LIB_PATH.exists():
+    if not os.environ.get("MJS_LIB") and built_hash() != source_hash():
         try:
             build()
         except Exception as e:  # noqa: BLE001
-            raise MjsError(f"libmjsim.so is missing and could not be built ({e}); there is no CPU fallback") from e
+            raise MjsError(f"libmjsim.so is missing or older than its sources (embedded {built_hash()}, sources "
+                           f"{source_hash()}) and could not be rebuilt ({e}); there is no CPU fallback") from e
     L = C.CDLL(str(LIB_PATH))
     L.mjs_version.restype = C.c_char_p
+    if not os.environ.get("MJS_LIB") and f"src={source_hash()}".encode() not in L.mjs_version():
+        raise MjsError(f"loaded {LIB_PATH} reports {L.mjs_version()!r}, sources hash to {source_hash()}")
     for name in ("mjs_obs_dim", "mjs_action_dim", "mjs_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps"):
         getattr(L, name).argtypes = [C.c_int]
         getattr(L, name).restype = C.c_int

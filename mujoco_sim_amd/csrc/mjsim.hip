@@ -157,7 +157,10 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
 
 extern "C" {
 
-const char* mjs_version(void) { return "mjsim-hip 0.1 (gfx950, abi 1)"; }
+#ifndef MJS_SOURCE_HASH
+#define MJS_SOURCE_HASH "unhashed"  // the in-tree build (mujoco_sim_amd/_native.py) passes -DMJS_SOURCE_HASH=<sha256 of csrc/ + include/>
+#endif
+const char* mjs_version(void) { return "mjsim-hip 0.2 (gfx950, abi 1) src=" MJS_SOURCE_HASH; }
 
 int mjs_obs_dim(int task) {
   return task == MJS_TASK_POINTMASS_REACH ? pm::OBS_DIM : task == MJS_TASK_ROBOT_REACH ? rr::OBS_DIM : task == MJS_TASK_BUTTON_PUSH ? bp::OBS_DIM : task == MJS_TASK_PLANAR_PUSH ? pp::OBS_DIM : -1;

@@ -26,6 +26,23 @@ def test_library_exports_every_declared_symbol(native):
         assert hasattr(L, name), f"libmjsim.so does not export {name}"
 
 
+def test_loaded_library_matches_its_sources(native, tmp_path, monkeypatch):
+    """Stale-binary guard: the library embeds the sha256 of csrc/ + include/ it was compiled from; the loader compares
+    it with the sources next to it on first load, rebuilds on mismatch and raises when it cannot."""
+    L = native.lib()
+    assert f"src={native.source_hash()}".encode() in L.mjs_version()
+    assert native.built_hash() == native.source_hash()
+    # a binary whose embedded hash differs from the sources is never loaded silently: with no compiler, lib() raises
+    stale = tmp_path / "libmjsim.so"
+    stale.write_bytes(native.LIB_PATH.read_bytes().replace(native.source_hash().encode(), b"0123456789abcdef"))
+    assert native.built_hash(stale) == "0123456789abcdef"
+    monkeypatch.setattr(native, "LIB_PATH", stale)
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setenv("HIPCC", "/nonexistent/hipcc")
+    with pytest.raises(native.MjsError, match="older than its sources"):
+        native.lib()
+
+
 def test_static_queries(native):
     L = native.lib()
     assert L.mjs_version().startswith(b"mjsim-hip")
