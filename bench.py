@@ -3,7 +3,9 @@
 4096 envs per MI355X, joint-space obs). One "step" = one control step of all envs of this rank
 (IK + 20 physics substeps + obs/reward/termination + auto-reset), one kernel launch.
 
-  python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or run
+      plainly, in which case this process spawns the N rank processes itself and never touches the GPU.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     : algorithmic HBM bytes per launch / HIP-event kernel time vs 8 TB/s
@@ -54,6 +56,8 @@ def parse():
     ap.add_argument("--visual", type=int, default=0, metavar="RES",
                     help="also render the task's camera(s) at RESxRES every step (BASELINE config 5: Button-Push, 64)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="time box of the CPU oracle sample")
+    ap.add_argument("--stub", action="store_true",
+                    help="launcher self-test: gloo on CPU with a no-physics stand-in env (tests/test_host_logic.py); never a measurement")
     return ap.parse_args()
 
 
@@ -109,22 +113,100 @@ def cpu_baseline(task, n_envs, seconds, n_objects=2):
             "sample": f"{n_envs} envs x {steps} control steps ({dt:.1f} s), oracle/ C restatement, OpenMP over envs"}
 
 
+class _StubVectorEnv:
+    """Launcher self-test stand-in (``--stub``, CPU, gloo): the same surface bench.py drives, NO physics and no GPU.
+    Its only purpose is to let a GPU-less test exercise the rank fan-out, the barrier / max-over-ranks timing and the
+    rollout gather; the JSON line it produces is marked ``"stub": true`` and is never a measurement."""
+
+    def __init__(self, n_local, rank):
+        self.num_envs, self.obs_dim, self.algorithmic_bytes_per_env_step, self.rank = n_local, 12, 379, rank
+        self._buf = {"obs": torch.zeros(n_local, 12, dtype=torch.float64), "fault": torch.zeros(n_local, dtype=torch.uint8)}
+
+    def reset(self):
+        self._buf["obs"].zero_()
+
+    def step_flat(self, a):
+        self._buf["obs"][:, 0] += 1.0
+
+    def rollout(self, a, keep=("obs",)):
+        T = a.shape[0]
+        o = torch.zeros(T, self.num_envs, 12, dtype=torch.float64)
+        o[..., 0] = self.rank
+        o[..., 1] = torch.arange(self.num_envs, dtype=torch.float64)
+        return {"obs": o}
+
+    def close(self):
+        pass
+
+
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` outside torchrun: fan out to N fresh rank processes (the counterpart of the
+    reference's ``SubprocVecEnv([create_env(rank=i, seed=...) ...])``, scripts/sb3/reach_sac.py:93-96, one env shard per
+    process with per-rank seeds ``seed + rank``-style global seeding). THIS process never touches the GPU (no HIP call,
+    no ``torch.cuda`` query): it only spawns ``python bench.py ...`` children with RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT set, relays rank 0's JSON line and returns non-zero if any rank fails."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, rc = "", 0
+    deadline = time.time() + float(os.environ.get("MJS_BENCH_LAUNCH_TIMEOUT", "1500"))
+    try:
+        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
+        for p in procs:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+    except subprocess.TimeoutExpired:
+        rc = 124
+    for r, p in enumerate(procs):
+        if p.poll() is None:  # a rank outlived a failed / timed-out sibling: stop exactly that child
+            p.kill()
+            p.wait()
+        if p.returncode != 0:
+            print(f"bench.py: rank {r} exited with code {p.returncode}", file=sys.stderr)
+            rc = rc or (p.returncode if p.returncode > 0 else 1)
+    lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
+    if rc == 0 and len(lines) != 1:
+        print(f"bench.py: rank 0 printed {len(lines)} JSON lines", file=sys.stderr)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
     from mujoco_sim_amd import distributed as D
 
-    rank, local_rank, world = D.init_process_group()
+    rank, local_rank, world = D.init_process_group(backend="gloo" if args.stub else None)
     if world != args.gpus:
-        if rank == 0:
-            print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
-    device = torch.device(f"cuda:{local_rank}")
-    torch.cuda.set_device(device)
-    import mujoco_sim_amd as m
-
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     n_local = args.envs_per_gpu
     n_global = n_local * world
-    extra = {"n_objects": args.n_objects} if args.task == "robot_planar_push" else {}
-    venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant, **extra)
+    if args.stub:
+        device = torch.device("cpu")
+        venv = _StubVectorEnv(n_local, rank)
+        sync = lambda: None  # noqa: E731
+        substeps = 20
+    else:
+        device = torch.device(f"cuda:{local_rank}")
+        torch.cuda.set_device(device)
+        import mujoco_sim_amd as m
+
+        extra = {"n_objects": args.n_objects} if args.task == "robot_planar_push" else {}
+        # global seeds: env i of the whole job <- RandomState(2025 + i) whatever the rank count (reach_sac.py:84 seeds sub-env rank with seed + rank)
+        venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant, **extra)
+        sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
+        substeps = venv._lib.mjs_substeps(venv.spec.task_id)
     venv.reset()
     chunk = 64  # distinct action slabs resident in HBM, cycled
     acts = make_actions(args.task, chunk, n_local, device, 12345 + rank)
@@ -139,11 +221,11 @@ def main():
     for i in range(args.warmup):
         one_step(i)
     D.barrier()
-    torch.cuda.synchronize(device)
+    sync()
     t0 = time.perf_counter()
     for i in range(args.steps):
         one_step(i)
-    torch.cuda.synchronize(device)
+    sync()
     D.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = D.max_over_ranks(elapsed, device=device)
@@ -151,17 +233,44 @@ def main():
     # per-launch kernel time with HIP events on the launch stream (torch's current stream). Each event pair brackets a
     # short train of back-to-back launches so that the ~4 us cost of the event records themselves is amortised and the
     # figure is the kernel's own duration (it then agrees with rocprofv3's per-kernel average, profiles/).
-    train = 10 if not cams else 1
-    n_ev = min(40, max(4, args.steps // train))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
-    for g, (a, b) in enumerate(evs):
-        a.record()
-        for k in range(train):
-            venv.step_flat(acts[(g * train + k) % chunk])
-        b.record()
-    torch.cuda.synchronize(device)
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) / train
+    if args.stub:
+        kernel_ms = elapsed / args.steps * 1e3
+    else:
+        train = 10 if not cams else 1
+        n_ev = min(40, max(4, args.steps // train))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_ev)]
+        for g, (a, b) in enumerate(evs):
+            a.record()
+            for k in range(train):
+                venv.step_flat(acts[(g * train + k) % chunk])
+            b.record()
+        torch.cuda.synchronize(device)
+        kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) / train
     faults = int(venv._buf["fault"].max().item())
+
+    # N > 1: the one collective of the design — all-gather of a rollout block once per 64-step chunk (RCCL over xGMI;
+    # gloo in the stub) — outside the timed step region and reported on its own; every rank checks that its own shard
+    # came back bit-identical at its global position.
+    gather = None
+    if world > 1:
+        block = venv.rollout(acts, keep=("obs",))["obs"]  # [64, n_local, obs_dim]
+        full = D.gather_rollout(block)
+        ok = tuple(full.shape) == (chunk, n_global, block.shape[2]) and bool(torch.equal(full[:, rank * n_local:(rank + 1) * n_local], block))
+        D.barrier()
+        sync()
+        tg = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            full = D.gather_rollout(block)
+        sync()
+        D.barrier()
+        tg = D.max_over_ranks((time.perf_counter() - tg) / reps, device=device)
+        ok = D.max_over_ranks(0.0 if ok else 1.0, device=device) == 0.0
+        nbytes = block.numel() * block.element_size()
+        gather = {"chunk_steps": chunk, "bytes_per_rank": nbytes, "ms_per_chunk": tg * 1e3, "ms_per_step_amortised": tg * 1e3 / chunk,
+                  "recv_GBps_per_rank": nbytes * (world - 1) / tg / 1e9, "backend": torch.distributed.get_backend(), "shards_bit_identical": ok}
+        if not ok:
+            raise SystemExit("bench.py: gathered rollout block does not contain this rank's shard at its global position")
 
     if rank == 0:
         env_steps = args.steps * n_global
@@ -176,16 +285,21 @@ def main():
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{args.task}: {n_local} envs per GPU, {venv._lib.mjs_substeps(venv.spec.task_id)} substeps/step, "
+            "config": {"workload": f"{args.task}: {n_local} envs per GPU, {substeps} substeps/step, "
                                    f"state obs, {'joint targets q_home +- U(0.2)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
                                    + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.task == "robot_planar_push" and args.n_objects != 2) else measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }
-        if args.task == "robot_reach":
+        if args.stub:
+            line["stub"] = True
+            line["data"] = "STUB: launcher self-test on CPU, no physics, not a measurement"
+        if gather is not None:
+            line["rollout_gather"] = gather
+        if args.task == "robot_reach" and not args.stub:
             # informational: the bound that actually applies. FP64 operation count per env-step:
             # 20 substeps x (generated M + bias code 725 ops + servo/actuators/U D U^T/inverse/integration ~330) + IK ~3000
             # + FK/observables ~500; peak = 1024 SIMDs x 16 FP64 FMA lanes x 2 x ~2.4 GHz (public spec 78.6 TFLOP/s;
@@ -200,7 +314,7 @@ def main():
                     line["roofline"]["valu_fp64"]["valu_busy_frac_on_occupied_simds_pmc"] = v["valu_busy_frac_of_wave_lifetime"]
             except Exception:  # noqa: BLE001
                 pass
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not args.stub:
             line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects)
         print(json.dumps(line))
     venv.close()

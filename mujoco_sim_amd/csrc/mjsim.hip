@@ -50,6 +50,23 @@ int hip_fail(mjs_handle* h, hipError_t e, const char* what) {
     if (e_ != hipSuccess) return hip_fail(h, e_, #expr);   \
   } while (0)
 
+// Select the handle's device for the duration of one ABI call and restore the caller's current device afterwards
+// (torch's notion of the current device must not change behind its back). Same device: one hipGetDevice, no switch.
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+    else prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 double default_time_limit(int task) {
   if (task == MJS_TASK_POINTMASS_REACH) return MJS_PM_MAX_CONTROL_STEPS * MJS_PM_CONTROL_DT;  // mujoco_sim/__init__.py:21,28
   if (task == MJS_TASK_BUTTON_PUSH) return MJS_BP_MAX_CONTROL_STEPS * MJS_RR_CONTROL_DT;      // mujoco_sim/__init__.py:45-49
@@ -222,7 +239,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   h->act_dim = mjs_action_dim_for(cfg->task, cfg->action_type);
   h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr; h->cams = nullptr;
   const size_t N = (size_t)cfg->num_envs;
-  hipError_t e = hipSetDevice(cfg->device);
+  DeviceGuard dev_(cfg->device);
+  hipError_t e = dev_.err;
   if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) {
     // > 64 KB of dynamic LDS per workgroup is an opt-in (gfx950 has 160 KB per CU)
     static_assert(sizeof(pp5::CoopLds) * pp5::WAVES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
@@ -307,7 +325,8 @@ void mjs_destroy(mjs_handle* h) {
 
 int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream) {
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_seed: null handle");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   seed_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(DevRng{h->rng_mt, h->rng_pos, h->cfg.num_envs}, base_seed,
                                                                            h->cfg.env_index_offset);
   HIP_TRY(h, hipGetLastError());
@@ -316,7 +335,8 @@ int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream) {
 
 int mjs_reset(mjs_handle* h, const uint8_t* mask_dev, const mjs_outputs* out, void* stream) {
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_reset: null handle");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   h->prims_valid = false;
   return launch<true>(h, make_params(h, nullptr, mask_dev, out), (hipStream_t)stream);
 }
@@ -324,7 +344,8 @@ int mjs_reset(mjs_handle* h, const uint8_t* mask_dev, const mjs_outputs* out, vo
 int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, void* stream) {
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_step: null handle");
   if (!actions_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_step: actions_dev is null");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   h->prims_valid = false;
   return launch<false>(h, make_params(h, actions_dev, nullptr, out), (hipStream_t)stream);
 }
@@ -332,7 +353,8 @@ int mjs_step(mjs_handle* h, const double* actions_dev, const mjs_outputs* out, v
 int mjs_rollout(mjs_handle* h, const double* actions_dev, int32_t T, const mjs_outputs* out, void* stream) {
   if (!h) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_rollout: null handle");
   if (!actions_dev || T < 0) return fail(h, MJS_ERR_INVALID_ARG, "mjs_rollout: bad arguments");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   h->prims_valid = false;
   const size_t N = (size_t)h->cfg.num_envs;
   for (int32_t t = 0; t < T; t++) {
@@ -363,7 +385,8 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   const bool wrist = camera == MJS_CAMERA_WRIST;
   if ((camera != MJS_CAMERA_SCENE && !(wrist && task == MJS_TASK_BUTTON_PUSH)) || height <= 0 || width <= 0)
     return fail(h, MJS_ERR_INVALID_ARG, "mjs_render: bad camera or size");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   rend::RenderParams p;
   p.N = h->cfg.num_envs; p.H = height; p.W = width; p.state = h->state; p.out = rgb_dev;
   p.env_cams = nullptr; p.nprim = 0;
@@ -436,7 +459,8 @@ int mjs_ur5e_tcp_to_joints(const double* tcp_pos_dev, const double* guess_dev, d
 
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream) {
   if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_get_state: null argument");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   get_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
@@ -444,7 +468,8 @@ int mjs_get_state(mjs_handle* h, double* state_dev, void* stream) {
 
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
   if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_set_state: null argument");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   h->prims_valid = false;
   set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
   HIP_TRY(h, hipGetLastError());
@@ -453,7 +478,8 @@ int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
 
 int mjs_get_rng_state(mjs_handle* h, uint32_t* mt_dev, int32_t* pos_dev, void* stream) {
   if (!h || !mt_dev || !pos_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_get_rng_state: null argument");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   const size_t N = (size_t)h->cfg.num_envs;
   HIP_TRY(h, hipMemcpyAsync(mt_dev, h->rng_mt, sizeof(uint32_t) * 624 * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(h, hipMemcpyAsync(pos_dev, h->rng_pos, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -462,7 +488,8 @@ int mjs_get_rng_state(mjs_handle* h, uint32_t* mt_dev, int32_t* pos_dev, void* s
 
 int mjs_set_rng_state(mjs_handle* h, const uint32_t* mt_dev, const int32_t* pos_dev, void* stream) {
   if (!h || !mt_dev || !pos_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_set_rng_state: null argument");
-  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  DeviceGuard dev_(h->cfg.device);
+  HIP_TRY(h, dev_.err);
   const size_t N = (size_t)h->cfg.num_envs;
   HIP_TRY(h, hipMemcpyAsync(h->rng_mt, mt_dev, sizeof(uint32_t) * 624 * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(h, hipMemcpyAsync(h->rng_pos, pos_dev, sizeof(int32_t) * N, hipMemcpyDeviceToDevice, (hipStream_t)stream));

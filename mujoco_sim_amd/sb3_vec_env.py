@@ -50,8 +50,14 @@ class HipSB3VecEnv(_Base):
 
     # ------------------------------------------------------------------ helpers
     def _obs_numpy(self, flat: torch.Tensor):
-        host = flat.cpu().numpy()
-        return OrderedDict((k, host[:, s:s + n].copy()) for k, s, n in self.venv._state_layout)
+        # the observation dict the spaces advertise: state keys, or (VISUAL_OBS) proprioception + rendered camera image(s)
+        return OrderedDict((k, v.cpu().numpy().copy()) for k, v in self.venv._obs_dict(flat).items())
+
+    def _terminal_obs_numpy(self, term_obs_host, i):
+        keys = self.venv._visual_keys if self.venv._img is not None else None
+        layout = [e for e in self.venv.spec.obs_layout if e[0] in keys] if keys is not None else self.venv._state_layout
+        # (the cameras show the post-reset state after a same-step reset: the terminal frame is not re-rendered)
+        return OrderedDict((k, term_obs_host[i, s:s + n].copy()) for k, s, n in layout)
 
     # ---------------------------------------------------------------- VecEnv API
     def seed(self, seed: int | None = None):
@@ -83,7 +89,7 @@ class HipSB3VecEnv(_Base):
         if dones.any():
             term_obs = b["terminal_obs"].cpu().numpy()
             for i in np.nonzero(dones)[0]:
-                infos[i]["terminal_observation"] = OrderedDict((k, term_obs[i, s:s + n].copy()) for k, s, n in self.venv._state_layout)
+                infos[i]["terminal_observation"] = self._terminal_obs_numpy(term_obs, i)
                 infos[i]["TimeLimit.truncated"] = bool(truncated[i] and not terminated[i])
                 infos[i]["episode"] = {"r": float(self._ep_return[i]), "l": int(self._ep_length[i])}  # Monitor's keys
                 self._ep_return[i] = 0

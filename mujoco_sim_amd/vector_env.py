@@ -123,11 +123,12 @@ class HipVectorEnv:
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise nat.MjsError("HipVectorEnv needs a HIP device (torch device 'cuda:N'); there is no CPU path")
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", self._dev_index)  # explicit ordinal: buffers, kernel launches and streams all name the same GPU
         self.num_envs = int(num_envs)
         self.autoreset = autoreset
         self.env_index_offset = int(env_index_offset)
         self._lib = nat.lib()
-        cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self.device.index or 0,
+        cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self._dev_index,
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
                             time_limit=float(time_limit) if time_limit is not None else -1.0,
@@ -246,13 +247,21 @@ class HipVectorEnv:
         nat.check(self._lib.mjs_reset(self._h, _as_uint8_ptr(m), C.byref(self._out), self._stream()), self._h)
         return self._obs_dict(self._buf["obs"]), {}
 
-    def step(self, actions):
+    def step(self, actions, copy: bool = False):
+        """One control step of all envs. The returned tensors are VIEWS of the handle's persistent output buffers (the
+        next ``step`` / ``reset`` overwrites them): a collector that keeps them across steps must pass ``copy=True`` (or
+        clone what it keeps); ``step_flat`` is the zero-copy path."""
         a = torch.as_tensor(actions, device=self.device).to(torch.float64).contiguous()
         if a.shape != (self.num_envs, self.action_dim):
             raise AssertionError(f"actions must have shape {(self.num_envs, self.action_dim)}, got {tuple(a.shape)}")  # cf. point_reach.py:158
         nat.check(self._lib.mjs_step(self._h, C.c_void_p(a.data_ptr()), C.byref(self._out), self._stream()), self._h)
         b = self._buf
-        return self._obs_dict(b["obs"]), b["reward"], b["terminated"].bool(), b["truncated"].bool(), self._info(b)
+        obs, reward, info = self._obs_dict(b["obs"]), b["reward"], self._info(b)
+        if copy:
+            obs = OrderedDict((k, v.clone()) for k, v in obs.items())
+            reward = reward.clone()
+            info = {k: (OrderedDict((kk, vv.clone()) for kk, vv in v.items()) if isinstance(v, dict) else v.clone()) for k, v in info.items()}
+        return obs, reward, b["terminated"].bool(), b["truncated"].bool(), info
 
     def step_flat(self, actions_f64: torch.Tensor):
         """Zero-overhead variant: float64 CUDA actions in, raw output buffers out (no copies)."""

@@ -137,6 +137,36 @@ def test_gloo_world2_gather_matches_single_process():
     assert tmax == 2.0
 
 
+def test_bench_gpus2_launches_its_own_ranks():
+    """`python bench.py --gpus 2` (the driver's command, no torchrun around it) must fan out to 2 rank processes itself,
+    the parent never touching the GPU (the reference's SubprocVecEnv fan-out, scripts/sb3/reach_sac.py:93-96). Run here
+    with the --stub stand-in (gloo, CPU, no physics): the launcher, barrier / max-over-ranks timing and the per-chunk
+    rollout gather are the real code; the line is marked as a stub."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "5", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["envs_total"] == 8192 and line["config"]["envs_per_gpu"] == 4096
+    assert line["steps"] == 5 and line["warmup"] == 1 and line["scaling"] == "weak" and line["stub"] is True
+    g = line["rollout_gather"]
+    assert g["chunk_steps"] == 64 and g["shards_bit_identical"] is True and g["backend"] == "gloo"
+    assert g["bytes_per_rank"] == 64 * 4096 * 12 * 8
+    # a failing rank makes the launcher fail: without --stub the ranks need a GPU, and this host has none
+    import torch
+
+    if not torch.cuda.is_available():
+        res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "0"],
+                             capture_output=True, text=True, timeout=300, env=env)
+        assert res.returncode != 0 and "rank" in res.stderr
+
+
 def test_lerobot_recorder_schema_and_round_trip(tmp_path):
     """Recorder with the reference collector's conventions (scripts/demonstration_collection.py:39-167): feature names,
     '/' -> '_' key mapping, observation.images.* for image keys, observation.state = concatenated state keys; LeRobot
