@@ -640,14 +640,91 @@ MJS_DEV Aff dh_cs(double ct, double st, double d, double a, double ca, double sa
 // Intermediates are shared per theta1 and per (theta1, theta5) exactly as in the nested loops of
 // the oracle; known sines/cosines are reused (sin(acos c) = sqrt(1-c^2), cos/sin(atan2(y,x)) =
 // (x,y)/hypot, atan2(-y,x) = -atan2(y,x)) and theta4 = theta234 - theta2 - theta3.
-MJS_DEV bool ik_closest(const Aff& T, const double* g, double* q_out) {
+// One theta1 branch (s1) of the closed form: its up to four candidates (s5, s3), the (s5p, s3p) pair first, each
+// abandoned as soon as the squared distance of the joints computed so far exceeds `best` (in/out, with best_idx and
+// q_out). ik_closest visits the guess's own branch first; the four-wavefront kernel gives each branch to its own
+// wavefront (best = INFINITY there: nothing is known about the other branch) and merges by (distance, idx).
+MJS_DEV void ik_branch(const Aff& T, const double* g, double psi, double phi, int s1, int s5p, int s3p, double& best, int& best_idx, double* q_out) {
   const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
+  // R60 = R06^T: X60 = (r0, r1), Y60 = (r3, r4) read column-wise from T
+  const double X60x = T.r[0], X60y = T.r[1], Y60x = T.r[3], Y60y = T.r[4];
+  double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
+  double q0 = wrap_pi(th1);
+  const double p0 = joint_dist2(q0, g[0]);
+  if (p0 > best) return;
+  double sn1, c1;
+  sincos(th1, &sn1, &c1);
+  bool ok5 = true;
+  const double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
+  if (!ok5) return;
+  const double ac5 = acos(c5), root5 = sqrt(fmax(0.0, 1.0 - c5 * c5));
+  const Aff T01i_T = aff_mul(aff_inv(dh_cs(c1, sn1, d1, 0, 0, 1)), T);
+#pragma unroll 1
+  for (int b = 0; b < 2; b++) {
+    const int s5 = s5p ^ b;
+    const double sg5 = s5 ? -1.0 : 1.0;
+    double q4 = wrap_pi(sg5 * ac5);
+    const double p4 = joint_dist2(q4, g[4]);
+    if (p0 + p4 > best) continue;
+    const double sn5 = sg5 * root5;
+    double th6 = 0, c6 = 1.0, sn6 = 0.0;
+    if (!(fabs(sn5) < 1e-12)) {
+      double y6 = (-X60y * sn1 + Y60y * c1) / sn5, x6 = (X60x * sn1 - Y60x * c1) / sn5;
+      th6 = atan2(y6, x6);
+      double h6 = sqrt(x6 * x6 + y6 * y6);
+      if (h6 > 0) { c6 = x6 / h6; sn6 = y6 / h6; }
+    }
+    double q5 = wrap_pi(th6);
+    const double p5 = joint_dist2(q5, g[5]);
+    if (p0 + p4 + p5 > best) continue;
+    const Aff T14 = aff_mul(T01i_T, aff_inv(aff_mul(dh_cs(c5, sn5, d5, 0, 0, -1), dh_cs(c6, sn6, d6, 0, 1, 0))));
+    const double px = T14.t[0], py = T14.t[1], r2 = px * px + py * py;
+    bool ok3 = true;
+    const double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
+    if (!ok3) continue;
+    const double ac3 = acos(c3), root3 = sqrt(fmax(0.0, 1.0 - c3 * c3));
+    const double base2 = atan2(py, px), at3 = atan2(a3 * root3, a2 + a3 * c3), th234 = atan2(T14.r[3], T14.r[0]);
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const int s3 = s3p ^ c;
+      const double sg3 = s3 ? -1.0 : 1.0;
+      const double th3 = sg3 * ac3;
+      double q2 = wrap_pi(th3);
+      const double p2 = joint_dist2(q2, g[2]);
+      if (p0 + p4 + p5 + p2 > best) continue;
+      const double th2 = base2 - sg3 * at3;
+      const double th4 = th234 - th2 - th3;  // rotation of frame 1->4 is Rz(th2+th3+th4)
+      double q1 = wrap_pi(th2), q3 = wrap_pi(th4);
+      if (!(isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3) && isfinite(q4) && isfinite(q5))) continue;
+      // same summation order as the exhaustive evaluation: joints 0..5
+      double dist = p0;
+      dist += joint_dist2(q1, g[1]);
+      dist += p2;
+      dist += joint_dist2(q3, g[3]);
+      dist += p4;
+      dist += p5;
+      const int idx = (s1 << 2) | (s5 << 1) | s3;
+      if (dist < best || (dist == best && idx < best_idx)) {
+        best = dist;
+        best_idx = idx;
+        q_out[0] = q0; q_out[1] = q1; q_out[2] = q2; q_out[3] = q3; q_out[4] = q4; q_out[5] = q5;
+      }
+    }
+  }
+}
+// what every branch shares: the wrist-centre angles; false when the pose is out of reach for every branch
+MJS_DEV bool ik_setup(const Aff& T, double& psi, double& phi) {
+  const double d4 = MJS_UR_DH_D4, d6 = MJS_UR_DH_D6;
   double p05x = T.t[0] - d6 * T.r[2], p05y = T.t[1] - d6 * T.r[5];
   double rxy = sqrt(p05x * p05x + p05y * p05y);
   if (rxy < fabs(d4)) return false;
-  const double psi = atan2(p05y, p05x), phi = acos(d4 / rxy);
-  // R60 = R06^T: X60 = (r0, r1), Y60 = (r3, r4) read column-wise from T
-  const double X60x = T.r[0], X60y = T.r[1], Y60x = T.r[3], Y60y = T.r[4];
+  psi = atan2(p05y, p05x);
+  phi = acos(d4 / rxy);
+  return true;
+}
+MJS_DEV bool ik_closest(const Aff& T, const double* g, double* q_out) {
+  double psi, phi;
+  if (!ik_setup(T, psi, phi)) return false;
   // branch of the guess
   double ta = wrap_pi(psi + phi + 0.5 * PI), tb = wrap_pi(psi - phi + 0.5 * PI);
   const int s1p = joint_dist2(tb, g[0]) < joint_dist2(ta, g[0]) ? 1 : 0;
@@ -655,72 +732,7 @@ MJS_DEV bool ik_closest(const Aff& T, const double* g, double* q_out) {
   double best = INFINITY;
   int best_idx = 8;
 #pragma unroll 1
-  for (int a = 0; a < 2; a++) {
-    const int s1 = s1p ^ a;
-    double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
-    double q0 = wrap_pi(th1);
-    const double p0 = joint_dist2(q0, g[0]);
-    if (p0 > best) continue;
-    double sn1, c1;
-    sincos(th1, &sn1, &c1);
-    bool ok5 = true;
-    const double c5 = clamp_unit((T.t[0] * sn1 - T.t[1] * c1 - d4) / d6, ok5);
-    if (!ok5) continue;
-    const double ac5 = acos(c5), root5 = sqrt(fmax(0.0, 1.0 - c5 * c5));
-    const Aff T01i_T = aff_mul(aff_inv(dh_cs(c1, sn1, d1, 0, 0, 1)), T);
-#pragma unroll 1
-    for (int b = 0; b < 2; b++) {
-      const int s5 = s5p ^ b;
-      const double sg5 = s5 ? -1.0 : 1.0;
-      double q4 = wrap_pi(sg5 * ac5);
-      const double p4 = joint_dist2(q4, g[4]);
-      if (p0 + p4 > best) continue;
-      const double sn5 = sg5 * root5;
-      double th6 = 0, c6 = 1.0, sn6 = 0.0;
-      if (!(fabs(sn5) < 1e-12)) {
-        double y6 = (-X60y * sn1 + Y60y * c1) / sn5, x6 = (X60x * sn1 - Y60x * c1) / sn5;
-        th6 = atan2(y6, x6);
-        double h6 = sqrt(x6 * x6 + y6 * y6);
-        if (h6 > 0) { c6 = x6 / h6; sn6 = y6 / h6; }
-      }
-      double q5 = wrap_pi(th6);
-      const double p5 = joint_dist2(q5, g[5]);
-      if (p0 + p4 + p5 > best) continue;
-      const Aff T14 = aff_mul(T01i_T, aff_inv(aff_mul(dh_cs(c5, sn5, d5, 0, 0, -1), dh_cs(c6, sn6, d6, 0, 1, 0))));
-      const double px = T14.t[0], py = T14.t[1], r2 = px * px + py * py;
-      bool ok3 = true;
-      const double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
-      if (!ok3) continue;
-      const double ac3 = acos(c3), root3 = sqrt(fmax(0.0, 1.0 - c3 * c3));
-      const double base2 = atan2(py, px), at3 = atan2(a3 * root3, a2 + a3 * c3), th234 = atan2(T14.r[3], T14.r[0]);
-#pragma unroll 1
-      for (int c = 0; c < 2; c++) {
-        const int s3 = s3p ^ c;
-        const double sg3 = s3 ? -1.0 : 1.0;
-        const double th3 = sg3 * ac3;
-        double q2 = wrap_pi(th3);
-        const double p2 = joint_dist2(q2, g[2]);
-        if (p0 + p4 + p5 + p2 > best) continue;
-        const double th2 = base2 - sg3 * at3;
-        const double th4 = th234 - th2 - th3;  // rotation of frame 1->4 is Rz(th2+th3+th4)
-        double q1 = wrap_pi(th2), q3 = wrap_pi(th4);
-        if (!(isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3) && isfinite(q4) && isfinite(q5))) continue;
-        // same summation order as the exhaustive evaluation: joints 0..5
-        double dist = p0;
-        dist += joint_dist2(q1, g[1]);
-        dist += p2;
-        dist += joint_dist2(q3, g[3]);
-        dist += p4;
-        dist += p5;
-        const int idx = (s1 << 2) | (s5 << 1) | s3;
-        if (dist < best || (dist == best && idx < best_idx)) {
-          best = dist;
-          best_idx = idx;
-          q_out[0] = q0; q_out[1] = q1; q_out[2] = q2; q_out[3] = q3; q_out[4] = q4; q_out[5] = q5;
-        }
-      }
-    }
-  }
+  for (int a = 0; a < 2; a++) ik_branch(T, g, psi, phi, s1p ^ a, s5p, s3p, best, best_idx, q_out);
   return best_idx < 8;
 }
 
@@ -729,9 +741,10 @@ MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const do
 MJS_DEV bool tcp_pose_to_joints(const double* pos, const double* q_guess, double* q_out) {
   return tcp_pose_to_joints_offset(pos, MJS_G2F85_TCP_Z, q_guess, q_out);
 }
-// tcp_z = TCP offset of the attached end effector along the flange z axis (gripper 0.174, CylinderEEF 0.1)
-MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const double* q_guess, double* q_out) {
-  double x = MJS_TOP_DOWN_QUAT_XYZW[0], y = MJS_TOP_DOWN_QUAT_XYZW[1], z = MJS_TOP_DOWN_QUAT_XYZW[2], w = MJS_TOP_DOWN_QUAT_XYZW[3];
+// flange pose of a TCP pose: TCP position + scalar-LAST quaternion, tcp_z = TCP offset of the attached end effector along
+// the flange z axis (gripper 0.174, CylinderEEF 0.1, bare flange 0)  (robot.py:138-151)
+MJS_DEV Aff flange_pose_of_tcp(const double* pos, const double* quat_xyzw, double tcp_z) {
+  double x = quat_xyzw[0], y = quat_xyzw[1], z = quat_xyzw[2], w = quat_xyzw[3];
   double n = sqrt(x * x + y * y + z * z + w * w);
   x /= n; y /= n; z /= n; w /= n;
   Aff T;
@@ -741,7 +754,10 @@ MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const do
   T.t[0] = pos[0] - T.r[2] * tcp_z;
   T.t[1] = pos[1] - T.r[5] * tcp_z;
   T.t[2] = pos[2] - T.r[8] * tcp_z;
-  return ik_closest(T, q_guess, q_out);
+  return T;
+}
+MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const double* q_guess, double* q_out) {
+  return ik_closest(flange_pose_of_tcp(pos, MJS_TOP_DOWN_QUAT_XYZW, tcp_z), q_guess, q_out);
 }
 
 // ----------------------------------------------------------------- contact detection
@@ -1077,6 +1093,293 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
 #pragma unroll
         for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
       } else {  // some lanes left earlier (auto-reset path, tail of the batch): each lane writes its own row
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+      }
+    }
+  }
+  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
+    if (p.out.terminal_obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    State fresh = episode_init(p.rng, i);
+    store_state(p, i, fresh);
+    p.flags[i] = 0;
+    fk(fresh.q, c);
+    make_obs(fresh, c, obs);
+    if (p.out.obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    if (p.out.ncon) p.out.ncon[i] = count_floor_contacts(c);
+  }
+  MJS_STAMP(p, 5);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Default stepping kernel: THREE wavefronts per 64 envs, each on its own SIMD of the CU.
+//   wave 2      the analytic IK of servoL (the whole closest-of-8 search), published through LDS; then it exits.
+//   waves 0, 1  meanwhile run substep 0 on their own, redundantly and without a barrier: its servo set-point is q0
+//               itself (fraction 0/20 of the trajectory), so it does not need the IK result. Then one barrier, and
+//               substeps 1..19 as the two role-specialised wavefronts of kernel<false, 2>; at the end role 1 counts
+//               the floor contacts while role 0 writes the outputs.
+// Why not more wavefronts or lanes per env — measured on gfx950 (tools/microbench/ub.hip, profiles/r02_a_microbench.txt):
+// one LDS exchange + barrier between two wavefronts costs 150 cycles + ~20 per double, a cross-lane move of a double
+// (2 x v_mov_b32_dpp) ~11 cycles = two FP64 issue slots, a wavefront with 16 active lanes issues FP64 no faster than a
+// full one, and FP64 MFMA has 53-72 cycles of dependent latency. Splitting the IK by theta1 branch over two wavefronts
+// was also measured and is SLOWER (profiles/r02_b_*): the serial search prunes the other 7 candidates against the
+// guess-branch result, a wavefront that owns the other branch cannot and evaluates up to 4 full candidates (DESIGN.md
+// section 4).
+struct IkOut {
+  double q[NJ];
+  bool found;
+};
+template <bool INLINE>
+__device__ __attribute__((always_inline)) inline IkOut ik_for_wave_body(double ax, double ay, double az, double g0, double g1, double g2, double g3, double g4, double g5) {
+  const double act[3] = {ax, ay, az}, g[NJ] = {g0, g1, g2, g3, g4, g5};
+  IkOut o;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) o.q[j] = g[j];
+  o.found = tcp_pose_to_joints(act, g, o.q);
+  if (!o.found) {
+#pragma unroll
+    for (int j = 0; j < NJ; j++) o.q[j] = g[j];
+  }
+  return o;
+}
+// out-of-line copy for the rare solo path (the IK wavefront inlines its own)
+__device__ __noinline__ IkOut ik_out_of_line(double ax, double ay, double az, double g0, double g1, double g2, double g3, double g4, double g5) {
+  return ik_for_wave_body<false>(ax, ay, az, g0, g1, g2, g3, g4, g5);
+}
+
+template <int DUMMY>
+__global__ __launch_bounds__(192) void kernel3(KernelParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int i = blockIdx.x * 64 + lane;
+  __shared__ double xch[12][64];    // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
+  __shared__ double ikx[7][64];     // q1[6], found
+  __shared__ double obs_tile[OBS_DIM * 64];
+  if (i >= p.N) return;
+  uint8_t flags = p.flags[i];
+  double obs[OBS_DIM];
+  Chain c;
+  if ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP) {
+    if (wave != 0) return;
+    State st = episode_init(p.rng, i);
+    store_state(p, i, st);
+    p.flags[i] = 0;
+    fk(st.q, c);
+    make_obs(st, c, obs);
+    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, count_floor_contacts(c));
+    return;
+  }
+  MJS_STAMP(p, 0);
+  State st = load_state(p, i);
+  double q0[NJ], q1[NJ], act[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) q0[j] = st.q[j];
+  // same wave-uniform guard as kernel<false, 2>: a joint within reach of its range sends the whole workgroup to the
+  // robust single-wavefront path (every wavefront evaluates it on the same data)
+  bool near_limit = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) near_limit = near_limit || (st.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - st.q[j] < 0.6);
+  const bool solo = __any(near_limit);
+  const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
+  const double inv_span = 1.0 / (t1 - t0);
+  bool bad = false, limit_rows_active = false;
+  double cs[NJ], sn[NJ];
+  if (solo) {
+    if (wave != 0) return;
+    {
+      IkOut ik = ik_out_of_line(act[0], act[1], act[2], q0[0], q0[1], q0[2], q0[3], q0[4], q0[5]);
+      if (!ik.found) flags |= FLAG_IK_FAILED;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) q1[j] = ik.q[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    SoloIn in;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
+    in.time = st.time; in.t0 = t0; in.t1 = t1;
+    SoloOut o = solo_control_step(in);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
+    st.time = o.time;
+    bad = o.bad;
+    limit_rows_active = o.limit_rows_active;
+  } else {
+    if (wave == 2) {
+      // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
+      IkOut o = ik_for_wave_body<true>(act[0], act[1], act[2], q0[0], q0[1], q0[2], q0[3], q0[4], q0[5]);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) ikx[j][lane] = o.q[j];
+      ikx[6][lane] = o.found ? 1.0 : 0.0;
+      __syncthreads();  // IK published
+      return;
+    }
+    const int role = wave;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    {
+      // substep 0, whole on this wavefront (both of them, same bits): ctrl = q0 (joint_trajectory.py:41-47 at t = t0)
+      double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ], ctrl[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j];
+      ur5e_M_gen(cs, sn, M);
+      ur5e_bias_gen(cs, sn, st.v, bias);
+#pragma unroll
+      for (int r = 0; r < NJ; r++) {
+#pragma unroll
+        for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+      }
+      const int clamped = actuator_forces(st.q, st.v, ctrl, fact);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
+      factor_system(A, clamped, Dinv);
+      udu_solve(A, Dinv, rhs);
+      double acc2 = 0, dq2 = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        acc2 = fma(rhs[j], rhs[j], acc2);
+        st.v[j] += MJS_RR_PHYSICS_DT * rhs[j];
+        double dq = MJS_RR_PHYSICS_DT * st.v[j];
+        st.q[j] += dq;
+        dq2 = fma(dq, dq, dq2);
+        rotate_small(cs[j], sn[j], dq);
+      }
+      bad = bad || !(acc2 <= 1e20);
+      if (!(dq2 <= 0.01)) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+      }
+      st.time += MJS_RR_PHYSICS_DT;
+    }
+    MJS_STAMP(p, 6);
+    __syncthreads();  // IK published
+    MJS_STAMP(p, 1);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) q1[j] = ikx[j][lane];
+    if (ikx[6][lane] == 0.0) flags |= FLAG_IK_FAILED;  // reference raises ValueError; batched: flag + hold position (D-4)
+#pragma unroll 1
+    for (int s = 1; s < MJS_RR_NSUB; s++) {
+      double qacc[NJ];
+      if (role == 1) {
+        double t = fmin(fmax(st.time, t0), t1);
+        double ctrl[NJ], bias[NJ], fact[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+        actuator_forces(st.q, st.v, ctrl, fact);
+        ur5e_bias_gen(cs, sn, st.v, bias);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+        __syncthreads();  // qfrc_smooth published
+        __syncthreads();  // qacc published
+#pragma unroll
+        for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
+      } else {
+        if (s == 10) MJS_STAMP(p, 8);
+        double t = fmin(fmax(st.time, t0), t1);
+        double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+        int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
+        ur5e_M_gen(cs, sn, M);
+#pragma unroll
+        for (int r = 0; r < NJ; r++) {
+#pragma unroll
+          for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+        }
+        factor_system(A, clamped, Dinv);
+        invert_unit_upper(A, W);
+#pragma unroll
+        for (int r = 0; r < NJ; r++) {
+          asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+          for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+        }
+        if (s == 10) MJS_STAMP(p, 9);
+        __syncthreads();  // qfrc_smooth published
+        if (s == 10) MJS_STAMP(p, 10);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
+        apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
+        __syncthreads();  // qacc published
+        if (s == 10) MJS_STAMP(p, 11);
+      }
+      double acc2 = 0, dq2 = 0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        acc2 = fma(qacc[j], qacc[j], acc2);
+        st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+        double dq = MJS_RR_PHYSICS_DT * st.v[j];
+        st.q[j] += dq;
+        dq2 = fma(dq, dq, dq2);
+        rotate_small(cs[j], sn[j], dq);
+      }
+      bad = bad || !(acc2 <= 1e20);
+      if (!(dq2 <= 0.01)) {
+#pragma unroll
+        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+      }
+      st.time += MJS_RR_PHYSICS_DT;
+      if (role == 0 && s == 10) MJS_STAMP(p, 12);
+    }
+    if (role == 1) {
+      // role 1's last job: the floor-contact count of the final configuration (role 0 is writing the outputs meanwhile).
+      // Not with a same-step reset: there role 0 may overwrite ncon with the post-reset count, and two wavefronts' stores
+      // to one address are unordered.
+      if (p.out.ncon && p.autoreset != MJS_AUTORESET_SAME_STEP) {
+        fk_cs(cs, sn, c);
+        p.out.ncon[i] = count_floor_contacts(c);
+      }
+      return;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);  // mj_checkPos / mj_checkVel
+  MJS_STAMP(p, 2);
+  fk_cs(cs, sn, c);
+  make_obs(st, c, obs);
+  double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
+  double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  bool success = dist < MJS_RR_GOAL_THRESHOLD;
+  double reward = (p.reward_type == MJS_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist;
+  double discount = 1.0;
+  bool terminate = false;
+  if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
+  if (bad) { reward = 0; discount = 0; terminate = true; }
+  if (st.time >= p.time_limit) terminate = true;
+  MJS_STAMP(p, 3);
+  const bool ncon_here = solo || p.autoreset == MJS_AUTORESET_SAME_STEP;  // otherwise role 1 writes it
+  int ncon = ncon_here ? count_floor_contacts(c) : 0;
+  MJS_STAMP(p, 4);
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
+  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+  store_state(p, i, st);
+  p.flags[i] = newflags;
+  {
+    KernelParams pn = p;
+    pn.out.obs = nullptr;
+    if (!ncon_here) pn.out.ncon = nullptr;
+    write_outputs<OBS_DIM>(pn, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+    if (p.out.obs) {
+      if (__ballot(1) == ~0ull) {  // whole wavefront alive: cooperative block store (only this wavefront touches obs_tile)
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) obs_tile[lane * OBS_DIM + k] = obs[k];
+        __builtin_amdgcn_wave_barrier();
+        double* dst = p.out.obs + (size_t)blockIdx.x * 64 * OBS_DIM;
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
+      } else {
 #pragma unroll
         for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
       }

@@ -165,7 +165,8 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
   }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);  // two role-specialised waves per 64 envs
+  else if (h->cfg.kernel_variant == MJS_VARIANT_TWO_ROLES) rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);  // round 1: two role-specialised waves per 64 envs
+  else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);  // an IK wave + two role-specialised dynamics waves per 64 envs
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }
