@@ -165,6 +165,26 @@ int mjs_debug_ur5e_ik(const double* T_dev, const double* guess_dev, double* q_de
  * Cartesian target into a Button-Push joint action (robot_push_button.py:287-291). */
 int mjs_ur5e_tcp_to_joints(const double* tcp_pos_dev, const double* guess_dev, double* q_dev, uint8_t* ok_dev, int32_t n, void* stream);
 
+/* Replaces the Robot entity's control API on a stand-alone UR5e (entities/robots/robot.py:198-272): Robot.moveJ :211-216,
+ * Robot.movej_IK :198-209, Robot.servoL :218-225, Robot.servoJ :227-259, then n_substeps x (Robot.before_substep :261-272 +
+ * JointTrajectory.get_target_joint_positions joint_trajectory.py:41-47; Physics.step), then Robot.get_tcp_pose :153-168.
+ * This is the component the reference's own tests drive (test/test_ur_control_api.py:7-82: UR5e() + raw mjcf.Physics at
+ * the XML's timestep); n independent robots, one lane each.
+ *   state_dev   float64 [n, MJS_UR_STATE], in/out: q[6], v[6], ctrl[6], time, trajectory active, q0[6], q1[6], t0, t1
+ *   target_dev  float64 [n, 7]: 6 joint angles (MOVEJ / SERVOJ) or a TCP pose xyz + scalar-LAST quaternion
+ *               (MOVEJ_IK / SERVOL, type_aliases.py:6-10); unused for MJS_UR_CMD_NONE
+ *   param       speed [rad/s] for MOVEJ / MOVEJ_IK, duration [s] for SERVOL / SERVOJ
+ *   eef         MJS_UR_EEF_NONE (bare flange, TCP = flange) or MJS_UR_EEF_GRIPPER (lumped 2F-85, TCP offset 0.174)
+ *   dt          physics timestep (the menagerie XML sets none: MuJoCo's default 0.002)
+ *   tcp_pose_out_dev float64 [n, 7] or NULL; status_dev uint8 [n] or NULL: bit 0 = the command's IK found a solution
+ *               (movej_IK prints and returns, servoL raises), bit 1 = a joint left its range (limit rows are not modelled by
+ *               this entry point), bit 2 = non-finite acceleration. No handle; device = current HIP device. */
+#define MJS_UR_STATE 34
+enum { MJS_UR_CMD_NONE = 0, MJS_UR_CMD_MOVEJ = 1, MJS_UR_CMD_MOVEJ_IK = 2, MJS_UR_CMD_SERVOL = 3, MJS_UR_CMD_SERVOJ = 4 };
+enum { MJS_UR_EEF_NONE = 0, MJS_UR_EEF_GRIPPER = 1 };
+int mjs_ur5e_robot_run(double* state_dev, const double* target_dev, int32_t command, double param, int32_t n_substeps, int32_t eef, double dt,
+                       double* tcp_pose_out_dev, uint8_t* status_dev, int32_t n, void* stream);
+
 /* checkpoint / resume of the physics+task state: float64 [state_dim, N] ... */
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream);
 int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream);

@@ -29,11 +29,14 @@ REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DI
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
+UR_STATE = 34
+UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
+UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1
 
 EXPORTED_SYMBOLS = [
     "mjs_version", "mjs_obs_dim", "mjs_action_dim", "mjs_action_dim_for", "mjs_state_dim", "mjs_env_obs_dim", "mjs_env_state_dim", "mjs_algorithmic_bytes_per_env_step", "mjs_substeps",
     "mjs_create", "mjs_destroy", "mjs_last_error", "mjs_seed", "mjs_reset", "mjs_step", "mjs_rollout",
-    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik", "mjs_ur5e_tcp_to_joints",
+    "mjs_get_state", "mjs_set_state", "mjs_get_rng_state", "mjs_set_rng_state", "mjs_render", "mjs_debug_ur5e_ik", "mjs_ur5e_tcp_to_joints", "mjs_ur5e_robot_run",
 ]
 
 
@@ -137,6 +140,7 @@ def lib() -> C.CDLL:
     L.mjs_set_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_debug_ur5e_ik.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mjs_ur5e_tcp_to_joints.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    L.mjs_ur5e_robot_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
     L.mjs_render.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
     L.mjs_get_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.mjs_set_rng_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]

@@ -246,11 +246,11 @@ MJS_DEV int actuator_forces(const double* q, const double* v, const double* ctrl
 // base: the CRBA produces the wrist rows of M first, so the serial pivot chain overlaps the rest of
 // the CRBA instead of starting after it (MuJoCo's L^T D L has the same order for sparsity).
 // Storage: symmetric entry (i,j), i < j, lives in A[j][i]; on return U(i,j) is in A[j][i], 1/D in Dinv.
-MJS_DEV void factor_system(double A[NJ][NJ], int clamped, double* Dinv) {
+MJS_DEV void factor_system(double A[NJ][NJ], int clamped, double* Dinv, double dt = MJS_RR_PHYSICS_DT) {
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
     A[j][j] += MJS_UR_ARMATURE;
-    if (!((clamped >> j) & 1)) A[j][j] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j];
+    if (!((clamped >> j) & 1)) A[j][j] += dt * MJS_UR_ACT_KD[j];
   }
   double Dg[NJ];
 #pragma unroll
@@ -1402,6 +1402,129 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
     if (p.out.ncon) p.out.ncon[i] = count_floor_contacts(c);
   }
   MJS_STAMP(p, 5);
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// The Robot entity's control API on a stand-alone UR5e (entities/robots/robot.py:113-272): moveJ / movej_IK / servoL /
+// servoJ -> JointTrajectory, then n x (Robot.before_substep; Physics.step), then Robot.get_tcp_pose. This is the
+// component the reference's own tests drive (test/test_ur_control_api.py:7-82: UR5e() + raw mjcf.Physics, the XML's
+// default timestep, no task), exposed as mjs_ur5e_robot_run so that those tests run literally on the HIP path. One
+// robot per lane, same device code as the task kernels (analytic IK, generated M / bias, implicitfast U D U^T solve);
+// exact sin/cos every substep (a utility, not a hot path). State block: include/mjsim.h MJS_UR_STATE.
+constexpr int UR_STATE = 34;
+// SE3Container.orientation_as_quaternion (SE3Container.py:102-106) of a rotation with columns (cx, cy, cz): angle-axis
+// (spatialmath tr2angvec, incl. its theta = pi branch) -> [sin(theta/2) axis, cos(theta/2)], scalar LAST
+MJS_DEV void rotation_to_quat_xyzw(V3 cx, V3 cy, V3 cz, double* q) {
+  const double R[9] = {cx.x, cy.x, cz.x, cx.y, cy.y, cz.y, cx.z, cy.z, cz.z};
+  double c = 0.5 * (R[0] + R[4] + R[8] - 1.0);
+  c = fmin(fmax(c, -1.0), 1.0);
+  const double theta = acos(c);
+  double ax[3] = {R[7] - R[5], R[2] - R[6], R[3] - R[1]};
+  const double n = sqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+  if (theta < 1e-12 || (n < 1e-12 && c > 0)) { q[0] = q[1] = q[2] = 0; q[3] = 1; return; }
+  if (n < 1e-9) {  // theta = pi: R = 2 a a^T - I
+    int k = 0;
+    if (R[4] > R[0]) k = 1;
+    if (R[8] > R[4 * k]) k = 2;
+    const double m = sqrt(2.0 * (1.0 + R[4 * k]));
+#pragma unroll
+    for (int i = 0; i < 3; i++) ax[i] = (R[3 * i + k] + (i == k ? 1.0 : 0.0)) / m;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; i++) ax[i] /= n;
+  }
+  const double sh = sin(0.5 * theta);
+  q[0] = sh * ax[0]; q[1] = sh * ax[1]; q[2] = sh * ax[2]; q[3] = cos(0.5 * theta);
+}
+
+__global__ __launch_bounds__(64) void ur_robot_kernel(double* state, const double* target, int command, double param, int n_substeps, int eef,
+                                                      double dt, double* pose_out, uint8_t* status, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  double* st = state + (size_t)i * UR_STATE;
+  double q[NJ], v[NJ], ctrl[NJ], q0[NJ], q1[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { q[j] = st[j]; v[j] = st[6 + j]; ctrl[j] = st[12 + j]; q0[j] = st[20 + j]; q1[j] = st[26 + j]; }
+  double time = st[18], t0 = st[32], t1 = st[33];
+  bool active = st[19] != 0.0;
+  const double tcp_z = eef == MJS_UR_EEF_GRIPPER ? MJS_G2F85_TCP_Z : 0.0;  // robot.py:104-107: the bare flange has no TCP offset
+  int stat = 1;
+  if (command != MJS_UR_CMD_NONE) {
+    double tgt[NJ];
+    bool have = true;
+    const double* tg = target + (size_t)i * 7;
+    if (command == MJS_UR_CMD_MOVEJ_IK || command == MJS_UR_CMD_SERVOL) {  // robot.py:204-205,219-220
+      have = ik_closest(flange_pose_of_tcp(tg, tg + 3, tcp_z), q, tgt);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJ; j++) tgt[j] = tg[j];
+    }
+    if (!have) stat = 0;  // movej_IK prints and returns, servoL raises: the trajectory stays as it was
+    else {
+      double span = param;  // servoJ / servoL: robot.py:254-258
+      if (command == MJS_UR_CMD_MOVEJ || command == MJS_UR_CMD_MOVEJ_IK) {  // robot.py:211-216: time = max |dq| / speed
+        double mx = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) mx = fmax(mx, fabs(tgt[j] - q[j]));
+        span = mx / param;
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { q0[j] = q[j]; q1[j] = tgt[j]; }
+      t0 = time; t1 = time + span; active = true;
+    }
+  }
+#pragma unroll 1
+  for (int s = 0; s < n_substeps; s++) {
+    if (active) {  // Robot.before_substep, robot.py:261-263; joint_trajectory.py:33-47
+      const double t = fmin(fmax(time, t0), t1);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) / (t1 - t0);
+      if (dt >= t1) active = false;  // robot.py:271: is_finished is handed physics.timestep()
+    }
+    double cs[NJ], sn[NJ], M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      sincos(q[j], &sn[j], &cs[j]);
+      if (q[j] < MJS_UR_JNT_RANGE[j][0] || q[j] > MJS_UR_JNT_RANGE[j][1]) stat |= 2;  // limit rows are not modelled here
+    }
+    if (eef == MJS_UR_EEF_GRIPPER) { ur5e_M_gen(cs, sn, M); ur5e_bias_gen(cs, sn, v, bias); }
+    else { ur5e_bare_M_gen(cs, sn, M); ur5e_bare_bias_gen(cs, sn, v, bias); }
+#pragma unroll
+    for (int r = 0; r < NJ; r++) {
+#pragma unroll
+      for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+    }
+    // actuator gain of the implicitfast derivative uses THIS dt
+    const int clamped = actuator_forces(q, v, ctrl, fact);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
+    factor_system(A, clamped, Dinv, dt);
+    udu_solve(A, Dinv, rhs);
+    double acc2 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      acc2 = fma(rhs[j], rhs[j], acc2);
+      v[j] += dt * rhs[j];
+      q[j] += dt * v[j];
+    }
+    if (!(acc2 <= 1e20)) stat |= 4;
+    time += dt;
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st[j] = q[j]; st[6 + j] = v[j]; st[12 + j] = ctrl[j]; st[20 + j] = q0[j]; st[26 + j] = q1[j]; }
+  st[18] = time; st[19] = active ? 1.0 : 0.0; st[32] = t0; st[33] = t1;
+  if (pose_out) {  // Robot.get_tcp_pose, robot.py:153-168: flange site pose, TCP offset along the flange z axis
+    Chain c;
+    fk(q, c);
+    // flange frame = wrist_3 * Rx(-90 deg) (MJS_UR_FLANGE_QUAT): x = body x, y = -body z, z = body y
+    const V3 fx = c.R[6].cx, fy = -c.R[6].cz, fz = c.R[6].cy;
+    const V3 p = madd(madd(c.p[6], MJS_UR_FLANGE_POS[1], c.R[6].cy), tcp_z, fz);
+    double* o = pose_out + (size_t)i * 7;
+    o[0] = p.x; o[1] = p.y; o[2] = p.z;
+    rotation_to_quat_xyzw(fx, fy, fz, o + 3);
+  }
+  if (status) status[i] = (uint8_t)stat;
 }
 
 }  // namespace rr

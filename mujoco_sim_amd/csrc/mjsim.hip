@@ -458,6 +458,17 @@ int mjs_ur5e_tcp_to_joints(const double* tcp_pos_dev, const double* guess_dev, d
   return MJS_OK;
 }
 
+int mjs_ur5e_robot_run(double* state_dev, const double* target_dev, int32_t command, double param, int32_t n_substeps, int32_t eef, double dt,
+                       double* tcp_pose_out_dev, uint8_t* status_dev, int32_t n, void* stream) {
+  if (!state_dev || n < 0 || n_substeps < 0 || command < MJS_UR_CMD_NONE || command > MJS_UR_CMD_SERVOJ || (command != MJS_UR_CMD_NONE && !target_dev) ||
+      (eef != MJS_UR_EEF_NONE && eef != MJS_UR_EEF_GRIPPER) || !(dt > 0) || (command != MJS_UR_CMD_NONE && !(param > 0)))
+    return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_ur5e_robot_run: bad argument");
+  static_assert(rr::UR_STATE == MJS_UR_STATE, "state block layout");
+  rr::ur_robot_kernel<<<grid_for(n), BLOCK, 0, (hipStream_t)stream>>>(state_dev, target_dev, command, param, n_substeps, eef, dt, tcp_pose_out_dev, status_dev, n);
+  HIP_TRY(nullptr, hipGetLastError());
+  return MJS_OK;
+}
+
 int mjs_get_state(mjs_handle* h, double* state_dev, void* stream) {
   if (!h || !state_dev) return fail(h, MJS_ERR_INVALID_ARG, "mjs_get_state: null argument");
   DeviceGuard dev_(h->cfg.device);

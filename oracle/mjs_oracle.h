@@ -196,6 +196,21 @@ int om_debug_convex(int type1, const double* size1, const double* pos1, const do
                     const double* mat2, double* out);
 void om_debug_reach_dynamics(const double* q, const double* v, double* M_out, double* bias_out);
 
+/* ---- the Robot entity's control API on a stand-alone UR5e (entities/robots/robot.py:113-272), the component the
+ * reference's own tests exercise (test/test_ur_control_api.py:7-82). State block (OM_UR_STATE doubles per robot, the same
+ * layout as the device entry point mjs_ur5e_robot_run): q[6], v[6], ctrl[6], time, traj_active, traj_q0[6], traj_q1[6],
+ * traj_t0, traj_t1. */
+#define OM_UR_STATE 34
+enum { OM_UR_CMD_NONE = 0, OM_UR_CMD_MOVEJ = 1, OM_UR_CMD_MOVEJ_IK = 2, OM_UR_CMD_SERVOL = 3, OM_UR_CMD_SERVOJ = 4 };
+enum { OM_UR_EEF_NONE = 0, OM_UR_EEF_GRIPPER = 1 };
+void om_build_ur5e_alone(om_model* m, int eef_gripper, double dt);
+/* applies `command` (target: 6 joints or a TCP pose xyz + scalar-last quaternion; param: speed [rad/s] for moveJ /
+ * movej_IK, duration [s] for servoL / servoJ), then n_substeps x (Robot.before_substep; Physics.step), and reports
+ * Robot.get_tcp_pose (7 numbers). Returns 0 when the command's IK found no solution (movej_IK prints and returns,
+ * servoL raises: robot.py:206-209,221-224), else 1. */
+int om_ur_robot_run(double* state, const double* target, int command, double param, int n_substeps, int eef, double dt, double* tcp_pose_out);
+void om_rotation_to_quat_xyzw(const double* R /*row-major 3x3*/, double* quat_xyzw); /* SE3Container.orientation_as_quaternion */
+
 /* batch helpers for the CPU baseline / parity tests (OpenMP over envs) */
 typedef struct om_batch om_batch;
 om_batch* om_batch_create(const om_task_config* cfg, int n, uint32_t base_seed);

@@ -185,6 +185,15 @@ static void build_robot(om_model* m, int eef_gripper) {
   om_set_const(m);
 }
 
+/* the UR5e alone, as the reference's component tests build it (test/test_ur_control_api.py:8-9: UR5e() compiled without an
+ * arena or end effector) or with the lumped gripper; no floor, no collision geoms: the test scenes have nothing to touch */
+void om_build_ur5e_alone(om_model* m, int eef_gripper, double dt) {
+  build_robot(m, eef_gripper);
+  m->ngeom = 0;
+  m->dt = dt;
+  om_set_const(m);
+}
+
 /* Button-Push scene (robot_push_button.py:66-108): UR5e + lumped gripper (+ collision stand-in sphere
  * for the closed finger tips) + wrist-camera geoms' mass + static switch (box, button cylinder, touch
  * site). The switch body position is a MODEL field rewritten at every reset (Entity.set_pose). */

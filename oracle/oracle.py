@@ -155,6 +155,31 @@ def ur5e_ik_closest(T, q_guess):
     return out if ok else None
 
 
+UR_STATE = 34
+UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
+UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1
+
+
+def ur_robot_state(q, ctrl=None):
+    """state block of a stand-alone UR5e at rest at q (Robot.set_joint_positions: ctrl = q; model creation: ctrl = 0)"""
+    st = np.zeros(UR_STATE)
+    st[0:6] = q
+    st[12:18] = q if ctrl is None else ctrl
+    return st
+
+
+def ur_robot_run(state, target, command, param, n_substeps, eef=UR_EEF_NONE, dt=0.002):
+    """Robot control API + n x (before_substep; Physics.step) on the oracle; returns (new state, tcp pose[7], ok)"""
+    L = lib()
+    L.om_ur_robot_run.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_double, C.c_void_p]
+    st = np.array(state, dtype=np.float64)
+    tgt = np.zeros(7)
+    tgt[: len(target)] = target
+    pose = np.zeros(7)
+    ok = L.om_ur_robot_run(st.ctypes.data, tgt.ctypes.data, command, float(param), int(n_substeps), int(eef), float(dt), pose.ctypes.data)
+    return st, pose, bool(ok)
+
+
 class OracleBatch:
     """N independent oracle envs, env i seeded ``base_seed + i`` (reach_sac.py:84)."""
 

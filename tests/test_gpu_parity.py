@@ -534,6 +534,63 @@ def test_button_push_cameras_match_oracle(oracle_mod):
     venv.close()
 
 
+def test_baseline_config5_button_push_visual_2048(oracle_mod):
+    """BASELINE.json configs[4] in its own shape, one GPU's share: Button-Push, 2048 envs, the 64x64 scene camera AND the
+    64x64 wrist camera rendered every control step as observations (robot_push_button.py:87-96 cameras, :110-124 visual
+    observables), absolute joint actions q_home +- U(0.2) + gripper U(0, 0.085) (SURVEY.md section 8d cfg 5).
+      * the first 32 envs against the oracle at every step: state within 1e-9, flags exact, BOTH cameras at 64x64 to the
+        renderer's bar (>= 99.9 % identical bytes, <= 2 grey levels);
+      * at the full size: determinism (a second handle repeats every image byte) and shard invariance (4 x 512 handles with
+        global seeds reproduce the 2048-env handle, images included)."""
+    import mujoco_sim_amd as m
+
+    N, NS, T, R = 2048, 32, 6, 64
+    home = np.array([-0.5, -0.5, 0.5, -0.5, -0.5, -0.5]) * np.pi
+    rs = np.random.RandomState(5)
+    acts = np.concatenate([home + rs.uniform(-0.2, 0.2, (T, N, 6)), rs.uniform(0.0, 0.085, (T, N, 1))], axis=2)
+
+    def run(n, offset):
+        venv = m.HipVectorEnv("robot_push_button", n, seed=2025, env_index_offset=offset, observation_type="visual_observations", image_resolution=R)
+        assert list(venv.single_observation_space.spaces) == ["ur5e/joint_configuration", "ur5e/Camera/rgb_image", "Camera/rgb_image"]
+        frames = []
+        obs, _ = venv.reset()
+        frames.append({k: v.cpu().numpy().copy() for k, v in obs.items()} | {"flat": venv.flat_obs.cpu().numpy().copy()})
+        for t in range(T):
+            obs, reward, term, trunc, info = venv.step(torch.from_numpy(acts[t, offset:offset + n]))
+            f = {k: v.cpu().numpy().copy() for k, v in obs.items()}
+            f |= {"flat": venv.flat_obs.cpu().numpy().copy(), "reward": reward.cpu().numpy().copy(), "term": term.cpu().numpy().copy(),
+                  "trunc": trunc.cpu().numpy().copy(), "ncon": info["ncon"].cpu().numpy().copy(), "success": info["is_success"].cpu().numpy().copy()}
+            frames.append(f)
+        venv.close()
+        return frames
+
+    full = run(N, 0)
+    assert full[0]["Camera/rgb_image"].shape == (N, R, R, 3) and full[0]["ur5e/Camera/rgb_image"].shape == (N, R, R, 3)
+    assert full[-1]["Camera/rgb_image"].std() > 10 and full[-1]["ur5e/Camera/rgb_image"].std() > 5
+    # oracle on the first NS envs (global seeds 2025 + i)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, NS, 2025, nthreads=8)
+    o = ob.reset()
+    for t in range(T + 1):
+        if t > 0:
+            o = ob.step(acts[t - 1, :NS])
+            np.testing.assert_allclose(full[t]["reward"][:NS], o["reward"], rtol=0, atol=ATOL)
+            assert np.array_equal(full[t]["term"][:NS], o["terminated"]) and np.array_equal(full[t]["trunc"][:NS], o["truncated"])
+            assert np.array_equal(full[t]["ncon"][:NS], o["ncon"]) and np.array_equal(full[t]["success"][:NS].astype(bool), o["is_success"])
+        np.testing.assert_allclose(full[t]["flat"][:NS], o["obs"], rtol=0, atol=ATOL, err_msg=f"state step {t}")
+        for key, cam in (("Camera/rgb_image", 0), ("ur5e/Camera/rgb_image", 1)):
+            gpu = full[t][key][:NS].astype(np.int16)
+            cpu = ob.render(R, R, cam).astype(np.int16)
+            diff = np.abs(gpu - cpu)
+            assert (diff > 0).mean() < 1e-3 and diff.max() <= 2, (t, key, (diff > 0).mean(), diff.max())
+    # determinism and shard invariance at the full size, every byte
+    again = run(N, 0)
+    shards = [run(N // 4, k * (N // 4)) for k in range(4)]
+    for t in range(T + 1):
+        for key in ("flat", "Camera/rgb_image", "ur5e/Camera/rgb_image"):
+            assert np.array_equal(full[t][key], again[t][key]), (t, key)
+            assert np.array_equal(full[t][key], np.concatenate([sh[t][key] for sh in shards])), (t, key)
+
+
 def test_registered_button_push_visual_env_id():
     # mujoco_sim/__init__.py:31-39: visual observations, 96x96, absolute joint actions, wrist + scene camera
     import mujoco_sim_amd as m
@@ -943,33 +1000,135 @@ def test_scene_camera_kernels_agree_byte_for_byte(task):
     b.close()
 
 
-def test_every_registered_env_runs_a_random_policy_to_the_end():
-    """test/test_gym_envs.py:7-18 (test_env_w_random_policy) and :21-36 (test_determinism_of_env) over every registered id:
-    an episode under the task's own random policy ends (terminated or truncated) within the step limit; seeded resets
-    repeat and differ between seeds."""
+# ------------------------------------------------------------------------------------------------------------------
+# The reference's own six tests, one named test each, on the HIP path. The three control-API tests
+# are literal: bare UR5e (TCP = flange), the XML's default timestep 0.002, the reference's start joints, target pose,
+# substep counts and atol = 1e-2 on every number it compares; each is also held to the oracle's result of the same test.
+REF_START_JOINTS = np.array([0.0, -0.5, 0.5, -0.5, -0.5, -0.5]) * np.pi
+REF_TARGET_POSE = np.array([0.1, 0.3, 0.5, 1, 0, 0, 0])
+
+
+def _pose_close(pose, target, atol):
+    # quaternion up to its double-cover sign (a rotation of ~pi: oracle/om_robot_api.c)
+    return np.allclose(pose[:3], target[:3], atol=atol) and (np.allclose(pose[3:], target[3:], atol=atol) or np.allclose(pose[3:], -target[3:], atol=atol))
+
+
+def test_reference_moveJ(oracle_mod):
+    """/root/reference/test/test_ur_control_api.py:7-28"""
+    from mujoco_sim_amd.entities.robots.robot import UR5eBatch
+
+    robot = UR5eBatch(3)  # default qpos = zeros, ctrl = zeros
+    robot.moveJ(REF_START_JOINTS, 1.0)
+    robot.substeps(10000)
+    q = robot.get_joint_positions().cpu().numpy()
+    assert np.allclose(q, REF_START_JOINTS, atol=1e-2), q
+    st, _, ok = oracle_mod.ur_robot_run(oracle_mod.ur_robot_state(np.zeros(6), ctrl=np.zeros(6)), REF_START_JOINTS, oracle_mod.UR_CMD_MOVEJ, 1.0, 10000)
+    assert ok and np.abs(q - st[0:6]).max() < 1e-8 and (robot.status.cpu().numpy() == 1).all()
+
+
+def test_reference_moveJ_IK(oracle_mod):
+    """/root/reference/test/test_ur_control_api.py:31-54"""
+    from mujoco_sim_amd.entities.robots.robot import UR5eBatch
+
+    robot = UR5eBatch(3)
+    robot.set_joint_positions(REF_START_JOINTS)
+    robot.movej_IK(REF_TARGET_POSE, 1.0)
+    robot.substeps(6000)
+    pose = robot.get_tcp_pose().cpu().numpy()
+    assert all(_pose_close(p, REF_TARGET_POSE, 1e-2) for p in pose), pose
+    _, opose, ok = oracle_mod.ur_robot_run(oracle_mod.ur_robot_state(REF_START_JOINTS), REF_TARGET_POSE, oracle_mod.UR_CMD_MOVEJ_IK, 1.0, 6000)
+    assert ok and robot.ik_ok.all() and np.abs(pose[:, :3] - opose[:3]).max() < 1e-8 and all(_pose_close(p, opose, 1e-7) for p in pose)
+
+
+def test_reference_servoL(oracle_mod):
+    """/root/reference/test/test_ur_control_api.py:57-82"""
+    from mujoco_sim_amd.entities.robots.robot import UR5eBatch
+
+    robot = UR5eBatch(3)
+    robot.set_joint_positions(REF_START_JOINTS)
+    st = oracle_mod.ur_robot_state(REF_START_JOINTS)
+    for _ in range(20):
+        robot.servoL(REF_TARGET_POSE, 0.2)
+        robot.substeps(100)
+        st, opose, ok = oracle_mod.ur_robot_run(st, REF_TARGET_POSE, oracle_mod.UR_CMD_SERVOL, 0.2, 100)
+        assert ok and robot.ik_ok.all()
+    pose = robot.get_tcp_pose().cpu().numpy()
+    assert all(_pose_close(p, REF_TARGET_POSE, 1e-2) for p in pose), pose
+    assert np.abs(robot.get_joint_positions().cpu().numpy() - st[0:6]).max() < 1e-8 and np.abs(pose[:, :3] - opose[:3]).max() < 1e-8
+    # an unreachable target: servoL raises ValueError("IK failed") in the reference (robot.py:221-224); batched: status bit 0
+    robot.servoL(np.array([2.0, 0.0, 0.5, 1, 0, 0, 0]), 0.2)
+    robot.substeps(1)
+    assert not robot.ik_ok.any()
+
+
+def test_reference_sim_ur_frame_matches_real(oracle_mod):
+    """/root/reference/test/test_ur_frame_matches_real.py:7-29: at q = 0 the attachment_site's 4x4 world pose equals the
+    analytic forward kinematics of the real UR5e (DH) within atol 1e-2"""
+    from mujoco_sim_amd.entities.robots.robot import UR5eBatch
+
+    robot = UR5eBatch(1)
+    robot.set_joint_positions(np.zeros(6))
+    x, y, z, qx, qy, qz, qw = robot.get_tcp_pose().cpu().numpy()[0]  # bare flange: TCP = attachment_site
+    pose = np.eye(4)
+    pose[:3, :3] = [[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                    [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                    [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]]
+    pose[:3, 3] = [x, y, z]
+    FK_pose = oracle_mod.ur5e_fk_dh(np.zeros(6))
+    assert np.allclose(pose, FK_pose, atol=1e-2), f"Pose mismatch: {pose} vs {FK_pose}"
+
+
+def _registered_ids():
     import mujoco_sim_amd as m
 
-    limits = {"point_mass": 51, "robot_reach": 100, "robot_push_button": 100, "robot_planar_push": 500}
-    for env_id in sorted(m.registry):
-        kwargs = {"max_control_steps_per_episode": 40} if "planar_push" in env_id else {}
-        env = m.make(env_id, **kwargs)
-        env.seed(2025)
-        obs, _ = env.reset()
-        env.seed(2025)
-        obs2, _ = env.reset()
-        env.seed(2024)
-        obs3, _ = env.reset()
-        state_keys = [k for k in obs if "image" not in k]
-        assert all(np.allclose(obs[k], obs2[k], atol=1e-6) for k in obs)
-        assert not all(np.allclose(obs[k], obs3[k], atol=1e-6) for k in state_keys if "active" not in k)
-        policy = env.dmc_env.task.create_random_policy()
-        limit = 40 if "planar_push" in env_id else next(v for k, v in limits.items() if k in env_id)
-        done, n = False, 0
-        while not done and n <= limit:
-            obs, reward, term, trunc, info = env.step(policy(None))
-            done, n = bool(term or trunc), n + 1
-        assert done and n <= limit, (env_id, n)
-        env.close()
+    return sorted(m.registry)
+
+
+@pytest.mark.parametrize("env_id", ["mujoco_sim/point_mass_reach-v0", "mujoco_sim/robot_push_button_visual-v0", "mujoco_sim/point_mass_reach_state-v0",
+                                    "mujoco_sim/robot_reach_state-v0", "mujoco_sim/robot_push_button_state-v0", "mujoco_sim/robot_planar_push_state-v0"])
+def test_reference_env_w_random_policy(env_id):
+    """/root/reference/test/test_gym_envs.py:7-18 over every registered id (the first two are the reference's own): an
+    episode under the task's own random policy ends (terminated or truncated) within the step limit"""
+    import mujoco_sim_amd as m
+
+    assert env_id in _registered_ids()
+    limits = {"point_mass": 51, "robot_reach": 100, "robot_push_button": 100, "robot_planar_push": 40}
+    kwargs = {"max_control_steps_per_episode": 40} if "planar_push" in env_id else {}
+    env = m.make(env_id, **kwargs)
+    env.reset()
+    policy = env.dmc_env.task.create_random_policy()
+    limit = next(v for k, v in limits.items() if k in env_id)
+    done, n = False, 0
+    while not done and n <= limit:
+        obs, reward, term, trunc, info = env.step(policy(None))
+        done, n = bool(term or trunc), n + 1
+    assert done and n <= limit, (env_id, n)
+    env.close()
+
+
+@pytest.mark.parametrize("env_id", ["mujoco_sim/point_mass_reach-v0", "mujoco_sim/robot_push_button_visual-v0", "mujoco_sim/point_mass_reach_state-v0",
+                                    "mujoco_sim/robot_reach_state-v0", "mujoco_sim/robot_push_button_state-v0", "mujoco_sim/robot_planar_push_state-v0"])
+def test_reference_determinism_of_env(env_id):
+    """/root/reference/test/test_gym_envs.py:21-36: seed(2025) twice -> every observation key allclose(atol 1e-6); seed(2024)
+    -> the state keys differ (images included for the pointmass env, whose image shows the sampled positions; a robot image
+    can coincide to 1e-6 only if the poses did)"""
+    import mujoco_sim_amd as m
+
+    kwargs = {"max_control_steps_per_episode": 40} if "planar_push" in env_id else {}
+    env = m.make(env_id, **kwargs)
+    env.seed(2025)
+    obs, _ = env.reset()
+    env.seed(2025)
+    obs2, _ = env.reset()
+    for key, value in obs.items():
+        assert np.allclose(value, obs2[key], atol=1e-6), key
+    env.seed(2024)
+    obs3, _ = env.reset()
+    for key, value in obs.items():
+        if "active" in key:  # the switch state is not sampled
+            continue
+        assert not np.allclose(value, obs3[key], atol=1e-6), key
+    env.close()
 
 
 def test_planar_push_reference_default_config_through_the_adapter():

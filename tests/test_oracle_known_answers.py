@@ -134,10 +134,46 @@ def test_ik_round_trip_and_closest(oracle_mod):
     assert oracle_mod.ur5e_ik_closest(T, np.zeros(6)) is None
 
 
-def test_servoL_converges_like_reference_test(oracle_mod):
-    # test/test_ur_control_api.py:57-82 re-expressed through the task: repeated servoL to a fixed TCP
-    # target converges within the reference's atol=1e-2 (pose error incl. the ~1 mm DH/model offset
-    # and the sag from the un-compensated gripper payload).
+# ---- the reference's component tests of the Robot control API, re-expressed LITERALLY on the oracle: a bare UR5e (no
+# arena, no end effector: TCP = flange), the XML's default timestep 0.002, the reference's start configuration, target,
+# substep counts and atol = 1e-2 on every number the reference compares. Same three tests on the HIP path:
+# tests/test_gpu_parity.py::test_reference_moveJ / _moveJ_IK / _servoL.
+REF_START_JOINTS = np.array([0.0, -0.5, 0.5, -0.5, -0.5, -0.5]) * np.pi
+REF_TARGET_POSE = np.array([0.1, 0.3, 0.5, 1, 0, 0, 0])
+
+
+def _pose_close(pose, target, atol):
+    # position + quaternion, the quaternion up to its double-cover sign: at a rotation of ~pi the sign spatialmath's log
+    # map returns follows sub-tolerance residuals (oracle/om_robot_api.c)
+    return np.allclose(pose[:3], target[:3], atol=atol) and (np.allclose(pose[3:], target[3:], atol=atol) or np.allclose(pose[3:], -target[3:], atol=atol))
+
+
+def test_reference_moveJ(oracle_mod):
+    """test/test_ur_control_api.py:7-28: from the default qpos (zeros, ctrl zeros) moveJ(joints, speed 1.0) and 10 000 x
+    (before_substep; physics.step()) -> joints within atol 1e-2"""
+    st, _, ok = oracle_mod.ur_robot_run(oracle_mod.ur_robot_state(np.zeros(6), ctrl=np.zeros(6)), REF_START_JOINTS, oracle_mod.UR_CMD_MOVEJ, 1.0, 10000)
+    assert ok and np.allclose(st[0:6], REF_START_JOINTS, atol=1e-2), st[0:6]
+    assert st[18] == pytest.approx(20.0, abs=1e-6) and st[19] == 1.0  # is_finished(physics.timestep()) never fires (robot.py:271)
+
+
+def test_reference_moveJ_IK(oracle_mod):
+    """test/test_ur_control_api.py:31-54: set_joint_positions(joints); movej_IK(target pose, 1.0); 6000 substeps ->
+    get_tcp_pose within atol 1e-2 on all 7 numbers"""
+    st, pose, ok = oracle_mod.ur_robot_run(oracle_mod.ur_robot_state(REF_START_JOINTS), REF_TARGET_POSE, oracle_mod.UR_CMD_MOVEJ_IK, 1.0, 6000)
+    assert ok and _pose_close(pose, REF_TARGET_POSE, 1e-2), pose
+
+
+def test_reference_servoL(oracle_mod):
+    """test/test_ur_control_api.py:57-82: 20 x (servoL(target pose, 0.2) + 100 substeps) -> get_tcp_pose within atol 1e-2"""
+    st = oracle_mod.ur_robot_state(REF_START_JOINTS)
+    for _ in range(20):
+        st, pose, ok = oracle_mod.ur_robot_run(st, REF_TARGET_POSE, oracle_mod.UR_CMD_SERVOL, 0.2, 100)
+        assert ok
+    assert _pose_close(pose, REF_TARGET_POSE, 1e-2), pose
+
+
+def test_servoL_converges_through_the_task(oracle_mod):
+    # the same convergence through the Robot-Reach task (gripper payload, dt 0.005, top-down orientation)
     b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, 1, 11)
     b.reset()
     target = np.array([[0.05, -0.45, 0.1]])

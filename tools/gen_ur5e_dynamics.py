@@ -290,7 +290,7 @@ def make_links(extra_parts):
             m, c, I = merge([(m, c, I)] + list(extra_parts))
         links.append(dict(C=quat_to_mat_exact(body_quat[b]), r=body_pos[b], axis=jnt_axis[j], m=m, c=c, I=I))
     um = sum(p[0] for p in extra_parts)
-    ucom = [sum(p[0] * p[1][k] for p in extra_parts) / um for k in range(3)]
+    ucom = [sum(p[0] * p[1][k] for p in extra_parts) / um for k in range(3)] if um > 0 else [0.0, 0.0, 0.0]
     return links, (um, ucom)
 
 
@@ -541,6 +541,8 @@ def main():
     cyl = cylinder_eef_part()
     links3, uncomp3 = make_links([cyl])
     text += emit_variant("ur5e_pp", links3, uncomp3, cyl[1], "Planar-Push: UR5e + CylinderEEF (robot_planar_push.py:81-87)")
+    links4, uncomp4 = make_links([])
+    text += emit_variant("ur5e_bare", links4, uncomp4, body_ipos[NJ], "the UR5e alone, nothing on the flange (test/test_ur_control_api.py:8-9; every body gravity-compensated, robot.py:80-82)")
     text += """
 MJS_DEV void ur5e_dynamics_gen(const double* c, const double* s, const double* qd, double* M, double* bias) {
   ur5e_M_gen(c, s, M);
