@@ -28,7 +28,7 @@ ACTION_ABS_JOINT, ACTION_ABS_EEF = 0, 1
 REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DISTANCE = 0, 1, 2, 3
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
-FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART = 1, 2, 4
+FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART, FAULT_UNSUPPORTED_CONTACT, FAULT_FASTPATH_VIOLATED = 1, 2, 4, 8, 16
 UR_STATE = 34
 UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
 UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1

@@ -437,15 +437,21 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
 }
 
-// can this lane get constraint rows during the next control step? (joint near its range, or the
-// gripper stand-in within reach of the floor / the switch; 0.12 m covers one control step of travel)
-MJS_DEV bool rows_possible(const double* q, const rr::Chain& ch, V3 sw) {
-  bool near = false;
+// can this lane get constraint rows during the next control step? A joint near its range (rr::joint_near_range: 0.6 rad
+// + the distance covered at the current joint velocity), or the gripper stand-in within reach of the floor / the switch:
+// 0.12 m (what the force-clamped servos add within 0.1 s from rest) + the distance the stand-in covers at its CURRENT
+// Cartesian speed |J(q) v| in one control step (mjs_set_state can inject any velocity). The fast path also re-checks its
+// final state (a posteriori, in the kernel): a joint outside its range or a touching stand-in after a row-free step is
+// reported as MJS_FAULT_FASTPATH_VIOLATED.
+MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch, V3 sw) {
+  const V3 c = proxy_centre(ch);
+  V3 vel = v3(0, 0, 0);
 #pragma unroll
-  for (int j = 0; j < NJ; j++) near = near || (q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - q[j] < 0.6);
-  V3 c = proxy_centre(ch);
-  V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
-  return near || c.z < 0.15 || dot(d, d) < 0.2 * 0.2;
+  for (int j = 0; j < NJ; j++) vel += v[j] * cross(rr::joint_axis(ch, j), c - ch.p[j + 1]);
+  const double travel = 0.12 + MJS_RR_CONTROL_DT * sqrt(dot(vel, vel));
+  const V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
+  const double reach = 0.08 + travel;
+  return rr::joint_near_range(q, v) || c.z < 0.03 + travel || dot(d, d) < reach * reach;
 }
 
 // Switch._update_activation (switch.py:51-60)
@@ -621,7 +627,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
   rr::fk_cs(cs, sn, c);
-  const bool maybe_rows = rows_possible(st.q, c, sw);
+  const bool maybe_rows = rows_possible(st.q, st.v, c, sw);
   const bool solo = (ROLES == 1) || __any(maybe_rows);  // both roles: same data, same decision
   if (solo) {
     if (role != 0) return;
@@ -630,7 +636,9 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
     in.time = st.time; in.t0 = t0; in.t1 = t1;
     in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
-    in.flags = flags; in.maybe_rows = maybe_rows;
+    in.flags = flags;
+    in.maybe_rows = true;  // the whole wavefront runs the robust path anyway: detect contacts for every lane of it (a lane's own a-priori
+                           // bound can be exceeded by a far joint target: saturated servos add up to ~0.25 m in one step from rest)
     SoloOut o = solo_control_step(in);
 #pragma unroll
     for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
@@ -717,12 +725,17 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   if (st.time >= p.time_limit) terminate = true;
   // ncon after the step (mj_step1 of the last substep): arm-vs-floor + stand-in sphere contacts
   int ncon = rr::count_floor_contacts(c);
-  if (maybe_rows) {
+  const bool arm_touches_floor = ncon > 0;  // detected and counted, not solved: reported below
+  int ncon_proxy;
+  {
     ContactSet con;
     detect_contacts(proxy_centre(c), sw, con);
+    ncon_proxy = con.n;
     ncon += con.n;
   }
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
+  const bool violated = !solo && (ncon_proxy > 0 || rr::joint_outside_range(st.q));  // a-posteriori check of the row-free path (solo: every lane detects)
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+              (arm_touches_floor ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0));
   rr::store_state(p, i, st);

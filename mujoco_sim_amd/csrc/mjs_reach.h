@@ -799,6 +799,30 @@ MJS_DEV int count_floor_contacts(const Chain& c) {
   return n;
 }
 
+// ---- the fast path's guard ---------------------------------------------------------------------------------------
+// The role-specialised fast path builds no constraint rows. A PRIORI it is only taken when no joint can reach its
+// range during the control step: margin = 0.6 rad (what the force-clamped servos add within 0.1 s from rest) plus the
+// distance the joint covers at its CURRENT velocity, |v| * 0.1 s (mjs_set_state can inject any velocity). A POSTERIORI
+// the final joint positions are re-checked; a violation (never observed; the bound is not a proof) is REPORTED as
+// MJS_FAULT_FASTPATH_VIOLATED for that env and step, so a wrong result is never published silently. (Redoing the step
+// on the robust path from inside the kernel was built and measured: the extra call after the hot loop costs 4.6 us per
+// launch in spills, profiles/r02_e_guard_ab.txt.)
+MJS_DEV bool joint_near_range(const double* q, const double* v) {
+  bool near = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const double margin = 0.6 + MJS_RR_CONTROL_DT * fabs(v[j]);
+    near = near || (q[j] - MJS_UR_JNT_RANGE[j][0] < margin) || (MJS_UR_JNT_RANGE[j][1] - q[j] < margin);
+  }
+  return near;
+}
+MJS_DEV bool joint_outside_range(const double* q) {
+  bool out = false;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) out = out || (q[j] < MJS_UR_JNT_RANGE[j][0]) || (q[j] > MJS_UR_JNT_RANGE[j][1]);
+  return out;
+}
+
 // ---------------------------------------------------------------------------- kernel
 struct State {
   double q[NJ], v[NJ], time, target[3];
@@ -962,9 +986,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   // control step (0.6 rad of travel is far beyond what the clamped servos produce in 0.1 s). Then the
   // whole workgroup takes the robust single-wavefront path, which checks the limits every substep;
   // both roles evaluate the same predicate on the same data, so the decision is consistent.
-  bool near_limit = false;
-#pragma unroll
-  for (int j = 0; j < NJ; j++) near_limit = near_limit || (st.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - st.q[j] < 0.6);
+  const bool near_limit = joint_near_range(st.q, st.v);
   const bool solo = (ROLES == 1) || __any(near_limit);
   if (solo) {
     if (role != 0) return;
@@ -1070,7 +1092,10 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 3);
   int ncon = count_floor_contacts(c);
   MJS_STAMP(p, 4);
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
+  // arm-vs-floor contacts are detected and counted but not solved, and the row-free path assumed that no
+  // joint leaves its range: both are reported, never silent
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+              (ncon > 0 ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!solo && joint_outside_range(st.q)) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
   // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
@@ -1185,10 +1210,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   for (int j = 0; j < NJ; j++) q0[j] = st.q[j];
   // same wave-uniform guard as kernel<false, 2>: a joint within reach of its range sends the whole workgroup to the
   // robust single-wavefront path (every wavefront evaluates it on the same data)
-  bool near_limit = false;
-#pragma unroll
-  for (int j = 0; j < NJ; j++) near_limit = near_limit || (st.q[j] - MJS_UR_JNT_RANGE[j][0] < 0.6) || (MJS_UR_JNT_RANGE[j][1] - st.q[j] < 0.6);
-  const bool solo = __any(near_limit);
+  const bool solo = __any(joint_near_range(st.q, st.v));
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
   bool bad = false, limit_rows_active = false;
@@ -1361,7 +1383,10 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   const bool ncon_here = solo || p.autoreset == MJS_AUTORESET_SAME_STEP;  // otherwise role 1 writes it
   int ncon = ncon_here ? count_floor_contacts(c) : 0;
   MJS_STAMP(p, 4);
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0);
+  // arm-vs-floor contacts are detected and counted but not solved, and the row-free path assumed that no
+  // joint leaves its range: both are reported, never silent
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+              (ncon > 0 ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!solo && joint_outside_range(st.q)) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
   store_state(p, i, st);

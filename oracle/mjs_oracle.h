@@ -171,6 +171,7 @@ typedef struct {
   double switch_pos[3];
   /* Planar-Push: RobotTask.episode_step (base.py:29-32) */
   int episode_step;
+  int dbg_arm_floor_seen; /* test knob, om_debug_arm_floor_seen() */
 } om_env;
 
 void om_default_config(int task, om_task_config* cfg);
@@ -190,6 +191,7 @@ void om_render_camera(const om_env* e, int camera, int H, int W, uint8_t* out);
 void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out);
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
 int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time);
+int om_debug_arm_floor_seen(om_env* e);
 void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);
 void om_debug_substeps(om_env* e, int n);
 int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,

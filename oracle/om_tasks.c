@@ -493,6 +493,9 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     }
     om_physics_step(m, d);
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) switch_update(e); /* Switch.after_substep (switch.py:71-72) */
+    if (e->cfg.task != OM_TASK_POINTMASS) /* test knob: a floor contact of one of the arm's own collision geoms (ids 1..10) */
+      for (int c = 0; c < d->ncon; c++)
+        if (d->contact[c].geom1 == 0 && d->contact[c].geom2 >= 1 && d->contact[c].geom2 <= MJS_UR_NCOLGEOM) e->dbg_arm_floor_seen = 1;
   }
   /* after_step + reward/discount/termination */
   if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.button_disturbances) {
@@ -604,6 +607,14 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
   invw_out[1] = m.body_invweight0[8][1];
   invw_out[2] = m.meaninertia;
   for (int i = 0; i < 6; i++) invw_out[3 + i] = m.dof_invweight0[i];
+}
+
+/* debug hook for tests: did an arm link touch the floor in any substep since the last call? (the HIP kernels detect and count
+ * those contacts but do not solve them, DESIGN.md D-8: tests drop such envs from the comparison) */
+int om_debug_arm_floor_seen(om_env* e) {
+  int r = e->dbg_arm_floor_seen;
+  e->dbg_arm_floor_seen = 0;
+  return r;
 }
 
 /* debug hook for tests: copy out qpos[nq], qvel[nv] and time of an env; returns nq */

@@ -248,6 +248,12 @@ class OracleBatch:
         for i in range(self.n):
             L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
 
+    def arm_floor_seen(self) -> np.ndarray:
+        """debug: per env, did an arm link touch the floor in any substep since the last call (sticky flag, cleared)"""
+        L = lib()
+        L.om_debug_arm_floor_seen.argtypes = [C.c_void_p]
+        return np.array([bool(L.om_debug_arm_floor_seen(L.om_batch_env(self._h, i))) for i in range(self.n)])
+
     def get_state(self):
         """debug: (qpos [N, nq], qvel [N, nv], time [N]) of every env"""
         L = lib()
