@@ -867,7 +867,11 @@ def test_planar_push_parity_with_oracle(oracle_mod):
             o2 = ob2.step(a)
         finally:
             knob.value = 0.0
-        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] != 1) & (o2["step_type"] != 1)  # an episode boundary (FIRST, or LAST whose same-step reset already shows the new episode)
+        # the env re-enters the comparison there, unless its reset (150 settle steps) is itself ill-conditioned: it must
+        # reproduce the 1e-13 perturbation to 1e-12 (amplification < 10) to come back; 1e-10 marks it as before
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
         g = _gpu_result(venv)
         ok = ~sens
         np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
@@ -929,12 +933,17 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
         knob.value = 1e-13
         o2 = ob2.step(a)
         knob.value = 0.0
-        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] != 1) & (o2["step_type"] != 1)  # an episode boundary (FIRST, or LAST whose same-step reset already shows the new episode)
+        # the env re-enters the comparison there, unless its reset (150 settle steps) is itself ill-conditioned: it must
+        # reproduce the 1e-13 perturbation to 1e-12 (amplification < 10) to come back; 1e-10 marks it as before
+        sens_old_episode = sens
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
         g = _gpu_result(venv)
         ok = ~sens
         np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
-        np.testing.assert_allclose(g["reward"][ok], o["reward"][ok], rtol=0, atol=1e-8)
-        ended = (o["step_type"] == 2) & ok
+        np.testing.assert_allclose(g["reward"][ok & ~sens_old_episode], o["reward"][ok & ~sens_old_episode], rtol=0, atol=1e-8)
+        ended = (o["step_type"] == 2) & ok & ~sens_old_episode  # the terminal observation belongs to the episode that just ended
         np.testing.assert_allclose(g["terminal_obs"][ended], o["terminal_obs"][ended], rtol=0, atol=1e-8)
         for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
             assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
@@ -980,7 +989,11 @@ def test_planar_push_many_objects(oracle_mod, n_objects):
         knob.value = 1e-13
         o2 = ob2.step(a)
         knob.value = 0.0
-        sens |= np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] != 1) & (o2["step_type"] != 1)  # an episode boundary (FIRST, or LAST whose same-step reset already shows the new episode)
+        # the env re-enters the comparison there, unless its reset (150 settle steps) is itself ill-conditioned: it must
+        # reproduce the 1e-13 perturbation to 1e-12 (amplification < 10) to come back; 1e-10 marks it as before
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
         g = _gpu_result(venv)
         ok = ~sens
         np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
