@@ -240,7 +240,9 @@ MJS_K double MJS_PP_TARGET_DEFAULT_POS[3] = {0.0, -0.5, 0.001};
 /* block stand-in: box half extents, mass (google_block.py:33), geom centre above the body origin, contact parameters
  * (google_block.py:47-49: condim 4, friction (1, 0.05, 0)) */
 MJS_K double MJS_BLOCK_HALF[3] = {0.019826, 0.019826, 0.01905};
-MJS_K double MJS_BLOCK_MASS = 0.1;
+MJS_K double MJS_BLOCK_MASS = 0.1;                 /* google_block.py:30 */
+MJS_K double MJS_BLOCK_SCALE_LO = 0.8;             /* google_block.py:59: scale_range */
+MJS_K double MJS_BLOCK_SCALE_HI = 1.2;
 MJS_K double MJS_BLOCK_GEOM_Z = 0.01905;
 MJS_K int    MJS_BLOCK_CONDIM = 4;
 MJS_K double MJS_BLOCK_FRICTION[3] = {1.0, 0.05, 0.0};
@@ -310,7 +312,9 @@ MJS_K float MJS_CAM_BODY_RGB[3] = {0.0f, 0.0f, 0.0f};
 MJS_K float MJS_CYL_RGB[3] = {0.2f, 0.2f, 0.2f};
 MJS_K float MJS_PP_TARGET_RGB[3] = {1.0f, 1.0f, 1.0f};
 MJS_K float MJS_PP_TARGET_HALF_HEIGHT = 0.001f;
-MJS_K float MJS_BLOCK_RGB[5][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.5f, 0.0f}};
+MJS_K float MJS_BLOCK_RGB[5][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.5f, 0.0f}}; /* box stand-in: block i */
+/* [REF] google_block.py:12-19 COLORS: red, blue, green, yellow, orange, purple (a mesh block's sampled colour) */
+MJS_K float MJS_BLOCK_COLORS[6][3] = {{1.0f, 0.0f, 0.0f}, {0.0f, 0.0f, 1.0f}, {0.0f, 1.0f, 0.0f}, {1.0f, 1.0f, 0.0f}, {1.0f, 0.5f, 0.0f}, {1.0f, 0.0f, 1.0f}};
 /* [REF] empty_robot_arena.py:24-26: six positional lights at (x, +-x, 3), x in {-3, 3, 0.5} */
 MJS_K float MJS_RR_LIGHT_POS[6][3] = {{-3.0f, -3.0f, 3.0f}, {-3.0f, 3.0f, 3.0f}, {3.0f, 3.0f, 3.0f},
                                       {3.0f, -3.0f, 3.0f},  {0.5f, 0.5f, 3.0f},  {0.5f, -0.5f, 3.0f}};

@@ -83,7 +83,11 @@ typedef struct {
   int32_t n_objects;            /* Planar-Push only: number of blocks, 1..5 (robot_planar_push.py:61; <= 0: 2 = the registered env, :315,
                                  * and BASELINE config 4). 1..2 run the 2-slot kernel, 3..5 the 5-slot kernel */
   int32_t max_episode_steps;    /* Planar-Push only: RobotTask step limit (tasks/base.py:47-51); <= 0: 500 */
+  int32_t block_shape;          /* Planar-Push only: MJS_BLOCKS_MESH (0, the reference: GoogleBlockProp.sample_random_object per episode,
+                                 * google_block.py:55-68, category / colour / scale from the env's seeded stream) or MJS_BLOCKS_BOX (round 1's box
+                                 * stand-in of the cube mesh's bounding box, scale 1: a documented fast variant) */
 } mjs_config;
+enum { MJS_BLOCKS_MESH = 0, MJS_BLOCKS_BOX = 1 };
 
 /* Per-step outputs. Device pointers, caller-owned, any may be NULL.
  * Replaces the (obs, reward, terminated, truncated, info) tuple of

@@ -29,6 +29,7 @@ REW_SPARSE, REW_DENSE_POTENTIAL, REW_DENSE_NEG_DISTANCE, REW_DENSE_BIASED_NEG_DI
 STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART, FAULT_UNSUPPORTED_CONTACT, FAULT_FASTPATH_VIOLATED = 1, 2, 4, 8, 16
+BLOCKS_MESH, BLOCKS_BOX = 0, 1
 UR_STATE = 34
 UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
 UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1
@@ -44,7 +45,7 @@ class MjsConfig(C.Structure):
     _fields_ = [
         ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
-        ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("button_disturbances", C.c_int32), ("n_objects", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("button_disturbances", C.c_int32), ("n_objects", C.c_int32), ("max_episode_steps", C.c_int32), ("block_shape", C.c_int32),
     ]
 
 

@@ -55,9 +55,14 @@ __device__ inline uint32_t rng_u32(const DevRng& r, int i, RngCursor& c) {
   y ^= y >> 18;
   return y;
 }
-// RandomState.uniform(lo, hi) = lo + (hi - lo) * ((a >> 5) * 2^26 + (b >> 6)) / 2^53
+// RandomState.uniform(lo, hi) = lo + (hi - lo) * ((a >> 5) * 2^26 + (b >> 6)) / 2^53. numpy rounds the product and the sum
+// separately: no FMA contraction here (HIP's __dmul_rn / __dadd_rn are plain operators and do not prevent it; a contracted
+// 0.8 + 0.4 u differs from numpy in the last bit for ~1 draw in 10)
+#pragma clang fp contract(off)
 __device__ inline double rng_uniform(const DevRng& r, int i, RngCursor& c, double lo, double hi) {
   uint32_t a = rng_u32(r, i, c) >> 5, b = rng_u32(r, i, c) >> 6;
-  double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
-  return lo + (hi - lo) * u;
+  double u = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;  // exact: a 2^26 + b < 2^53
+  const double span = hi - lo, prod = span * u;
+  return lo + prod;
 }
+#pragma clang fp contract(on)

@@ -5,6 +5,7 @@
 
 #include "../../include/mjsim.h"
 #include "../../include/mjs_scene_spec.h"
+#include "../../include/mjs_block_hulls.h"
 #include "mjs_dev_math.h"
 #include "mjs_dev_rng.h"
 
@@ -20,6 +21,7 @@ struct KernelParams {
   int button_disturbances;
   int n_objects;          // Planar-Push
   int max_episode_steps;  // Planar-Push
+  int block_shape;        // Planar-Push: MJS_BLOCKS_MESH / MJS_BLOCKS_BOX
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]

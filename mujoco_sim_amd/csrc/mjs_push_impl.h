@@ -8,9 +8,13 @@
 //   per substep robot.py:261-263 servo interpolation + Physics.step() on the scene of :81-117 (UR5e + CylinderEEF +
 //   n free blocks on the floor), :203-241 + tasks/base.py:47-57 reward / accomplished / step limit / discount,
 //   :149-176 initialize_episode (robot, target, blocks re-drawn until nothing touches, 150 settle steps).
-// Deviation D-9: the blocks are BOXES of the cube mesh's bounding box (google_block.py loads a bevelled-cube mesh);
-// convex pairs (cylinder-box, box-box) go through an own MPR (role of mjc_Convex -> libccd), one contact per pair;
-// box-floor gives up to 4 corner contacts. Contacts are condim 4 (block) pyramids: 6 rows each.
+// Blocks (google_block.py:37-68): one of the reference's four meshes (cube / moon / pentagon / star), collided by its
+// convex hull (include/mjs_block_hulls.h, generated from the reference's .obj files), category / colour / scale in
+// [0.8, 1.2] drawn per episode from the env's seeded stream (deviation D-5), mass 0.1 kg, inertia of the closed mesh;
+// block_shape = box keeps round 1's stand-in (a box of the cube mesh's bounding box, scale 1) as a fast variant.
+// Convex pairs (cylinder-hull, hull-hull) go through an own MPR (role of mjc_Convex -> libccd), one contact per pair;
+// hull-floor gives up to 4 vertex contacts (first four hull vertices at or below the plane in the table's
+// farthest-point order; box: mjc_PlaneBox's corner order). Contacts are condim 4 (block) pyramids: 6 rows each.
 //
 // First correct version: lane per env, one wavefront per 64 envs, generic dense in-lane Newton over nv = 6 + 6 n
 // dofs with the rows in per-lane scratch arrays. The arm's M and bias come from the generated code (ur5e_pp_*),
@@ -22,7 +26,8 @@ using rr::NJ;
 constexpr int NB = MJS_PP_NB, NV = NJ + 6 * NB;
 constexpr int OBS_DIM = 5 + 2 * NB, ACT_DIM = 2;
 // state rows (float64 SoA): arm q, v, time, target xyz, episode_step, then per block pos3 quat4 vel6
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK = 17, BLOCK_DIM = 13;
+// per block: pos3 quat4 vel6, then shape code (-1 = box stand-in, else category + 8 * colour) and mesh scale
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK = 17, BLOCK_DIM = 15;
 constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
 constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
 constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
@@ -49,7 +54,42 @@ struct Block {
   V3 p;          // body origin = centre of the bottom face (free joint qpos[0:3])
   double q[4];   // orientation (w, x, y, z)
   V3 v, w;       // linear velocity of the origin (world), angular velocity (body frame)
+  double shape, scale;  // shape code (-1 = box stand-in, else category + 8 * colour), mesh scale: constant within an episode
 };
+// what the dynamics and the collision code need to know about a block's shape
+struct Shape {
+  int cat;               // -1 = box stand-in, else hull category
+  double scale;
+  V3 c;                  // centre of mass in the body frame
+  double Ixx, Iyy, Izz;  // inertia about the COM, diagonal in the body axes
+  double rbound;         // bounding radius about the COM
+};
+static_assert(MJS_HULL_NCAT == 4, "shape code: category in bits 0-1 (always a valid table index), colour from bit 3 up");
+MJS_DEV Shape shape_of(const Block& b) {
+  Shape sh;
+  if (b.shape < 0.0) {
+    sh.cat = -1; sh.scale = 1.0;
+    sh.c = v3(0, 0, MJS_BLOCK_GEOM_Z);
+    sh.Ixx = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+    sh.Iyy = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
+    sh.Izz = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1]) / 3;
+    sh.rbound = sqrt(MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]);
+  } else {
+    const int cat = ((int)b.shape) & 3;
+    const double sc = b.scale;
+    sh.cat = cat; sh.scale = sc;
+    sh.c = v3(MJS_HULL_COM[cat][0] * sc, MJS_HULL_COM[cat][1] * sc, MJS_HULL_COM[cat][2] * sc);
+    sh.Ixx = MJS_BLOCK_MASS * MJS_HULL_INERTIA_PER_MASS[cat][0] * sc * sc;
+    sh.Iyy = MJS_BLOCK_MASS * MJS_HULL_INERTIA_PER_MASS[cat][1] * sc * sc;
+    sh.Izz = MJS_BLOCK_MASS * MJS_HULL_INERTIA_PER_MASS[cat][2] * sc * sc;
+    sh.rbound = MJS_HULL_RBOUND[cat] * sc;
+  }
+  return sh;
+}
+// a free body's share of mj_setConst's meaninertia (sum of the diagonal of M at qpos0): 3 m + tr(I_c) + 2 m |c|^2
+MJS_DEV double shape_inertia_trace(const Shape& sh) {
+  return 3 * MJS_BLOCK_MASS + sh.Ixx + sh.Iyy + sh.Izz + 2 * MJS_BLOCK_MASS * dot(sh.c, sh.c);
+}
 struct World {
   double q[NJ], v[NJ], time, target[3], episode_step;
   Block b[NB];
@@ -73,6 +113,7 @@ MJS_DEV World load_world(const KernelParams& p, int i) {
     for (int k = 0; k < 4; k++) s.b[b].q[k] = bs[(3 + k) * N];
     s.b[b].v = v3(bs[7 * N], bs[8 * N], bs[9 * N]);
     s.b[b].w = v3(bs[10 * N], bs[11 * N], bs[12 * N]);
+    s.b[b].shape = bs[13 * N]; s.b[b].scale = bs[14 * N];
   }
   return s;
 }
@@ -93,6 +134,7 @@ MJS_DEV void store_world(const KernelParams& p, int i, const World& s) {
     for (int k = 0; k < 4; k++) bs[(3 + k) * N] = s.b[b].q[k];
     bs[7 * N] = s.b[b].v.x; bs[8 * N] = s.b[b].v.y; bs[9 * N] = s.b[b].v.z;
     bs[10 * N] = s.b[b].w.x; bs[11 * N] = s.b[b].w.y; bs[12 * N] = s.b[b].w.z;
+    bs[13 * N] = s.b[b].shape; bs[14 * N] = s.b[b].scale;
   }
 }
 
@@ -112,12 +154,14 @@ MJS_DEV V3 rot_t(const M3& R, V3 a) { return v3(dot(R.cx, a), dot(R.cy, a), dot(
 // biased tie-break thresholds, identical to oracle/om_engine.c (see the comment there)
 constexpr double MPR_EPS_DIR = 1e-10, MPR_EPS_LEN = 1e-13, MPR_EPS_VOL = 1e-16;
 
-struct Geom {  // a convex collision geom in the world: box (half extents s) or cylinder (radius s.x, half length s.y)
-  V3 c;
+struct Geom {  // a convex collision geom in the world: box (half extents s), cylinder (radius s.x, half length s.y) or the
+  V3 c;        // convex hull of a block mesh (category cat, scale s.x, vertices relative to the COM = the geom centre c)
   M3 R;
   V3 s;
   bool box;
+  int cat;     // >= 0: hull
 };
+constexpr double MPR_EPS_TIE = 1e-12;  // hull vertices whose projections differ by less are tied: the first in table order wins
 struct Contact {
   double dist;
   V3 pos, n;
@@ -128,7 +172,26 @@ struct Contact {
 MJS_DEV V3 support(const Geom& g, V3 dir) {
   const V3 loc = rot_t(g.R, dir);
   V3 res;
-  if (g.box) {
+  if (g.cat >= 0) {
+    // hull vertex with the largest projection on the direction; structural ties (a face or an edge square to the direction) go
+    // to the FIRST vertex in table order among those within MPR_EPS_TIE of the maximum, whatever the rounding noise
+    const int nvx = MJS_HULL_NV[g.cat];
+    const double sc = g.s.x;
+    double best = -1e300;
+    for (int i = 0; i < nvx; i++) {
+      const double vx = (MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * sc, vy = (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * sc,
+                   vz = (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * sc;
+      const double pr = loc.x * vx + loc.y * vy + loc.z * vz;
+      if (pr > best) best = pr;
+    }
+    res = v3(0, 0, 0);
+    for (int i = nvx - 1; i >= 0; i--) {
+      const double vx = (MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * sc, vy = (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * sc,
+                   vz = (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * sc;
+      const double pr = loc.x * vx + loc.y * vy + loc.z * vz;
+      if (pr >= best - MPR_EPS_TIE) res = v3(vx, vy, vz);
+    }
+  } else if (g.box) {
     res = v3(loc.x >= -MPR_EPS_DIR ? g.s.x : -g.s.x, loc.y >= -MPR_EPS_DIR ? g.s.y : -g.s.y, loc.z >= -MPR_EPS_DIR ? g.s.z : -g.s.z);
   } else {
     const double len = sqrt(loc.x * loc.x + loc.y * loc.y);
@@ -220,7 +283,9 @@ __device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, dou
   }
   return false;
 }
-MJS_DEV double rbound(const Geom& g) { return g.box ? sqrt(g.s.x * g.s.x + g.s.y * g.s.y + g.s.z * g.s.z) : sqrt(g.s.x * g.s.x + g.s.y * g.s.y); }
+MJS_DEV double rbound(const Geom& g) {
+  return g.cat >= 0 ? MJS_HULL_RBOUND[g.cat] * g.s.x : g.box ? sqrt(g.s.x * g.s.x + g.s.y * g.s.y + g.s.z * g.s.z) : sqrt(g.s.x * g.s.x + g.s.y * g.s.y);
+}
 MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, double tran, Contact& c) {
   const V3 diff = sub_nc(g2.c, g1.c);
   const double bound = rbound(g1) + rbound(g2);
@@ -235,17 +300,40 @@ MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, doub
 MJS_DEV Geom block_geom(const Block& b, const M3& R) {
   Geom g;
   g.R = R;
-  const double gz = MJS_BLOCK_GEOM_Z;  // geom_xpos = xpos + xmat * geom_pos
-  g.c = v3(b.p.x + R.cz.x * gz, b.p.y + R.cz.y * gz, b.p.z + R.cz.z * gz);
-  g.s = v3(MJS_BLOCK_HALF[0], MJS_BLOCK_HALF[1], MJS_BLOCK_HALF[2]);
-  g.box = true;
+  if (b.shape < 0.0) {
+    const double gz = MJS_BLOCK_GEOM_Z;  // geom_xpos = xpos + xmat * geom_pos
+    g.c = v3(b.p.x + R.cz.x * gz, b.p.y + R.cz.y * gz, b.p.z + R.cz.z * gz);
+    g.s = v3(MJS_BLOCK_HALF[0], MJS_BLOCK_HALF[1], MJS_BLOCK_HALF[2]);
+    g.box = true;
+    g.cat = -1;
+  } else {  // a mesh geom's frame sits at the mesh's centre of mass: geom_pos = COM * scale
+    const int cat = ((int)b.shape) & 3;
+    const double sc = b.scale;
+    const double cx = MJS_HULL_COM[cat][0] * sc, cy = MJS_HULL_COM[cat][1] * sc, cz = MJS_HULL_COM[cat][2] * sc;
+    g.c = v3(b.p.x + (R.cx.x * cx + R.cy.x * cy + R.cz.x * cz), b.p.y + (R.cx.y * cx + R.cy.y * cy + R.cz.y * cz), b.p.z + (R.cx.z * cx + R.cy.z * cy + R.cz.z * cz));
+    g.s = v3(sc, sc, sc);
+    g.box = false;
+    g.cat = cat;
+  }
   return g;
 }
-// mjc_PlaneBox against the floor z = 0: corners at or below the plane, at most 4, x index fastest
+// local coordinates (geom frame) of the k-th floor-contact candidate of a block geom and how many there are: the 8 corners
+// of the box in mjc_PlaneBox's order (x index fastest), or the hull's vertices in the table's farthest-point order
+MJS_DEV int floor_candidates(const Geom& g) { return g.cat >= 0 ? MJS_HULL_NV[g.cat] : 8; }
+MJS_DEV V3 floor_candidate(const Geom& g, int i) {
+  if (g.cat >= 0)
+    return v3((MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * g.s.x, (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * g.s.x,
+              (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * g.s.x);
+  return v3((i & 1) ? g.s.x : -g.s.x, (i & 2) ? g.s.y : -g.s.y, (i & 4) ? g.s.z : -g.s.z);
+}
+// mjc_PlaneBox against the floor z = 0: corners at or below the plane, at most 4, x index fastest (hull: the same rule on
+// its vertices in table order)
 MJS_DEV int floor_box(const Geom& g, int bb, Contact* out) {
   int cnt = 0;
-  for (int i = 0; i < 8 && cnt < 4; i++) {
-    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+  const int ncand = floor_candidates(g);
+  for (int i = 0; i < ncand && cnt < 4; i++) {
+    const V3 lc = floor_candidate(g, i);
+    const double lx = lc.x, ly = lc.y, lz = lc.z;
     const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
                          g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
     const double dist = corner.z;  // (corner - plane pos) . n with n = +z, plane through the origin
@@ -268,6 +356,7 @@ MJS_DEV Geom eef_geom(const rr::Chain& ch) {  // CylinderEEF: axis = flange z = 
   g.c = madd(ch.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_POS_Z, R6.cy);
   g.s = v3(MJS_CYL_RADIUS, MJS_CYL_HALFLEN, 0);
   g.box = false;
+  g.cat = -1;
   return g;
 }
 MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collision proxy is a CYLINDER (MJS_UR_COL_* index 9):
@@ -278,6 +367,7 @@ MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collisi
   g.c = madd(madd(madd(ch.p[6], MJS_UR_COL_POS[G][0], R6.cx), MJS_UR_COL_POS[G][1], R6.cy), MJS_UR_COL_POS[G][2], R6.cz);
   g.s = v3(MJS_UR_COL_SIZE[G][0], MJS_UR_COL_SIZE[G][1], 0);
   g.box = false;
+  g.cat = -1;
   return g;
 }
 MJS_DEV V3 eef_tcp_position(const rr::Chain& c) { return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_CYL_TCP_Z, c.R[6].cy); }
@@ -293,14 +383,16 @@ MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
   FloorSlots fs;
 #pragma unroll
   for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
-  int rank = 0;  // number of detected corners so far
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    const double lx = (i & 1) ? g.s.x : -g.s.x, ly = (i & 2) ? g.s.y : -g.s.y, lz = (i & 4) ? g.s.z : -g.s.z;
+  int rank = 0;  // number of detected corners / vertices so far
+  const int ncand = floor_candidates(g);
+#pragma unroll 1
+  for (int i = 0; i < ncand && rank < 4; i++) {
+    const V3 lc = floor_candidate(g, i);
+    const double lx = lc.x, ly = lc.y, lz = lc.z;
     const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
                          g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
     const double dist = corner.z;
-    const bool hit = !(dist > 0.0) && rank < 4;
+    const bool hit = !(dist > 0.0);
     const V3 r = v3(corner.x - origin.x, corner.y - origin.y, (corner.z - dist * 0.5) - origin.z);
 #pragma unroll
     for (int k = 0; k < 4; k++)
@@ -359,19 +451,17 @@ MJS_DEV int detect_contacts(const rr::Chain& ch, const World& s, const M3* Rb, i
 }
 
 // ------------------------------------------------------------------------------------------------ dynamics
-// Free block, generalised velocity (v_origin in the world, w in the body frame), COM at c_l = (0, 0, gz) in the body:
-//   M = [[m I, -m R C], [m C R^T, I_c - m C C]],  C = [c_l]x
-//   smooth force = -( m R (w x (w x c_l)) - m g ;  w x I_c w + m c_l x (w x (w x c_l)) - m c_l x R^T g )
-constexpr double BLK_IXX = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
-constexpr double BLK_IYY = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[2] * MJS_BLOCK_HALF[2]) / 3;
-constexpr double BLK_IZZ = MJS_BLOCK_MASS * (MJS_BLOCK_HALF[0] * MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] * MJS_BLOCK_HALF[1]) / 3;
-constexpr double BLK_INVW_TRAN = 1.0 / MJS_BLOCK_MASS, BLK_INVW_ROT = (1.0 / BLK_IXX + 1.0 / BLK_IYY + 1.0 / BLK_IZZ) / 3;
-MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
+// Free block, generalised velocity (v_origin in the world, w in the body frame), COM at c in the body frame, inertia I_c about
+// the COM diagonal in the body axes (Shape):
+//   M = [[m I, -m R C], [m C R^T, I_c - m C C]],  C = [c]x
+//   smooth force = -( m R (w x (w x c)) - m g ;  w x I_c w + m c x (w x (w x c)) - m c x R^T g )
+constexpr double BLK_INVW_TRAN = 1.0 / MJS_BLOCK_MASS;
+MJS_DEV void block_smooth_force(const M3& R, V3 w, const Shape& sh, double* f) {
   const double m = MJS_BLOCK_MASS;
-  const V3 c = v3(0, 0, MJS_BLOCK_GEOM_Z), grav = v3(0, 0, MJS_GRAVITY_Z);
+  const V3 c = sh.c, grav = v3(0, 0, MJS_GRAVITY_Z);
   const V3 wwc = cross(w, cross(w, c));
   const V3 lin = m * rot(R, wwc) - m * grav;
-  const V3 Iw = v3(BLK_IXX * w.x, BLK_IYY * w.y, BLK_IZZ * w.z);
+  const V3 Iw = v3(sh.Ixx * w.x, sh.Iyy * w.y, sh.Izz * w.z);
   const V3 ang = cross(w, Iw) + m * cross(c, wwc) - m * cross(c, rot_t(R, grav));
   f[0] = -lin.x; f[1] = -lin.y; f[2] = -lin.z; f[3] = -ang.x; f[4] = -ang.y; f[5] = -ang.z;
 }
@@ -382,27 +472,33 @@ MJS_DEV void block_smooth_force(const M3& R, V3 w, double* f) {
 // (0, axis_d . n) for the torsional row. Solved by quad_block_floor below. Cold start at qacc_smooth: a warm start from
 // the previous substep's accelerations (mjData.qacc_warmstart; tried per component) needed MORE Newton iterations
 // (2.4 -> 3.8 per coupled solve) and moved hand-set scenarios by the solver tolerance (5e-10) instead of 1e-16.
-// x = M^-1 f for a block in closed form: with the 3x3 blocks M = [[m I, B], [B^T, D]], B = m g (-R.cy, R.cx, 0) and
-// D = diag(Ixx + m g^2, Iyy + m g^2, Izz), the Schur complement D - B^T B / m is diag(Ixx, Iyy, Izz): no factorisation
-MJS_DEV void block_minv(const M3& R, const double* f, double* x) {
-  const double g = MJS_BLOCK_GEOM_Z;
+// x = M^-1 f for a block in closed form: with the 3x3 blocks M = [[m I, B], [B^T, D]], B = -m R C and D = I_c - m C C, the
+// Schur complement D - B^T B / m is I_c = diag(Ixx, Iyy, Izz) for ANY c: alpha = I_c^-1 (f_ang - c x R^T f_lin),
+// a = f_lin / m + R (c x alpha): no factorisation
+MJS_DEV void block_minv(const M3& R, const Shape& sh, const double* f, double* x) {
   const V3 fl = v3(f[0], f[1], f[2]);
-  const double ax = (f[3] + g * dot(R.cy, fl)) * (1.0 / BLK_IXX), ay = (f[4] - g * dot(R.cx, fl)) * (1.0 / BLK_IYY), az = f[5] * (1.0 / BLK_IZZ);
-  const V3 a = madd(madd((1.0 / MJS_BLOCK_MASS) * fl, g * ax, R.cy), -g * ay, R.cx);
+  const V3 cu = cross(sh.c, rot_t(R, fl));
+  const double ax = (f[3] - cu.x) / sh.Ixx, ay = (f[4] - cu.y) / sh.Iyy, az = (f[5] - cu.z) / sh.Izz;
+  const V3 a = (1.0 / MJS_BLOCK_MASS) * fl + rot(R, cross(sh.c, v3(ax, ay, az)));
   x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = ax; x[4] = ay; x[5] = az;
 }
-MJS_DEV void block_mass_matrix6(const M3& R, double (*M)[6]) {  // lower triangle + the coupling block both ways
-  const double m = MJS_BLOCK_MASS, g = MJS_BLOCK_GEOM_Z;
+MJS_DEV void block_mass_matrix6(const M3& R, const Shape& sh, double (*M)[6]) {  // full symmetric matrix
+  const double m = MJS_BLOCK_MASS;
+  const V3 c = sh.c;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
 #pragma unroll
     for (int j = 0; j < 6; j++) M[i][j] = 0;
   }
   M[0][0] = M[1][1] = M[2][2] = m;
-  M[3][3] = BLK_IXX + m * g * g; M[4][4] = BLK_IYY + m * g * g; M[5][5] = BLK_IZZ;
-  const V3 cx = (-m * g) * R.cy, cy = (m * g) * R.cx;
-  M[3][0] = M[0][3] = cx.x; M[3][1] = M[1][3] = cx.y; M[3][2] = M[2][3] = cx.z;
-  M[4][0] = M[0][4] = cy.x; M[4][1] = M[1][4] = cy.y; M[4][2] = M[2][4] = cy.z;
+  const double c2 = dot(c, c);
+  M[3][3] = sh.Ixx + m * (c2 - c.x * c.x); M[4][4] = sh.Iyy + m * (c2 - c.y * c.y); M[5][5] = sh.Izz + m * (c2 - c.z * c.z);
+  M[4][3] = M[3][4] = -m * c.x * c.y; M[5][3] = M[3][5] = -m * c.x * c.z; M[5][4] = M[4][5] = -m * c.y * c.z;
+  // B = -m R C, column d = -m R (C e_d): C e_0 = (0, cz, -cy), C e_1 = (-cz, 0, cx), C e_2 = (cy, -cx, 0)
+  const V3 b0 = (-m) * (c.z * R.cy - c.y * R.cz), b1 = (-m) * (c.x * R.cz - c.z * R.cx), b2 = (-m) * (c.y * R.cx - c.x * R.cy);
+  M[3][0] = M[0][3] = b0.x; M[3][1] = M[1][3] = b0.y; M[3][2] = M[2][3] = b0.z;
+  M[4][0] = M[0][4] = b1.x; M[4][1] = M[1][4] = b1.y; M[4][2] = M[2][4] = b1.z;
+  M[5][0] = M[0][5] = b2.x; M[5][1] = M[1][5] = b2.y; M[5][2] = M[2][5] = b2.z;
 }
 
 // ---- the decoupled case, lane-parallel -------------------------------------------------------------------------
@@ -422,13 +518,13 @@ MJS_DEV double quad_sum(double x) {
   x += dpp_f64<0x4E>(x);  // quad_perm [2, 3, 0, 1]
   return x;
 }
-MJS_DEV void quad_block_floor(const M3 R, const double* qvel, const double* f, bool on, double dist, V3 r, double meaninertia, int nv_total, double* f_out) {
+MJS_DEV void quad_block_floor(const M3 R, const Shape& sh, const double* qvel, const double* f, bool on, double dist, V3 r, double meaninertia, int nv_total, double* f_out) {
   const double mu[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[1]};
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
   const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
   const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
   double Mb[6][6];
-  block_mass_matrix6(R, Mb);
+  block_mass_matrix6(R, sh, Mb);
   double Jc[4][6], aref[6];  // this lane's corner: rows normal, t1, t2, torsion (frame of n = +z as in solve_block_floor)
   const V3 axs[3] = {R.cx, R.cy, R.cz};
 #pragma unroll
@@ -460,7 +556,7 @@ MJS_DEV void quad_block_floor(const M3 R, const double* qvel, const double* f, b
   }
   double a[6], a_s[6], Ma[6], jar[6], force[6];
   bool act[6];
-  block_minv(R, f, a_s);
+  block_minv(R, sh, f, a_s);
 #pragma unroll
   for (int i = 0; i < 6; i++) a[i] = a_s[i];
 #pragma unroll
@@ -633,6 +729,7 @@ struct CoopLds {
   // the sub-system being solved: the bodies with an active arm-block / block-block contact or joint-limit row; its
   // dofs are packed (arm first when present). off[0] = arm offset (0) or -1, off[1 + b] = offset of block b or -1.
   int nv, off[NB + 1];
+  double meaninertia;  // mj_setConst's statistic of the owner env's model (depends on its blocks' shapes)
   double jtf[NV];  // J^T force accumulator of the compact-row instance
   // problem description written by the owner lane; the rows are then built by all lanes
   int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
@@ -649,7 +746,7 @@ MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[thre
 // exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
 // cooperative solver, which runs after it
 struct QuadIn {
-  double R[9], qv[6], f[6], dist[4], r[4][3];
+  double R[9], qv[6], f[6], dist[4], r[4][3], shape, scale, meaninertia;
   int on[4], need;
 };
 struct QuadLds {
@@ -1030,8 +1127,9 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
 MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
-                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in) {
+                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in, double meaninertia) {
   CoopLds& sh = coop_lds();
+  sh.meaninertia = meaninertia;
   int off[NB + 1], nvs = arm_in ? NJ : 0;
   off[0] = arm_in ? 0 : -1;
 #pragma unroll
@@ -1096,8 +1194,9 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
     if (off[1 + b] < 0) continue;
     const int o = off[1 + b];
     double Mb[6][6], f[6];
-    block_mass_matrix6(Rb[b], Mb);
-    block_smooth_force(Rb[b], s.b[b].w, f);
+    const Shape shp = shape_of(s.b[b]);
+    block_mass_matrix6(Rb[b], shp, Mb);
+    block_smooth_force(Rb[b], s.b[b].w, shp, f);
     for (int i = 0; i < 6; i++) {
       for (int j = 0; j < 6; j++) sh.M[o + i][o + j] = Mb[i][j];
       sh.qs[o + i] = f[i];
@@ -1224,12 +1323,9 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
   }
 }
 MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const double* sn, const double* Marm, int nb, double* qacc, StepInfo& info,
-                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in) {
+                          const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in, double meaninertia) {
   CoopLds& sh = coop_lds();
   const int lane = threadIdx.x & 63, nv_all = NJ + 6 * nb;
-  // mj_solPrimal's stopping rules are scaled by the WHOLE model (meaninertia, nv), also when a sub-system is solved
-  const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv_all;
-  const double scale = 1 / (meaninertia * nv_all);
   unsigned long long todo = __ballot(need);
   while (todo) {  // wave-uniform loop over the lanes whose env needs the coupled solve
     const int owner = __ffsll((long long)todo) - 1;
@@ -1238,8 +1334,10 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
-    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in);
+    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in, meaninertia);
     MJS_WAVE_SYNC();
+    // mj_solPrimal's stopping rules are scaled by the WHOLE model (meaninertia, nv) of the owner env, also when a sub-system is solved
+    const double scale = 1 / (sh.meaninertia * nv_all);
     PP_ACC(info, 5, tp);
     PP_TIC(tp);
     coop_build_rows(sh, lane);
@@ -1365,14 +1463,19 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   if (coupled) info.rows_active = true;
 #pragma unroll
   for (int b = 0; b < NB; b++)
-    if (b < nb) block_smooth_force(Rb[b], s.b[b].w, qacc + NJ + 6 * b);
+    if (b < nb) block_smooth_force(Rb[b], s.b[b].w, shape_of(s.b[b]), qacc + NJ + 6 * b);
   }  // live
+  // mj_setConst's meaninertia of THIS env's model: the arm's share + every block's (shape-dependent) share
+  double meaninertia = UR5E_PP_MEANINERTIA * NJ;
+#pragma unroll
+  for (int b = 0; b < NB; b++)
+    if (b < nb) meaninertia += shape_inertia_trace(shape_of(s.b[b]));
+  meaninertia /= nv;
   // decoupled case (nothing but floor contacts): every block with its corner contacts is an independent 6-dof problem,
   // solved by a quad of lanes (quad_block_floor). Env lanes publish, all lanes solve, env lanes collect.
   {
     QuadLds& qx = quad_lds();
     const int lane = threadIdx.x & 63;
-    const double meaninertia = (UR5E_PP_MEANINERTIA * NJ + nb * (3 * MJS_BLOCK_MASS + BLK_IXX + BLK_IYY + 2 * MJS_BLOCK_MASS * MJS_BLOCK_GEOM_Z * MJS_BLOCK_GEOM_Z + BLK_IZZ)) / nv;
     if (lane < EPW) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
@@ -1381,6 +1484,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
         in.need = need;
         if (need) {
           info.rows_active = true;
+          in.shape = s.b[b].shape; in.scale = s.b[b].scale; in.meaninertia = meaninertia;
           in.R[0] = Rb[b].cx.x; in.R[1] = Rb[b].cx.y; in.R[2] = Rb[b].cx.z; in.R[3] = Rb[b].cy.x; in.R[4] = Rb[b].cy.y; in.R[5] = Rb[b].cy.z;
           in.R[6] = Rb[b].cz.x; in.R[7] = Rb[b].cz.y; in.R[8] = Rb[b].cz.z;
           in.qv[0] = s.b[b].v.x; in.qv[1] = s.b[b].v.y; in.qv[2] = s.b[b].v.z; in.qv[3] = s.b[b].w.x; in.qv[4] = s.b[b].w.y; in.qv[5] = s.b[b].w.z;
@@ -1405,7 +1509,9 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
         double qv[6], f[6], out[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) { qv[k] = in.qv[k]; f[k] = in.f[k]; }
-        quad_block_floor(R, qv, f, in.on[c] != 0, in.dist[c], v3(in.r[c][0], in.r[c][1], in.r[c][2]), meaninertia, nv, out);
+        Block shp_src;
+        shp_src.shape = in.shape; shp_src.scale = in.scale;
+        quad_block_floor(R, shape_of(shp_src), qv, f, in.on[c] != 0, in.dist[c], v3(in.r[c][0], in.r[c][1], in.r[c][2]), in.meaninertia, nv, out);
         if (c == 0) {
 #pragma unroll
           for (int k = 0; k < 6; k++) qx.out[e][b][k] = out[k];
@@ -1424,7 +1530,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     MJS_WAVE_SYNC();  // the cooperative solver reuses the area
   }
   PP_ACC(info, 2, tt);
-  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb, arm_in, blk_in);  // all lanes
+  coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb, arm_in, blk_in, meaninertia);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
@@ -1447,7 +1553,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (b >= nb) continue;
     const int o = NJ + 6 * b;
     double x[6];
-    block_minv(Rb[b], qacc + o, x);
+    block_minv(Rb[b], shape_of(s.b[b]), qacc + o, x);
 #pragma unroll
     for (int i = 0; i < 6; i++) { qacc[o + i] = x[i]; acc2 = fma(x[i], x[i], acc2); }
   }
@@ -1529,9 +1635,22 @@ MJS_DEV void make_obs(const World& s, const double* cs, const double* sn, int nb
 
 // initialize_episode (robot_planar_push.py:149-176, intended semantics), first part: the draws. The 150 settle steps
 // run in the kernel's uniform substep loop. `commit` = false leaves the env's RNG stream untouched (padding lanes).
-__device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, bool commit) {
+__device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, bool commit, bool mesh_blocks) {
   RngCursor c = rng_open(rng, i);
   double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
+  // initialize_episode_mjcf (robot_planar_push.py:144-147,163-167) comes first: every block is replaced by
+  // GoogleBlockProp.sample_random_object() (google_block.py:55-68): category, colour, scale in [0.8, 1.2]; three uniforms per block
+  // from the env's seeded stream (deviation D-5: the reference uses Python's unseeded global `random`)
+  for (int b = 0; b < NB; b++) { s.b[b].shape = -1.0; s.b[b].scale = 1.0; }
+  if (mesh_blocks) {
+    for (int b = 0; b < nb; b++) {
+      int cat = (int)rng_uniform(rng, i, c, 0.0, (double)MJS_HULL_NCAT), col = (int)rng_uniform(rng, i, c, 0.0, 6.0);
+      cat = cat < MJS_HULL_NCAT ? cat : MJS_HULL_NCAT - 1;
+      col = col < 6 ? col : 5;
+      s.b[b].shape = (double)(cat + 8 * col);
+      s.b[b].scale = rng_uniform(rng, i, c, MJS_BLOCK_SCALE_LO, MJS_BLOCK_SCALE_HI);
+    }
+  }
   for (int k = 0; k < 3; k++) rp[k] = rng_uniform(rng, i, c, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
   const bool ok = tcp_to_joints(rp, zeros, q);
   for (int j = 0; j < NJ; j++) { s.q[j] = ok ? q[j] : 0.0; s.v[j] = 0; }
@@ -1571,7 +1690,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
   double t0 = 0, t1 = 1, inv_span = 1;
   int nsub = 0;
   if (resetting) {
-    episode_draws(p.rng, i, nb, s, valid);
+    episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
     nsub = MJS_PP_SETTLE_STEPS;
     for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189)
   } else if (stepping) {
@@ -1658,7 +1777,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     if (again) {
       if (valid && p.out.terminal_obs)
         for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
-      episode_draws(p.rng, i, nb, s, valid);
+      episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
       for (int j = 0; j < NJ; j++) { ctrl0[j] = s.q[j]; sincos(s.q[j], &sn[j], &cs[j]); }
     }
     StepInfo info2{false, false, false, 0};

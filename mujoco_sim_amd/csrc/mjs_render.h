@@ -379,11 +379,25 @@ __global__ __launch_bounds__(64) void push_prims_kernel(const double* state, flo
     const M3 R = pp::quat_to_m3(qn);
     const V3 origin = v3(bs[0], bs[(size_t)N], bs[2 * (size_t)N]);
     pr[0] = (float)PRIM_BOX;
-    put3(pr + 1, b < nb ? madd(origin, MJS_BLOCK_GEOM_Z, R.cz) : v3(0, 0, -10.0));  // unused slot: out of sight
     put3(pr + 4, R.cx); put3(pr + 7, R.cy);
-    pr[10] = (float)MJS_BLOCK_HALF[0]; pr[11] = (float)MJS_BLOCK_HALF[1]; pr[12] = (float)MJS_BLOCK_HALF[2];
-    pr[17] = bound_radius((float)(MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2]));
-    put_rgb(pr + 14, MJS_BLOCK_RGB[b]);
+    const double shape = bs[13 * (size_t)N], sc = bs[14 * (size_t)N];
+    if (shape >= 0.0 && b < nb) {
+      // a mesh block is drawn as the bounding box of its hull (scaled), in its sampled colour (D-6: own ray caster)
+      const int cat = ((int)shape) & 3, col = ((int)shape) >> 3;
+      const double bx = 0.5 * (MJS_HULL_BOX_LO[cat][0] + MJS_HULL_BOX_HI[cat][0]) * sc, by = 0.5 * (MJS_HULL_BOX_LO[cat][1] + MJS_HULL_BOX_HI[cat][1]) * sc,
+                   bz = 0.5 * (MJS_HULL_BOX_LO[cat][2] + MJS_HULL_BOX_HI[cat][2]) * sc;
+      put3(pr + 1, v3(origin.x + (R.cx.x * bx + R.cy.x * by + R.cz.x * bz), origin.y + (R.cx.y * bx + R.cy.y * by + R.cz.y * bz), origin.z + (R.cx.z * bx + R.cy.z * by + R.cz.z * bz)));
+      const float hx = (float)(0.5 * (MJS_HULL_BOX_HI[cat][0] - MJS_HULL_BOX_LO[cat][0]) * sc), hy = (float)(0.5 * (MJS_HULL_BOX_HI[cat][1] - MJS_HULL_BOX_LO[cat][1]) * sc),
+                  hz = (float)(0.5 * (MJS_HULL_BOX_HI[cat][2] - MJS_HULL_BOX_LO[cat][2]) * sc);
+      pr[10] = hx; pr[11] = hy; pr[12] = hz;
+      pr[17] = bound_radius(hx + hy + hz);
+      put_rgb(pr + 14, MJS_BLOCK_COLORS[col < 6 ? col : 5]);
+    } else {
+      put3(pr + 1, b < nb ? madd(origin, MJS_BLOCK_GEOM_Z, R.cz) : v3(0, 0, -10.0));  // unused slot: out of sight
+      pr[10] = (float)MJS_BLOCK_HALF[0]; pr[11] = (float)MJS_BLOCK_HALF[1]; pr[12] = (float)MJS_BLOCK_HALF[2];
+      pr[17] = bound_radius((float)(MJS_BLOCK_HALF[0] + MJS_BLOCK_HALF[1] + MJS_BLOCK_HALF[2]));
+      put_rgb(pr + 14, MJS_BLOCK_RGB[b]);
+    }
   }
 }
 

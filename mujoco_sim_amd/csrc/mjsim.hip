@@ -139,6 +139,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.button_disturbances = h->cfg.button_disturbances;
   p.n_objects = h->cfg.n_objects;
   p.max_episode_steps = h->cfg.max_episode_steps;
+  p.block_shape = h->cfg.block_shape;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -220,6 +221,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
     return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: unknown task id");
   if (mjs_action_dim_for(cfg->task, cfg->action_type) < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad action_type");
   if (cfg->task == MJS_TASK_PLANAR_PUSH && cfg->n_objects > MJS_PP_MAX_OBJECTS) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: n_objects exceeds MJS_PP_MAX_OBJECTS");
+  if (cfg->task == MJS_TASK_PLANAR_PUSH && cfg->block_shape != MJS_BLOCKS_MESH && cfg->block_shape != MJS_BLOCKS_BOX)
+    return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad block_shape");
   if (cfg->num_envs <= 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: num_envs must be positive");
   if (cfg->autoreset < MJS_AUTORESET_NEXT_STEP || cfg->autoreset > MJS_AUTORESET_DISABLED)
     return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad autoreset mode");

@@ -104,7 +104,7 @@ class HipVectorEnv:
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
                  button_disturbances: bool = False, use_wrist_camera: bool = True, n_objects: int | None = None,
-                 max_episode_steps: int | None = None):
+                 max_episode_steps: int | None = None, block_shape: str = "mesh"):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -119,6 +119,9 @@ class HipVectorEnv:
             raise AssertionError(f"reward_type {reward_type!r} not in {self.spec.reward_types}")  # reference asserts (point_reach.py:68)
         if autoreset not in _AUTORESET_IDS:
             raise ValueError(f"autoreset must be one of {sorted(_AUTORESET_IDS)}")
+        if block_shape not in ("mesh", "box"):
+            raise ValueError("block_shape must be 'mesh' (the reference's GoogleBlockProp meshes) or 'box' (round 1's stand-in)")
+        self.block_shape = block_shape
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise nat.MjsError("HipVectorEnv needs a HIP device (torch device 'cuda:N'); there is no CPU path")
@@ -133,7 +136,8 @@ class HipVectorEnv:
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),
                             time_limit=float(time_limit) if time_limit is not None else -1.0,
                             action_type=_ACTION_IDS.get(action_type, 0), button_disturbances=int(bool(button_disturbances)),
-                            n_objects=int(n_objects or 0), max_episode_steps=int(max_episode_steps or 0))
+                            n_objects=int(n_objects or 0), max_episode_steps=int(max_episode_steps or 0),
+                            block_shape=nat.BLOCKS_BOX if block_shape == "box" else nat.BLOCKS_MESH)
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h

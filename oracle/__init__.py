@@ -23,6 +23,7 @@ from .oracle import (  # noqa: F401
     ur5e_ik_all,
     ur5e_ik_closest,
     UR_STATE, UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ, UR_EEF_NONE, UR_EEF_GRIPPER,
+    BLOCKS_MESH, BLOCKS_BOX,
     ur_robot_state,
     ur_robot_run,
 )

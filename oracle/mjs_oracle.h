@@ -60,6 +60,10 @@ typedef struct {
   /* geoms */
   int geom_type[OM_MAXGEOM], geom_body[OM_MAXGEOM], geom_contype[OM_MAXGEOM], geom_conaffinity[OM_MAXGEOM], geom_condim[OM_MAXGEOM];
   double geom_pos[OM_MAXGEOM][3], geom_quat[OM_MAXGEOM][4], geom_size[OM_MAXGEOM][3], geom_friction[OM_MAXGEOM][3];
+  /* OM_GEOM_MESH: category of include/mjs_block_hulls.h (collided by its convex hull, as MuJoCo does) and mesh scale; the geom
+   * frame sits at the mesh's centre of mass (MuJoCo re-centres a mesh geom there) */
+  int geom_mesh[OM_MAXGEOM];
+  double geom_mesh_scale[OM_MAXGEOM];
   /* sites */
   int site_body[OM_MAXSITE];
   double site_pos[OM_MAXSITE][3], site_quat[OM_MAXSITE][4];
@@ -143,7 +147,10 @@ typedef struct {
   int button_disturbances;   /* Button-Push only: robot_push_button.py:159-165 */
   int n_objects;             /* Planar-Push only: 1..MJS_PP_MAX_OBJECTS blocks (<= 0: 2) */
   int max_episode_steps;     /* Planar-Push only: RobotTask step limit (base.py:47-51), default 500 */
+  int block_shape;           /* Planar-Push only: OM_BLOCKS_MESH (reference: google_block.py, category / colour / scale drawn per
+                              * episode from the env's seeded stream, deviation D-5) or OM_BLOCKS_BOX (round 1's stand-in) */
 } om_task_config;
+enum { OM_BLOCKS_MESH = 0, OM_BLOCKS_BOX = 1 };
 
 #define OM_MAXOBS 16
 typedef struct {
@@ -171,6 +178,9 @@ typedef struct {
   double switch_pos[3];
   /* Planar-Push: RobotTask.episode_step (base.py:29-32) */
   int episode_step;
+  /* Planar-Push: the blocks of this episode (GoogleBlockProp.sample_random_object, google_block.py:55-68) */
+  int block_cat[5], block_color[5];
+  double block_scale[5];
   int dbg_arm_floor_seen; /* test knob, om_debug_arm_floor_seen() */
 } om_env;
 
@@ -192,6 +202,8 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
 int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time);
 int om_debug_arm_floor_seen(om_env* e);
+void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale);
+void om_debug_get_block_shape(const om_env* e, int* cat, int* color, double* scale);
 void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);
 void om_debug_substeps(om_env* e, int n);
 int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,

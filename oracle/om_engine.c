@@ -21,6 +21,7 @@
 
 #include "../include/mjs_scene_spec.h"
 #include "mjs_oracle.h"
+#include "../include/mjs_block_hulls.h"
 
 /* ------------------------------------------------------------ small math */
 static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
@@ -402,6 +403,25 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
       for (int k = 0; k < 3; k++) pos[k] = corner[k] - n[k] * dist * 0.5;
       cnt += add_contact(m, d, g1, g2, dist, pos, n);
     }
+  } else if (m->geom_type[g2] == OM_GEOM_MESH) {
+    /* plane vs mesh = plane vs the vertices of its convex hull. ASSUMED rule (MuJoCo's mjc_PlaneConvex is third-party and
+     * absent): the hull vertices in the table's farthest-point order, each one at or below the plane (margin 0)
+     * is a contact, at most 4 - the shape of mjc_PlaneBox's rule, with a vertex order that spreads the four over the
+     * touching face. dist = height of the vertex, pos = vertex - n dist / 2 (as for a box corner). */
+    const int cat = m->geom_mesh[g2];
+    const double sc = m->geom_mesh_scale[g2];
+    int cnt = 0;
+    for (int i = 0; i < MJS_HULL_NV[cat] && cnt < 4; i++) {
+      double loc[3], vert[3];
+      for (int k = 0; k < 3; k++) loc[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
+      mulMatVec3(vert, gm, loc);
+      for (int k = 0; k < 3; k++) vert[k] += gp[k];
+      for (int k = 0; k < 3; k++) tmp[k] = vert[k] - pp[k];
+      double dist = dot3(tmp, n);
+      if (dist > margin) continue;
+      for (int k = 0; k < 3; k++) pos[k] = vert[k] - n[k] * dist * 0.5;
+      cnt += add_contact(m, d, g1, g2, dist, pos, n);
+    }
   }
 }
 
@@ -495,6 +515,7 @@ typedef struct { double v[3], a[3], b[3]; } mpr_vert; /* v = a - b, a on geom1, 
 #define MPR_EPS_DIR 1e-10
 #define MPR_EPS_LEN 1e-13
 #define MPR_EPS_VOL 1e-16
+#define MPR_EPS_TIE 1e-12
 
 static void support_geom(const om_model* m, const om_data* d, int g, const double* dir, double* out) {
   const double* gp = d->geom_xpos[g];
@@ -504,6 +525,25 @@ static void support_geom(const om_model* m, const om_data* d, int g, const doubl
   for (int k = 0; k < 3; k++) loc[k] = gm[k] * dir[0] + gm[3 + k] * dir[1] + gm[6 + k] * dir[2]; /* R^T dir */
   if (m->geom_type[g] == OM_GEOM_BOX) {
     for (int k = 0; k < 3; k++) res[k] = loc[k] >= -MPR_EPS_DIR ? sz[k] : -sz[k];
+  } else if (m->geom_type[g] == OM_GEOM_MESH) {
+    /* hull vertex with the largest projection on the direction; structural ties (a face or an edge square to the direction) go to
+     * the FIRST vertex in table order among those within MPR_EPS_TIE of the maximum, whatever the rounding noise */
+    const int cat = m->geom_mesh[g];
+    const double sc = m->geom_mesh_scale[g];
+    double best = -1e300;
+    for (int i = 0; i < MJS_HULL_NV[cat]; i++) {
+      double v[3];
+      for (int k = 0; k < 3; k++) v[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
+      double pr = loc[0] * v[0] + loc[1] * v[1] + loc[2] * v[2];
+      if (pr > best) best = pr;
+    }
+    res[0] = res[1] = res[2] = 0;
+    for (int i = MJS_HULL_NV[cat] - 1; i >= 0; i--) {
+      double v[3];
+      for (int k = 0; k < 3; k++) v[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
+      double pr = loc[0] * v[0] + loc[1] * v[1] + loc[2] * v[2];
+      if (pr >= best - MPR_EPS_TIE) { res[0] = v[0]; res[1] = v[1]; res[2] = v[2]; }
+    }
   } else { /* cylinder, axis = local z */
     double len = sqrt(loc[0] * loc[0] + loc[1] * loc[1]);
     if (len > MPR_EPS_DIR) { res[0] = sz[0] * loc[0] / len; res[1] = sz[0] * loc[1] / len; } else { res[0] = 0; res[1] = 0; }
@@ -612,6 +652,7 @@ static int mpr_penetration(const om_model* m, const om_data* d, int g1, int g2, 
 static double geom_rbound(const om_model* m, int g) {
   const double* sz = m->geom_size[g];
   if (m->geom_type[g] == OM_GEOM_BOX) return sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+  if (m->geom_type[g] == OM_GEOM_MESH) return MJS_HULL_RBOUND[m->geom_mesh[g]] * m->geom_mesh_scale[g];
   return sqrt(sz[0] * sz[0] + sz[1] * sz[1]); /* cylinder */
 }
 static void collide_convex(const om_model* m, om_data* d, int g1, int g2) {
@@ -657,7 +698,7 @@ static void om_collision(const om_model* m, om_data* d) {
       if (t1 == OM_GEOM_PLANE && t2 != OM_GEOM_PLANE) collide_plane(m, d, ga, gb);
       else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_CYLINDER) collide_sphere_cylinder(m, d, ga, gb);
       else if (t1 == OM_GEOM_SPHERE && t2 == OM_GEOM_BOX) collide_sphere_box(m, d, ga, gb);
-      else if ((t1 == OM_GEOM_CYLINDER || t1 == OM_GEOM_BOX) && t2 == OM_GEOM_BOX) collide_convex(m, d, ga, gb);
+      else if ((t1 == OM_GEOM_CYLINDER || t1 == OM_GEOM_BOX || t1 == OM_GEOM_MESH) && (t2 == OM_GEOM_BOX || t2 == OM_GEOM_MESH)) collide_convex(m, d, ga, gb);
       /* other pairs (capsule-capsule, capsule-box, ...): not evaluated */
     }
 }

@@ -15,6 +15,7 @@
 
 #include "../include/mjs_scene_spec.h"
 #include "mjs_oracle.h"
+#include "../include/mjs_block_hulls.h"
 
 typedef struct { float x, y, z; } v3;
 static v3 V(float x, float y, float z) { v3 r = {x, y, z}; return r; }
@@ -333,6 +334,17 @@ static void render_robot_scene(const om_env* e, int camera, int H, int W, uint8_
           const double* bp = dd->geom_xpos[ge + 1 + i];
           const double* bm = dd->geom_xmat[ge + 1 + i];
           double u[3] = {bm[0], bm[3], bm[6]}, w[3] = {bm[1], bm[4], bm[7]};
+          if (e->cfg.block_shape == OM_BLOCKS_MESH) {
+            /* a mesh block is drawn as the bounding box of its hull (scaled), in its sampled colour (D-6: own ray caster) */
+            const int cat = e->block_cat[i], body = e->m.geom_body[ge + 1 + i];
+            const double sc = e->block_scale[i];
+            double ctr[3], bc[3];
+            for (int k = 0; k < 3; k++) bc[k] = 0.5 * (MJS_HULL_BOX_LO[cat][k] + MJS_HULL_BOX_HI[cat][k]) * sc;
+            for (int k = 0; k < 3; k++) ctr[k] = dd->xpos[body][k] + (bm[3 * k] * bc[0] + bm[3 * k + 1] * bc[1] + bm[3 * k + 2] * bc[2]);
+            obb(eye, d, Vd(ctr), Vd(u), Vd(w), V((float)(0.5 * (MJS_HULL_BOX_HI[cat][0] - MJS_HULL_BOX_LO[cat][0]) * sc), (float)(0.5 * (MJS_HULL_BOX_HI[cat][1] - MJS_HULL_BOX_LO[cat][1]) * sc),
+                                                    (float)(0.5 * (MJS_HULL_BOX_HI[cat][2] - MJS_HULL_BOX_LO[cat][2]) * sc)),
+                V(MJS_BLOCK_COLORS[e->block_color[i]][0], MJS_BLOCK_COLORS[e->block_color[i]][1], MJS_BLOCK_COLORS[e->block_color[i]][2]), &s);
+          } else
           obb(eye, d, Vd(bp), Vd(u), Vd(w), V((float)MJS_BLOCK_HALF[0], (float)MJS_BLOCK_HALF[1], (float)MJS_BLOCK_HALF[2]),
               V(MJS_BLOCK_RGB[i][0], MJS_BLOCK_RGB[i][1], MJS_BLOCK_RGB[i][2]), &s);
         }

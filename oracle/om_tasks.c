@@ -17,6 +17,7 @@
 
 #include "../include/mjs_scene_spec.h"
 #include "mjs_oracle.h"
+#include "../include/mjs_block_hulls.h"
 
 /* ------------------------------------------------------- model building */
 static void quat_z2vec(double* q, const double* vec) {
@@ -252,6 +253,27 @@ static void build_push(om_model* m, int n_objects) {
   om_set_const(m);
 }
 
+/* GoogleBlockProp (google_block.py:37-49): body i's geom becomes the mesh of `cat` at `scale` (collided by its convex hull),
+ * mass 0.1 kg set on the geom, inertia of the closed mesh (include/mjs_block_hulls.h), condim 4, friction (1, 0.05, 0).
+ * The reference rebuilds the MJCF every episode (initialize_episode_mjcf, robot_planar_push.py:144-147,163-167): a model edit. */
+static void set_block_shape(om_model* m, int block, int cat, double scale) {
+  int body = -1, seen = 0;
+  for (int b = 1; b < m->nbody; b++)
+    if (m->body_jntnum[b] == 1 && m->jnt_type[m->body_jntadr[b]] == OM_JNT_FREE && seen++ == block) { body = b; break; }
+  if (body < 0) return;
+  int g = -1;
+  for (int k = 0; k < m->ngeom; k++) if (m->geom_body[k] == body) g = k;
+  m->geom_type[g] = OM_GEOM_MESH;
+  m->geom_mesh[g] = cat;
+  m->geom_mesh_scale[g] = scale;
+  for (int k = 0; k < 3; k++) {
+    m->geom_pos[g][k] = MJS_HULL_COM[cat][k] * scale;
+    m->body_ipos[body][k] = MJS_HULL_COM[cat][k] * scale;
+    m->body_inertia[body][k] = MJS_BLOCK_MASS * MJS_HULL_INERTIA_PER_MASS[cat][k] * scale * scale;
+  }
+  m->body_mass[body] = MJS_BLOCK_MASS;
+}
+
 /* ------------------------------------------------------------ task API */
 void om_default_config(int task, om_task_config* cfg) {
   memset(cfg, 0, sizeof *cfg);
@@ -264,6 +286,7 @@ void om_default_config(int task, om_task_config* cfg) {
     cfg->reward_type = OM_REW_DENSE_NEG_DISTANCE;                         /* robot_planar_push.py:69 */
     cfg->time_limit = 1e300;                                              /* scripts/sb3/planar_push.py:72: no Environment time limit */
     cfg->n_objects = MJS_PP_FAST_OBJECTS;                                 /* BASELINE config 4 / robot_planar_push.py:315 */
+    cfg->block_shape = OM_BLOCKS_MESH;                                    /* robot_planar_push.py:164: GoogleBlockProp.sample_random_object() */
     cfg->max_episode_steps = MJS_PP_MAX_CONTROL_STEPS;                    /* robot_planar_push.py:53 */
   } else if (task == OM_TASK_BUTTON_PUSH) {
     cfg->reward_type = OM_REW_SPARSE;                                     /* robot_push_button.py:47 */
@@ -371,6 +394,21 @@ static void episode_init(om_env* e) {
      * blocks' xyz (identity orientation), ALL blocks re-drawn until mj_forward reports no contact; 150 settle steps */
     double rp[3], q[6], zeros[6] = {0, 0, 0, 0, 0, 0};
     e->episode_step = 0; /* base.py:29 */
+    if (e->cfg.block_shape == OM_BLOCKS_MESH) {
+      /* initialize_episode_mjcf (robot_planar_push.py:144-147,163-167) runs BEFORE initialize_episode: every block is replaced by
+       * GoogleBlockProp.sample_random_object() (google_block.py:55-68): category, colour, scale in [0.8, 1.2]. The reference draws
+       * them from Python's unseeded global `random`; here they come from the env's seeded stream (deviation D-5), three uniforms
+       * per block in that order. */
+      for (int i = 0; i < e->cfg.n_objects; i++) {
+        int cat = (int)om_rng_uniform(&e->rng, 0.0, (double)MJS_HULL_NCAT), col = (int)om_rng_uniform(&e->rng, 0.0, 6.0);
+        e->block_cat[i] = cat < MJS_HULL_NCAT ? cat : MJS_HULL_NCAT - 1;
+        e->block_color[i] = col < 6 ? col : 5;
+        e->block_scale[i] = om_rng_uniform(&e->rng, MJS_BLOCK_SCALE_LO, MJS_BLOCK_SCALE_HI);
+        set_block_shape(m, i, e->block_cat[i], e->block_scale[i]);
+      }
+      om_set_const(m); /* the recompiled model's invweight0 / meaninertia */
+      om_reset_data(m, d);
+    }
     for (int k = 0; k < 3; k++) rp[k] = om_rng_uniform(&e->rng, MJS_PP_ROBOT_SPACE_LO[k], MJS_PP_ROBOT_SPACE_HI[k]);
     if (tcp_pose_to_joints(rp, MJS_TOP_DOWN_QUAT_XYZW, MJS_CYL_TCP_Z, zeros, q))
       for (int j = 0; j < 6; j++) { d->qpos[j] = q[j]; d->qvel[j] = 0; d->ctrl[j] = q[j]; }
@@ -608,6 +646,17 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
   invw_out[1] = m.body_invweight0[8][1];
   invw_out[2] = m.meaninertia;
   for (int i = 0; i < 6; i++) invw_out[3 + i] = m.dof_invweight0[i];
+}
+
+/* debug hook for tests: give block `i` of a Planar-Push env the mesh `cat` at `scale` (as initialize_episode_mjcf would) */
+void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale) {
+  e->block_cat[i] = cat; e->block_color[i] = color; e->block_scale[i] = scale;
+  set_block_shape(&e->m, i, cat, scale);
+  om_set_const(&e->m);
+}
+
+void om_debug_get_block_shape(const om_env* e, int* cat, int* color, double* scale) {
+  for (int i = 0; i < 5; i++) { cat[i] = e->block_cat[i]; color[i] = e->block_color[i]; scale[i] = e->block_scale[i]; }
 }
 
 /* debug hook for tests: did an arm link touch the floor in any substep since the last call? (the HIP kernels detect and count

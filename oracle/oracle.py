@@ -30,6 +30,7 @@ class TaskConfig(C.Structure):
         ("button_disturbances", C.c_int),
         ("n_objects", C.c_int),
         ("max_episode_steps", C.c_int),
+        ("block_shape", C.c_int),
     ]
 
 
@@ -155,6 +156,7 @@ def ur5e_ik_closest(T, q_guess):
     return out if ok else None
 
 
+BLOCKS_MESH, BLOCKS_BOX = 0, 1
 UR_STATE = 34
 UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
 UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1
@@ -186,7 +188,8 @@ class OracleBatch:
     def __init__(self, task: int, n: int, base_seed: int = 0, *, reward_type: int | None = None,
                  autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
                  terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None,
-                 button_disturbances: bool = False, n_objects: int | None = None, max_episode_steps: int | None = None):
+                 button_disturbances: bool = False, n_objects: int | None = None, max_episode_steps: int | None = None,
+                 block_shape: int | None = None):
         L = lib()
         cfg = TaskConfig()
         L.om_default_config(task, C.byref(cfg))
@@ -203,6 +206,8 @@ class OracleBatch:
             cfg.n_objects = n_objects
         if max_episode_steps is not None:
             cfg.max_episode_steps = max_episode_steps
+        if block_shape is not None:
+            cfg.block_shape = block_shape
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
         L.om_obs_dim_for.argtypes = [C.c_void_p]
         self.obs_dim, self.action_dim = L.om_obs_dim_for(C.byref(cfg)), L.om_action_dim(task)
@@ -247,6 +252,25 @@ class OracleBatch:
         L.om_debug_set_robot_state.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         for i in range(self.n):
             L.om_debug_set_robot_state(L.om_batch_env(self._h, i), q[i].ctypes.data, v[i].ctypes.data)
+
+    def set_block_shapes(self, cats, colors, scales):
+        """debug (Planar-Push): block b of env i becomes mesh category cats[i, b] at scales[i, b] ([N, n_objects] each)"""
+        L = lib()
+        L.om_debug_set_block_shape.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double]
+        cats, colors, scales = np.asarray(cats), np.asarray(colors), np.asarray(scales, dtype=np.float64)
+        for i in range(self.n):
+            for b in range(cats.shape[1]):
+                L.om_debug_set_block_shape(L.om_batch_env(self._h, i), b, int(cats[i, b]), int(colors[i, b]), float(scales[i, b]))
+
+    def block_shapes(self):
+        """debug (Planar-Push): (category, colour, scale) arrays [N, 5] of the current episode"""
+        import struct  # noqa: F401
+        L = lib()
+        L.om_debug_get_block_shape.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        cat, col, sc = np.zeros((self.n, 5), np.int32), np.zeros((self.n, 5), np.int32), np.zeros((self.n, 5))
+        for i in range(self.n):
+            L.om_debug_get_block_shape(L.om_batch_env(self._h, i), cat[i].ctypes.data, col[i].ctypes.data, sc[i].ctypes.data)
+        return cat, col, sc
 
     def arm_floor_seen(self) -> np.ndarray:
         """debug: per env, did an arm link touch the floor in any substep since the last call (sticky flag, cleared)"""

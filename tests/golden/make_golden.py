@@ -76,16 +76,16 @@ def run_button(N, T, base_seed):
     return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
 
 
-def run_push(N, T, base_seed, limit, n_objects=2):
-    """Planar-Push: noisy push-towards-block-0 policy, closed loop on the oracle, step limit `limit` so that
+def run_push(N, T, base_seed, limit, n_objects=2, block_shape=oracle.BLOCKS_BOX):
+    """Planar-Push (box stand-in blocks by default; block_shape=MESH: the reference's meshes): noisy push-towards-block-0 policy, closed loop on the oracle, step limit `limit` so that
     truncations + device-side resets (rejection-sampled draws, 150 settle steps) are inside the fixture. Returns None
     when some env of the batch is ill-conditioned (a second oracle perturbed by 1e-13 m at every reset disagrees by
     more than 1e-10): rigid-body contact amplifies rounding noise there and no fixed tolerance would be meaningful."""
     import ctypes as C
 
     knob = C.c_double.in_dll(oracle.lib(), "om_dbg_perturb")
-    b = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8)
-    b2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8)
+    b = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8, block_shape=block_shape)
+    b2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, base_seed, max_episode_steps=limit, n_objects=n_objects, nthreads=8, block_shape=block_shape)
     r = b.reset()
     knob.value = 1e-13
     r2 = b2.reset()
@@ -125,6 +125,12 @@ if __name__ == "__main__":
         if fx is not None and int((fx["ncon"] > 20).sum()) >= 8:
             np.savez_compressed(OUT / "planar_push5_n4_t36.npz", base_seed=seed, **fx)
             print("planar push (5 blocks) fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 20).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
+            break
+    for seed in range(4025, 4425):  # the reference's MESH blocks (category / colour / scale drawn per episode), 8 well-conditioned envs
+        fx = run_push(8, 70, seed, 25, block_shape=oracle.BLOCKS_MESH)
+        if fx is not None:
+            np.savez_compressed(OUT / "planar_push_mesh_n8_t70.npz", base_seed=seed, **fx)
+            print("planar push (mesh blocks) fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 8).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
             break
     np.savez_compressed(OUT / "button_push_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025))
     np.savez_compressed(OUT / "pointmass_n8_t70_seed2025.npz", **run(oracle.TASK_POINTMASS, 8, 70, 2025, oracle.AUTORESET_NEXT_STEP))

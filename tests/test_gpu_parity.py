@@ -88,7 +88,7 @@ def test_pointmass_wall_contacts_parity(oracle_mod):
 
 @pytest.mark.parametrize("name,task", [("pointmass_n8_t70_seed2025", "point_mass_reach"), ("robot_reach_n8_t110_seed2025", "robot_reach"),
                                        ("button_push_eef_n8_t80_seed2025", "robot_push_button"), ("planar_push_n8_t70", "robot_planar_push"),
-                                       ("planar_push5_n4_t36", "robot_planar_push")])
+                                       ("planar_push5_n4_t36", "robot_planar_push"), ("planar_push_mesh_n8_t70", "robot_planar_push")])
 def test_gpu_matches_committed_golden(name, task):
     import mujoco_sim_amd as m
 
@@ -97,6 +97,8 @@ def test_gpu_matches_committed_golden(name, task):
     kw = {"action_type": "absolute_eef_action"} if task == "robot_push_button" else {"max_episode_steps": 25} if task == "robot_planar_push" else {}
     if name.startswith("planar_push5"):
         kw = {"max_episode_steps": 14, "n_objects": 5}
+    if task == "robot_planar_push":
+        kw["block_shape"] = "mesh" if "mesh" in name else "box"
     venv = m.HipVectorEnv(task, N, seed=int(g["base_seed"]) if "base_seed" in g else 2025, **kw)
     venv.reset()
     atol = 1e-8 if task == "robot_planar_push" else ATOL  # contact-rich free bodies (fixture envs are well-conditioned, see make_golden.py)
@@ -692,15 +694,24 @@ def test_registered_button_push_visual_env_id():
 
 
 # ------------------------------------------------------------------------------------------ Planar-Push
+def _push_state_to_gpu_into(gs, qpos, qvel, time):
+    gs[0:6] = torch.from_numpy(qpos[:, :6].T)
+    gs[6:12] = torch.from_numpy(qvel[:, :6].T)
+    gs[12] = torch.from_numpy(time)
+    for b in range((qpos.shape[1] - 6) // 7):
+        gs[17 + 15 * b: 17 + 15 * b + 7] = torch.from_numpy(qpos[:, 6 + 7 * b: 13 + 7 * b].T)
+        gs[17 + 15 * b + 7: 17 + 15 * b + 13] = torch.from_numpy(qvel[:, 6 + 6 * b: 12 + 6 * b].T)
+
+
 def _push_state_to_gpu(venv, qpos, qvel, time):
-    """oracle layout (qpos [N, 6 + 7 n], qvel [N, 6 + 6 n]) -> mjs_set_state rows (q6 v6 time target3 step, 13 per block)"""
+    """oracle layout (qpos [N, 6 + 7 n], qvel [N, 6 + 6 n]) -> mjs_set_state rows (q6 v6 time target3 step, 15 per block: pos3 quat4 vel6 shape scale)"""
     gs = venv.get_state().clone()
     gs[0:6] = torch.from_numpy(qpos[:, :6].T)
     gs[6:12] = torch.from_numpy(qvel[:, :6].T)
     gs[12] = torch.from_numpy(time)
     for b in range((qpos.shape[1] - 6) // 7):
-        gs[17 + 13 * b: 17 + 13 * b + 7] = torch.from_numpy(qpos[:, 6 + 7 * b: 13 + 7 * b].T)
-        gs[17 + 13 * b + 7: 17 + 13 * b + 13] = torch.from_numpy(qvel[:, 6 + 6 * b: 12 + 6 * b].T)
+        gs[17 + 15 * b: 17 + 15 * b + 7] = torch.from_numpy(qpos[:, 6 + 7 * b: 13 + 7 * b].T)
+        gs[17 + 15 * b + 7: 17 + 15 * b + 13] = torch.from_numpy(qvel[:, 6 + 6 * b: 12 + 6 * b].T)
     venv.set_state(gs)
 
 
@@ -716,8 +727,8 @@ def test_planar_push_controlled_scenarios(oracle_mod):
     import mujoco_sim_amd as m
 
     N = 7
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=1)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 1, nthreads=4)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=1, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 1, nthreads=4, block_shape=1)
     venv.reset()
     o = ob.reset()
     qp, qv, tm = ob.get_state()
@@ -748,8 +759,8 @@ def test_planar_push_controlled_scenarios(oracle_mod):
         g = venv.get_state().cpu().numpy()
         q2, v2, _ = ob.get_state()
         for b in range(2):
-            np.testing.assert_allclose(g[17 + 13 * b: 24 + 13 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-10, err_msg=f"block {b} pose, step {t}")
-            np.testing.assert_allclose(g[24 + 13 * b: 30 + 13 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-8, err_msg=f"block {b} velocity, step {t}")
+            np.testing.assert_allclose(g[17 + 15 * b: 24 + 15 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-10, err_msg=f"block {b} pose, step {t}")
+            np.testing.assert_allclose(g[24 + 15 * b: 30 + 15 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-8, err_msg=f"block {b} velocity, step {t}")
         np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-10)
         assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), t
         np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-10)
@@ -764,7 +775,7 @@ def test_planar_push_full_size_shard_invariance_and_determinism():
 
     N, T = 4096, 5
     def run(parts):
-        envs = [m.HipVectorEnv("robot_planar_push", N // parts, seed=99, env_index_offset=k * (N // parts), max_episode_steps=3) for k in range(parts)]
+        envs = [m.HipVectorEnv("robot_planar_push", N // parts, seed=99, env_index_offset=k * (N // parts), max_episode_steps=3, block_shape="box") for k in range(parts)]
         for e in envs:
             e.reset()
         outs = []
@@ -795,8 +806,8 @@ def test_planar_push_block_train_couples_all_bodies(oracle_mod):
     import mujoco_sim_amd as m
 
     N = 4
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=3, n_objects=5)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 3, n_objects=5, nthreads=4)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=3, n_objects=5, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 3, n_objects=5, nthreads=4, block_shape=1)
     venv.reset()
     o = ob.reset()
     qp, qv, tm = ob.get_state()
@@ -819,8 +830,8 @@ def test_planar_push_block_train_couples_all_bodies(oracle_mod):
         q2, v2, _ = ob.get_state()
         assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), (t, venv._buf["ncon"].cpu().numpy(), r["ncon"])
         for b in range(5):
-            np.testing.assert_allclose(g[17 + 13 * b: 24 + 13 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-8, err_msg=f"block {b} pose, step {t}")
-            np.testing.assert_allclose(g[24 + 13 * b: 30 + 13 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-6, err_msg=f"block {b} velocity, step {t}")
+            np.testing.assert_allclose(g[17 + 15 * b: 24 + 15 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-8, err_msg=f"block {b} pose, step {t}")
+            np.testing.assert_allclose(g[24 + 15 * b: 30 + 15 * b].T, v2[:, 6 + 6 * b: 12 + 6 * b], rtol=0, atol=1e-6, err_msg=f"block {b} velocity, step {t}")
         np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-9)
         np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-8)
         most = max(most, int(r["ncon"].max()))
@@ -841,9 +852,9 @@ def test_planar_push_parity_with_oracle(oracle_mod):
 
     N, T, LIMIT = 128, 66, 30
     knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=2025, max_episode_steps=LIMIT)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
-    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2025, max_episode_steps=LIMIT, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT, block_shape=1)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT, block_shape=1)
     venv.reset()
     o = ob.reset()
     try:
@@ -885,6 +896,136 @@ def test_planar_push_parity_with_oracle(oracle_mod):
     assert n_pushed > 100                    # EEF-block / block-block contacts on top of the 8 floor corners
 
 
+def test_planar_push_mesh_block_draws_match_numpy():
+    """D-5: GoogleBlockProp.sample_random_object (google_block.py:55-68: category, colour, scale in [0.8, 1.2]) is drawn per
+    episode from the env's seeded stream, three uniforms per block BEFORE initialize_episode's draws: env i's first draws are
+    RandomState(seed + i).uniform(0, 4) / (0, 6) / (0.8, 1.2)."""
+    import mujoco_sim_amd as m
+
+    N = 16
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2025)
+    venv.reset()
+    st = venv.get_state().cpu().numpy()  # [state_dim, N]
+    for i in range(N):
+        rs = np.random.RandomState(2025 + i)
+        for b in range(2):
+            cat, col, sc = int(rs.uniform(0, 4)), int(rs.uniform(0, 6)), rs.uniform(0.8, 1.2)
+            assert st[17 + 15 * b + 13, i] == cat + 8 * col and st[17 + 15 * b + 14, i] == sc, (i, b)
+    venv.close()
+
+
+@pytest.mark.parametrize("cat", [0, 1, 2, 3])
+def test_planar_push_mesh_categories_controlled(oracle_mod, cat):
+    """Per block category (cube, moon, pentagon, star; hulls of the reference's .obj meshes at scales 0.8 / 1.0 / 1.2): hand-set
+    states through mjs_set_state against the oracle, step by step at 1e-9 — a block dropped flat, one dropped tilted (vertex
+    contacts come and go), one next to the EEF cylinder that is pushed (cylinder-hull MPR contact), two blocks touching
+    (hull-hull)."""
+    import mujoco_sim_amd as m
+
+    N = 12
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=1, time_limit=1e9, max_episode_steps=10**6)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 1, time_limit=1e9, max_episode_steps=10**6, nthreads=8)
+    venv.reset()
+    o = ob.reset()
+    qpos, qvel, tm = ob.get_state()
+    scales = np.tile([0.8, 1.0, 1.2], 4)
+    cats = np.stack([np.full(N, cat), (np.full(N, cat) + np.arange(N) // 3) % 4], axis=1)
+    cols = np.stack([np.arange(N) % 6, (np.arange(N) + 2) % 6], axis=1)
+    sc2 = np.stack([scales, scales[::-1]], axis=1)
+    ob.set_block_shapes(cats, cols, sc2)
+    tcp = o["obs"][:, :3].copy()
+    qvel[:] = 0
+    for i in range(N):
+        kind = i // 3
+        b0, b1 = qpos[i, 6:13], qpos[i, 13:20]
+        b0[:] = [tcp[i, 0] + 0.10, tcp[i, 1], 0.03, 1, 0, 0, 0]
+        b1[:] = [tcp[i, 0] - 0.10, tcp[i, 1], 0.001, 1, 0, 0, 0]
+        if kind == 1:    # dropped tilted about a skew axis
+            b0[3:7] = _quat([1.0, 0.4, 0.2], 0.5)
+            b0[2] = 0.06
+        elif kind == 2:  # right in front of the EEF cylinder (radius 0.02), which is then servoed into it
+            b0[:3] = [tcp[i, 0] + 0.045 * sc2[i, 0], tcp[i, 1], 0.0005]
+        elif kind == 3:  # the two blocks overlapping slightly, side by side
+            b0[:3] = [tcp[i, 0] + 0.08, tcp[i, 1] + 0.06, 0.0005]
+            b1[:3] = [tcp[i, 0] + 0.08 + 0.036 * (sc2[i, 0] + sc2[i, 1]) / 2, tcp[i, 1] + 0.06, 0.0005]
+    ob.set_state(qpos, qvel)
+    gs = venv.get_state().clone()
+    _push_state_to_gpu_into(gs, qpos, qvel, tm)
+    for b in range(2):
+        gs[17 + 15 * b + 13] = torch.from_numpy((cats[:, b] + 8 * cols[:, b]).astype(np.float64))
+        gs[17 + 15 * b + 14] = torch.from_numpy(sc2[:, b])
+    venv.set_state(gs)
+    n_convex = 0
+    for t in range(6):
+        a = tcp[:, :2].copy()
+        a[6:9, 0] += 0.012 * (t + 1)  # kind 2: push along +x
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        np.testing.assert_allclose(g["obs"], o["obs"], rtol=0, atol=1e-9, err_msg=f"category {cat} step {t}")
+        assert np.array_equal(g["ncon"], o["ncon"]), (cat, t, g["ncon"], o["ncon"])
+        n_convex += int((o["ncon"] > 8).sum())
+    gq = venv.get_state().cpu().numpy()
+    oq, ov, _ = ob.get_state()
+    for b in range(2):  # full block poses, not only the observed xy
+        np.testing.assert_allclose(gq[17 + 15 * b: 17 + 15 * b + 7].T, oq[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-9)
+    assert n_convex > 0
+    venv.close()
+
+
+def test_planar_push_mesh_parity_with_oracle(oracle_mod):
+    """Seeded episodes with the reference's mesh blocks (random category / colour / scale per episode, pushes, step-limit
+    truncations, device-side resets with re-drawn shapes and 150 settle steps) against the oracle on the envs the oracle itself
+    calls well-conditioned (second oracle perturbed by 1e-13 m at every reset), as for the box stand-in."""
+    import ctypes as C
+
+    import mujoco_sim_amd as m
+
+    N, T, LIMIT = 128, 66, 30
+    knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2025, max_episode_steps=LIMIT)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2025, nthreads=8, max_episode_steps=LIMIT)
+    venv.reset()
+    o = ob.reset()
+    try:
+        knob.value = 1e-13
+        o2 = ob2.reset()
+    finally:
+        knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    g = _gpu_result(venv)
+    np.testing.assert_allclose(g["obs"][~sens], o["obs"][~sens], rtol=0, atol=1e-8)
+    assert np.array_equal(g["ncon"][~sens], o["ncon"][~sens])
+    rs = np.random.RandomState(5)
+    n_last = n_pushed = 0
+    frac = []
+    for t in range(T):
+        tcp, blk = o["obs"][:, :2], o["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        try:
+            knob.value = 1e-13
+            o2 = ob2.step(a)
+        finally:
+            knob.value = 0.0
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] != 1) & (o2["step_type"] != 1)
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
+        g = _gpu_result(venv)
+        ok = ~sens
+        frac.append(sens.mean())
+        np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
+        n_last += int((o["step_type"] == 2).sum())
+        n_pushed += int((o["ncon"] > 8).sum())
+    print("mesh blocks: ill-conditioned fraction per step, mean", np.mean(frac), "max", np.max(frac))
+    assert np.mean(frac) < 0.3, np.mean(frac)
+    assert n_last >= 2 * N - 4 and n_pushed > 50
+
+
 def test_planar_push_env_id(oracle_mod):
     import mujoco_sim_amd as m
 
@@ -893,7 +1034,7 @@ def test_planar_push_env_id(oracle_mod):
     obs, _ = env.reset()
     assert list(obs.keys()) == ["ur5e/tcp_position", "target_position", "block_positions"] and obs["block_positions"].shape == (2,)
     assert env.action_space.shape == (2,)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, 3, n_objects=1, max_episode_steps=5)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, 1, 3, n_objects=1, max_episode_steps=5)  # both sides: the reference's mesh blocks
     o = ob.reset()
     np.testing.assert_allclose(obs["block_positions"], o["obs"][0, 5:7], atol=1e-8)
     for t in range(5):
@@ -914,9 +1055,9 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
     N, T, LIMIT = 32, 26, 12
     knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
     rid = {"sparse_reward": 0, "dense_negative_distance_reward": 2}[reward_type]
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=40, autoreset=autoreset, reward_type=reward_type, n_objects=n_objects, max_episode_steps=LIMIT)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
-    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=40, autoreset=autoreset, reward_type=reward_type, n_objects=n_objects, max_episode_steps=LIMIT, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 40, autoreset=1, reward_type=rid, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
     venv.reset()
     o = ob.reset()
     knob.value = 1e-13
@@ -964,11 +1105,11 @@ def test_planar_push_many_objects(oracle_mod, n_objects):
 
     N, T, LIMIT = 16, 16, 7
     knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=77, n_objects=n_objects, max_episode_steps=LIMIT)
-    assert venv.obs_dim == 15 and venv.state_dim == 1 + 17 + 13 * 5
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=77, n_objects=n_objects, max_episode_steps=LIMIT, block_shape="box")
+    assert venv.obs_dim == 15 and venv.state_dim == 1 + 17 + 15 * 5
     assert venv.single_observation_space["block_positions"].shape == (2 * n_objects,)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
-    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
     venv.reset()
     o = ob.reset()
     knob.value = 1e-13
@@ -1051,8 +1192,8 @@ def test_planar_push_camera_matches_oracle(oracle_mod):
     import mujoco_sim_amd as m
 
     N = 12
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=2032)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2032, nthreads=4)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2032, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2032, nthreads=4, block_shape=1)
     venv.reset()
     o = ob.reset()
     for t in range(4):
@@ -1068,7 +1209,7 @@ def test_planar_push_camera_matches_oracle(oracle_mod):
         assert (diff > 0).mean() < 2e-4 and diff.max() <= 2, (res, (diff > 0).mean(), diff.max())
         assert gpu.std() > 10
     venv.close()
-    vis = m.HipVectorEnv("robot_planar_push", 4, seed=1, observation_type="visual_observations", image_resolution=64)
+    vis = m.HipVectorEnv("robot_planar_push", 4, seed=1, observation_type="visual_observations", image_resolution=64, block_shape="box")
     obs, _ = vis.reset()
     assert list(obs) == ["ur5e/tcp_position", "Camera/rgb_image"] and obs["Camera/rgb_image"].shape == (4, 64, 64, 3)
     assert obs["Camera/rgb_image"].float().std() > 10
