@@ -169,28 +169,57 @@ struct Contact {
   double tran; // body_invweight0 (translation) of the two bodies, summed: diagApprox of the pyramid rows
 };
 
+// the hull tables (vertices relative to the COM) staged in LDS behind the cooperative workspaces (kernel prologue): the scans
+// below read them with per-lane category indices, an uncoalesced gather when served from the constant segment in global memory
+MJS_DEV const double* hull_lds();
+MJS_DEV double hull_c(int cat, int i, int k) { return hull_lds()[(cat * MJS_HULL_MAXV + i) * 3 + k]; }
+// Lanes per env: only EPW lanes of a wavefront carry an env, so the hot path's convex pairs are evaluated by GROUPS of
+// LPE = 64 / EPW lanes (one DPP row of 16, or half a row) that hold the same pair and share the hull scans (COOP = true)
+constexpr int LPE = 64 / EPW;
+static_assert(LPE == 16 || LPE == 8, "group reductions below: one DPP row or half a row per env");
+template <int CTRL>
+MJS_DEV double dppd(double x) {
+  const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), CTRL, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+MJS_DEV int dppi(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+// all-reduce over the lanes of an env group, the same bits in every lane: quad_perm xor 1, xor 2, row_half_mirror, row_mirror
+MJS_DEV double group_max(double x) {
+  x = fmax(x, dppd<0xB1>(x)); x = fmax(x, dppd<0x4E>(x)); x = fmax(x, dppd<0x141>(x));
+  if constexpr (LPE == 16) x = fmax(x, dppd<0x140>(x));
+  return x;
+}
+MJS_DEV int group_min(int x) {
+  x = min(x, dppi<0xB1>(x)); x = min(x, dppi<0x4E>(x)); x = min(x, dppi<0x141>(x));
+  if constexpr (LPE == 16) x = min(x, dppi<0x140>(x));
+  return x;
+}
+// COOP: called by all lanes of an env group with identical arguments; the result is identical in every lane
+template <bool COOP>
 MJS_DEV V3 support(const Geom& g, V3 dir) {
   const V3 loc = rot_t(g.R, dir);
   V3 res;
   if (g.cat >= 0) {
     // hull vertex with the largest projection on the direction; structural ties (a face or an edge square to the direction) go
-    // to the FIRST vertex in table order among those within MPR_EPS_TIE of the maximum, whatever the rounding noise
+    // to the LOWEST table index among the vertices within MPR_EPS_TIE of the maximum, whatever the rounding noise
     const int nvx = MJS_HULL_NV[g.cat];
     const double sc = g.s.x;
+    const double lsx = loc.x * sc, lsy = loc.y * sc, lsz = loc.z * sc;
+    const int first = COOP ? (int)(threadIdx.x & (LPE - 1)) : 0, stride = COOP ? LPE : 1;
     double best = -1e300;
-    for (int i = 0; i < nvx; i++) {
-      const double vx = (MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * sc, vy = (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * sc,
-                   vz = (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * sc;
-      const double pr = loc.x * vx + loc.y * vy + loc.z * vz;
-      if (pr > best) best = pr;
+    for (int i = first; i < nvx; i += stride) {
+      const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
+      best = pr > best ? pr : best;
     }
-    res = v3(0, 0, 0);
-    for (int i = nvx - 1; i >= 0; i--) {
-      const double vx = (MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * sc, vy = (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * sc,
-                   vz = (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * sc;
-      const double pr = loc.x * vx + loc.y * vy + loc.z * vz;
-      if (pr >= best - MPR_EPS_TIE) res = v3(vx, vy, vz);
+    if constexpr (COOP) best = group_max(best);
+    int idx = 1 << 20;
+    for (int i = first; i < nvx; i += stride) {
+      const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
+      if (pr >= best - MPR_EPS_TIE) { idx = i; break; }
     }
+    if constexpr (COOP) idx = group_min(idx);
+    res = v3(hull_c(g.cat, idx, 0) * sc, hull_c(g.cat, idx, 1) * sc, hull_c(g.cat, idx, 2) * sc);
   } else if (g.box) {
     res = v3(loc.x >= -MPR_EPS_DIR ? g.s.x : -g.s.x, loc.y >= -MPR_EPS_DIR ? g.s.y : -g.s.y, loc.z >= -MPR_EPS_DIR ? g.s.z : -g.s.z);
   } else {
@@ -203,10 +232,11 @@ MJS_DEV V3 support(const Geom& g, V3 dir) {
   return v3(w.x + g.c.x, w.y + g.c.y, w.z + g.c.z);
 }
 struct MprVert { V3 v, a, b; };
+template <bool COOP>
 MJS_DEV MprVert mpr_support(const Geom& g1, const Geom& g2, V3 dir) {
   MprVert s;
-  s.a = support(g1, dir);
-  s.b = support(g2, v3(-dir.x, -dir.y, -dir.z));
+  s.a = support<COOP>(g1, dir);
+  s.b = support<COOP>(g2, v3(-dir.x, -dir.y, -dir.z));
   s.v = v3(s.a.x - s.b.x, s.a.y - s.b.y, s.a.z - s.b.z);
   return s;
 }
@@ -225,24 +255,25 @@ MJS_DEV V3 any_perpendicular(V3 v) {
   return cross_nc(v, v3(k == 0 ? 1.0 : 0.0, k == 1 ? 1.0 : 0.0, k == 2 ? 1.0 : 0.0));
 }
 // Minkowski portal refinement on g1 - g2; true + (depth, normal g1 -> g2, pos) when the geoms overlap
+template <bool COOP>
 __device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
   MprVert v0, v1, v2, v3_, v4;
   v0.a = g1.c; v0.b = g2.c; v0.v = sub_nc(g1.c, g2.c);
   if (sqrt(dot_nc(v0.v, v0.v)) < 1e-12) v0.v.x = 1e-5;
   V3 dir = v3(-v0.v.x, -v0.v.y, -v0.v.z);
   normalize_nc(dir);
-  v1 = mpr_support(g1, g2, dir);
+  v1 = mpr_support<COOP>(g1, g2, dir);
   if (dot_nc(v1.v, dir) <= 0) return false;
   dir = cross_nc(v0.v, v1.v);
   if (!normalize_nc(dir)) { dir = any_perpendicular(v0.v); normalize_nc(dir); }
-  v2 = mpr_support(g1, g2, dir);
+  v2 = mpr_support<COOP>(g1, g2, dir);
   if (dot_nc(v2.v, dir) <= 0) return false;
   dir = cross_nc(sub_nc(v1.v, v0.v), sub_nc(v2.v, v0.v));
   if (!normalize_nc(dir)) return false;
   if (dot_nc(dir, v0.v) > MPR_EPS_LEN) { MprVert t = v1; v1 = v2; v2 = t; dir = v3(-dir.x, -dir.y, -dir.z); }
   for (int it = 0;; it++) {  // portal discovery
     if (it >= MJS_MPR_MAX_ITER) return false;
-    v3_ = mpr_support(g1, g2, dir);
+    v3_ = mpr_support<COOP>(g1, g2, dir);
     if (dot_nc(v3_.v, dir) <= 0) return false;
     bool cont = false;
     if (dot_nc(cross_nc(v1.v, v3_.v), v0.v) < -MPR_EPS_VOL) { v2 = v3_; cont = true; }
@@ -256,7 +287,7 @@ __device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, dou
     dir = cross_nc(sub_nc(v2.v, v1.v), sub_nc(v3_.v, v1.v));
     if (!normalize_nc(dir)) return false;
     if (dot_nc(dir, v1.v) >= -MPR_EPS_LEN) hit = true;
-    v4 = mpr_support(g1, g2, dir);
+    v4 = mpr_support<COOP>(g1, g2, dir);
     const double reach = dot_nc(v4.v, dir);
     if (!hit && reach < 0) return false;
     const double progress = dot_nc(sub_nc(v4.v, v3_.v), dir);
@@ -291,7 +322,7 @@ MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, doub
   const double bound = rbound(g1) + rbound(g2);
   if (dot_nc(diff, diff) > bound * bound) return false;
   double depth;
-  if (!mpr_penetration(g1, g2, depth, c.n, c.pos)) return false;
+  if (!mpr_penetration<false>(g1, g2, depth, c.n, c.pos)) return false;
   c.dist = -depth;
   c.ba = ba; c.bb = bb;
   c.tran = tran;
@@ -322,8 +353,7 @@ MJS_DEV Geom block_geom(const Block& b, const M3& R) {
 MJS_DEV int floor_candidates(const Geom& g) { return g.cat >= 0 ? MJS_HULL_NV[g.cat] : 8; }
 MJS_DEV V3 floor_candidate(const Geom& g, int i) {
   if (g.cat >= 0)
-    return v3((MJS_HULL_VERT[g.cat][i][0] - MJS_HULL_COM[g.cat][0]) * g.s.x, (MJS_HULL_VERT[g.cat][i][1] - MJS_HULL_COM[g.cat][1]) * g.s.x,
-              (MJS_HULL_VERT[g.cat][i][2] - MJS_HULL_COM[g.cat][2]) * g.s.x);
+    return v3(hull_c(g.cat, i, 0) * g.s.x, hull_c(g.cat, i, 1) * g.s.x, hull_c(g.cat, i, 2) * g.s.x);
   return v3((i & 1) ? g.s.x : -g.s.x, (i & 2) ? g.s.y : -g.s.y, (i & 4) ? g.s.z : -g.s.z);
 }
 // mjc_PlaneBox against the floor z = 0: corners at or below the plane, at most 4, x index fastest (hull: the same rule on
@@ -410,15 +440,18 @@ struct ConvexHits {
   double dist[NCVX];
   V3 pos[NCVX], n[NCVX];
 };
-MJS_DEV void convex_slot(const Geom& g1, const Geom& g2, ConvexHits& h, int k) {  // k is a compile-time constant at every call site
-  h.hit[k] = false; h.dist[k] = 0; h.pos[k] = v3(0, 0, 0); h.n[k] = v3(0, 0, 1);
+// one convex pair, evaluated by all lanes of an env group together (identical arguments, identical result in every lane)
+struct PairHit { bool hit; double dist; V3 pos, n; };
+MJS_DEV PairHit convex_pair_group(const Geom& g1, const Geom& g2) {
+  PairHit h{false, 0.0, v3(0, 0, 0), v3(0, 0, 1)};
   const V3 diff = sub_nc(g2.c, g1.c);
   const double bound = rbound(g1) + rbound(g2);
-  if (dot_nc(diff, diff) > bound * bound) return;
+  if (dot_nc(diff, diff) > bound * bound) return h;
   double depth;
   V3 nn, pp_;
-  if (!mpr_penetration(g1, g2, depth, nn, pp_)) return;
-  h.hit[k] = true; h.dist[k] = -depth; h.pos[k] = pp_; h.n[k] = nn;
+  if (!mpr_penetration<true>(g1, g2, depth, nn, pp_)) return h;
+  h.hit = true; h.dist = -depth; h.pos = pp_; h.n = nn;
+  return h;
 }
 #pragma clang fp contract(on)
 
@@ -743,6 +776,10 @@ struct CoopLds {
 // to a FLAT instruction (measured: no ds_* instruction at all in physics_step, all fences waiting on vmcnt).
 extern __shared__ double pp_lds_raw[];
 MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
+static_assert(sizeof(CoopLds) % sizeof(double) == 0, "the hull tables follow the workspaces");
+constexpr int HULL_LDS_DOUBLES = MJS_HULL_NCAT * MJS_HULL_MAXV * 3;
+constexpr size_t LDS_BYTES = sizeof(CoopLds) * WAVES + sizeof(double) * HULL_LDS_DOUBLES;  // dynamic LDS of a launch
+MJS_DEV const double* hull_lds() { return pp_lds_raw + (sizeof(CoopLds) * WAVES) / sizeof(double); }
 // exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
 // cooperative solver, which runs after it
 struct QuadIn {
@@ -755,6 +792,30 @@ struct QuadLds {
 };
 static_assert(sizeof(QuadLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
 MJS_DEV QuadLds& quad_lds() { return *reinterpret_cast<QuadLds*>(&coop_lds()); }
+// exchange area of the group-parallel convex pairs (before the quads use the workspace): the env lanes publish their geoms
+// (wrist proxy, EEF cylinder, blocks), every env group evaluates the env's pairs, the env lanes collect the hits
+constexpr int GEOM_DOUBLES = 17;  // c[3], R[9], s[3], box, cat
+struct DetLds {
+  double g[EPW][NB + 2][GEOM_DOUBLES];
+  double out[EPW][NCVX][8];  // hit, dist, pos[3], n[3]
+  int live[EPW];
+};
+static_assert(sizeof(DetLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
+MJS_DEV DetLds& det_lds() { return *reinterpret_cast<DetLds*>(&coop_lds()); }
+MJS_DEV void put_geom(double* d, const Geom& g) {
+  d[0] = g.c.x; d[1] = g.c.y; d[2] = g.c.z;
+  d[3] = g.R.cx.x; d[4] = g.R.cx.y; d[5] = g.R.cx.z; d[6] = g.R.cy.x; d[7] = g.R.cy.y; d[8] = g.R.cy.z; d[9] = g.R.cz.x; d[10] = g.R.cz.y; d[11] = g.R.cz.z;
+  d[12] = g.s.x; d[13] = g.s.y; d[14] = g.s.z; d[15] = g.box ? 1.0 : 0.0; d[16] = (double)g.cat;
+}
+MJS_DEV Geom get_geom(const double* d) {
+  Geom g;
+  g.c = v3(d[0], d[1], d[2]);
+  g.R = M3{v3(d[3], d[4], d[5]), v3(d[6], d[7], d[8]), v3(d[9], d[10], d[11])};
+  g.s = v3(d[12], d[13], d[14]);
+  g.box = d[15] != 0.0;
+  g.cat = (int)d[16];
+  return g;
+}
 // wave broadcast of a double from a compile-time lane
 MJS_DEV double bcast(double x, int src) {
   const int lo = __builtin_amdgcn_readlane(__double2loint(x), src), hi = __builtin_amdgcn_readlane(__double2hiint(x), src);
@@ -1415,16 +1476,63 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     const Geom eg = eef_geom(ch), wg = wrist3_proxy_geom(ch);
     const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
     info.unsupported = info.unsupported || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);  // EEF cylinder below the floor (D-8)
+    // publish this env's geoms for the group-parallel pair evaluation below
+    DetLds& dl = det_lds();
+    const int lane_ = threadIdx.x & 63;
+    put_geom(dl.g[lane_][0], wg);
+    put_geom(dl.g[lane_][1], eg);
+#pragma unroll
+    for (int b = 0; b < NB; b++) put_geom(dl.g[lane_][2 + b], bg[b]);
+  }
+  }  // live (first part)
+  {
+    // convex pairs in MuJoCo's pair order (wrist proxy - block b, EEF - block b, block a - block b): every env group of LPE
+    // lanes evaluates the pairs of its env together (bounding spheres, then MPR with the hull scans split over the lanes)
+    DetLds& dl = det_lds();
+    const int lane_ = threadIdx.x & 63, grp = lane_ / LPE;
+    if (lane_ < EPW) dl.live[lane_] = live ? 1 : 0;
+    MJS_WAVE_SYNC();
+    if (dl.live[grp]) {  // group-uniform
+      Geom gg[NB + 2];
+#pragma unroll
+      for (int k = 0; k < NB + 2; k++) gg[k] = get_geom(dl.g[grp][k]);
+      auto run = [&](int ia, int ib, int slot) {
+        const PairHit h = convex_pair_group(gg[ia], gg[ib]);
+        if ((lane_ & (LPE - 1)) == 0) {
+          double* o = dl.out[grp][slot];
+          o[0] = h.hit ? 1.0 : 0.0; o[1] = h.dist; o[2] = h.pos.x; o[3] = h.pos.y; o[4] = h.pos.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
+        }
+      };
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+        if (b < nb) { run(0, 2 + b, b); run(1, 2 + b, NB + b); }
+#pragma unroll
+      for (int a = 0; a < NB; a++) {
+#pragma unroll
+        for (int b = a + 1; b < NB; b++)
+          if (b < nb) run(2 + a, 2 + b, pair_slot(a, b));
+      }
+    }
+    MJS_WAVE_SYNC();
+  }
+  if (live) {
+  {
+    DetLds& dl = det_lds();
+    const int lane_ = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < NCVX; k++) { cvx.hit[k] = false; cvx.dist[k] = 0; cvx.pos[k] = v3(0, 0, 0); cvx.n[k] = v3(0, 0, 1); }
+    auto take = [&](int slot) {
+      const double* o = dl.out[lane_][slot];
+      cvx.hit[slot] = o[0] != 0.0; cvx.dist[slot] = o[1]; cvx.pos[slot] = v3(o[2], o[3], o[4]); cvx.n[slot] = v3(o[5], o[6], o[7]);
+    };
 #pragma unroll
     for (int b = 0; b < NB; b++)
-      if (b < nb) { convex_slot(wg, bg[b], cvx, b); convex_slot(eg, bg[b], cvx, NB + b); }
+      if (b < nb) { take(b); take(NB + b); }
 #pragma unroll
     for (int a = 0; a < NB; a++) {
 #pragma unroll
       for (int b = a + 1; b < NB; b++)
-        if (b < nb) convex_slot(bg[a], bg[b], cvx, pair_slot(a, b));
+        if (b < nb) take(pair_slot(a, b));
     }
     // the coupled sub-system: the bodies joined by an ACTIVE arm-block / block-block contact; every other block only
     // touches the floor and stays an independent 6-dof problem
@@ -1677,6 +1785,12 @@ __device__ __noinline__ void episode_draws(DevRng rng, int i, int nb, World& s, 
 // run the 150 settle steps of a reset).
 template <bool IS_RESET>
 __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
+  {  // prologue: hull tables -> LDS (every lane of the workgroup runs the whole kernel: uniform control flow)
+    double* dst = pp_lds_raw + (sizeof(CoopLds) * WAVES) / sizeof(double);
+    const double* src = &MJS_HULL_VERT_C[0][0][0];
+    for (int k = threadIdx.x; k < HULL_LDS_DOUBLES; k += 64 * WAVES) dst[k] = src[k];
+    __syncthreads();
+  }
   const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
   const bool valid = (threadIdx.x & 63) < EPW && gi < p.N;
   const int i = valid ? gi : 0;  // helper / padding lanes shadow env 0 and never write

@@ -158,9 +158,9 @@ template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects <= MJS_PP_FAST_OBJECTS)
-    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, sizeof(pp::CoopLds) * pp::WAVES, s>>>(p);
+    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, pp::LDS_BYTES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)  // 3..5 blocks: the 5-slot instance, its cooperative workspace needs the large-LDS opt-in (mjs_create)
-    pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, sizeof(pp5::CoopLds) * pp5::WAVES, s>>>(p);
+    pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
@@ -245,11 +245,16 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   const size_t N = (size_t)cfg->num_envs;
   DeviceGuard dev_(cfg->device);
   hipError_t e = dev_.err;
-  if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) {
-    // > 64 KB of dynamic LDS per workgroup is an opt-in (gfx950 has 160 KB per CU)
-    static_assert(sizeof(pp5::CoopLds) * pp5::WAVES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(pp5::CoopLds) * pp5::WAVES));
-    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(pp5::CoopLds) * pp5::WAVES));
+  if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) {
+    // > 64 KB of dynamic LDS per workgroup is an opt-in (gfx950 has 160 KB per CU): cooperative workspaces + hull tables
+    static_assert(pp5::LDS_BYTES <= 160 * 1024 && pp::LDS_BYTES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
+    if (h->cfg.n_objects > MJS_PP_FAST_OBJECTS) {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp5::LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp5::LDS_BYTES);
+    } else {
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::LDS_BYTES);
+      if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp::LDS_BYTES);
+    }
   }
   if (e == hipSuccess) e = hipMalloc(&h->state, sizeof(double) * h->state_dim * N);
   if (e == hipSuccess) e = hipMalloc(&h->flags, N);

@@ -413,7 +413,7 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
     int cnt = 0;
     for (int i = 0; i < MJS_HULL_NV[cat] && cnt < 4; i++) {
       double loc[3], vert[3];
-      for (int k = 0; k < 3; k++) loc[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
+      for (int k = 0; k < 3; k++) loc[k] = MJS_HULL_VERT_C[cat][i][k] * sc;
       mulMatVec3(vert, gm, loc);
       for (int k = 0; k < 3; k++) vert[k] += gp[k];
       for (int k = 0; k < 3; k++) tmp[k] = vert[k] - pp[k];
@@ -527,23 +527,22 @@ static void support_geom(const om_model* m, const om_data* d, int g, const doubl
     for (int k = 0; k < 3; k++) res[k] = loc[k] >= -MPR_EPS_DIR ? sz[k] : -sz[k];
   } else if (m->geom_type[g] == OM_GEOM_MESH) {
     /* hull vertex with the largest projection on the direction; structural ties (a face or an edge square to the direction) go to
-     * the FIRST vertex in table order among those within MPR_EPS_TIE of the maximum, whatever the rounding noise */
+     * the LOWEST table index among the vertices within MPR_EPS_TIE of the maximum, whatever the rounding noise (two passes: the
+     * rule does not depend on the order of evaluation, so the kernels may split the scan over lanes) */
     const int cat = m->geom_mesh[g];
     const double sc = m->geom_mesh_scale[g];
+    const double ls[3] = {loc[0] * sc, loc[1] * sc, loc[2] * sc};
     double best = -1e300;
+    int idx = 0;
     for (int i = 0; i < MJS_HULL_NV[cat]; i++) {
-      double v[3];
-      for (int k = 0; k < 3; k++) v[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
-      double pr = loc[0] * v[0] + loc[1] * v[1] + loc[2] * v[2];
+      double pr = ls[0] * MJS_HULL_VERT_C[cat][i][0] + ls[1] * MJS_HULL_VERT_C[cat][i][1] + ls[2] * MJS_HULL_VERT_C[cat][i][2];
       if (pr > best) best = pr;
     }
-    res[0] = res[1] = res[2] = 0;
-    for (int i = MJS_HULL_NV[cat] - 1; i >= 0; i--) {
-      double v[3];
-      for (int k = 0; k < 3; k++) v[k] = (MJS_HULL_VERT[cat][i][k] - MJS_HULL_COM[cat][k]) * sc;
-      double pr = loc[0] * v[0] + loc[1] * v[1] + loc[2] * v[2];
-      if (pr >= best - MPR_EPS_TIE) { res[0] = v[0]; res[1] = v[1]; res[2] = v[2]; }
+    for (int i = 0; i < MJS_HULL_NV[cat]; i++) {
+      double pr = ls[0] * MJS_HULL_VERT_C[cat][i][0] + ls[1] * MJS_HULL_VERT_C[cat][i][1] + ls[2] * MJS_HULL_VERT_C[cat][i][2];
+      if (pr >= best - MPR_EPS_TIE) { idx = i; break; }
     }
+    for (int k = 0; k < 3; k++) res[k] = MJS_HULL_VERT_C[cat][idx][k] * sc;
   } else { /* cylinder, axis = local z */
     double len = sqrt(loc[0] * loc[0] + loc[1] * loc[1]);
     if (len > MPR_EPS_DIR) { res[0] = sz[0] * loc[0] / len; res[1] = sz[0] * loc[1] / len; } else { res[0] = 0; res[1] = 0; }
