@@ -31,15 +31,16 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 
 
 def measured_traffic(task, n_local):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_traffic_all_tasks.json: rocprofv3 --pmc
+    """HBM bytes per launch from the committed PMC passes (profiles/r02_traffic_all_tasks.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this very command, FETCH corrected per the gfx950 calibration of
     profiles/r01_traffic.json). Only valid for the configuration it was measured on; otherwise None."""
-    try:
-        d = json.load(open(ROOT / "profiles" / "r01_traffic_all_tasks.json"))["tasks"][task]
-        if n_local == d["envs"]:
-            return d["corrected_bytes_per_launch"]["total"]
-    except Exception:  # noqa: BLE001
-        pass
+    for name in ("r02_traffic_all_tasks.json",):  # measured on the kernels of THIS round (tools/profile_round.sh + collate_profiles.py)
+        try:
+            d = json.load(open(ROOT / "profiles" / name))["tasks"][task]
+            if n_local == d["envs"]:
+                return d["corrected_bytes_per_launch"]["total"]
+        except Exception:  # noqa: BLE001
+            pass
     return None
 
 
@@ -51,6 +52,7 @@ def parse():
     ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button", "robot_planar_push"])
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--n-objects", type=int, default=2, help="Planar-Push blocks: 2 = BASELINE config 4, 5 = the reference's dataclass default")
+    ap.add_argument("--block-shape", default="mesh", choices=["mesh", "box"], help="Planar-Push blocks: the reference's meshes (default) or round 1's box stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
     ap.add_argument("--visual", type=int, default=0, metavar="RES",
@@ -92,13 +94,13 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MJS_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(task, n_envs, seconds, n_objects=2):
+def cpu_baseline(task, n_envs, seconds, n_objects=2, block_shape="mesh"):
     import oracle
 
     tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH,
            "robot_planar_push": oracle.TASK_PLANAR_PUSH}[task]
     cores = host_cores()
-    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores, **({"n_objects": n_objects} if task == "robot_planar_push" else {}))
+    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores, **({"n_objects": n_objects, "block_shape": oracle.BLOCKS_BOX if block_shape == "box" else oracle.BLOCKS_MESH} if task == "robot_planar_push" else {}))
     b.reset()
     acts = make_actions(task, 8, n_envs, "cpu", 12345).numpy()
     b.step(acts[0])  # warm
@@ -202,7 +204,7 @@ def main():
         torch.cuda.set_device(device)
         import mujoco_sim_amd as m
 
-        extra = {"n_objects": args.n_objects} if args.task == "robot_planar_push" else {}
+        extra = {"n_objects": args.n_objects, "block_shape": args.block_shape} if args.task == "robot_planar_push" else {}
         # global seeds: env i of the whole job <- RandomState(2025 + i) whatever the rank count (reach_sac.py:84 seeds sub-env rank with seed + rank)
         venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant, **extra)
         sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
@@ -307,15 +309,15 @@ def main():
             flops = 20 * (725 + 330) + 3000 + 500
             tf = flops * value / 1e12
             line["roofline"]["valu_fp64"] = {"flops_per_env_step": flops, "achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
-                                             "simds_occupied_frac": min(1.0, 2 * (n_local / 64) / 1024)}
-            try:  # PMC view of this very launch shape (profiles/r01_reach_valu.json): VALU busy share of a wavefront's lifetime
-                v = json.load(open(ROOT / "profiles" / "r01_reach_valu.json"))
+                                             "simds_occupied_frac": min(1.0, (2 if args.variant == 2 else 1 if args.variant == 1 else 3) * (n_local / 64) / 1024)}
+            try:  # PMC view of this very launch shape (profiles/r02_reach_valu.json): VALU busy share of a wavefront's lifetime
+                v = json.load(open(ROOT / "profiles" / "r02_reach_valu.json"))
                 if v["envs"] == n_local:
                     line["roofline"]["valu_fp64"]["valu_busy_frac_on_occupied_simds_pmc"] = v["valu_busy_frac_of_wave_lifetime"]
             except Exception:  # noqa: BLE001
                 pass
         if world == 1 and not args.no_cpu_baseline and not args.stub:
-            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects)
+            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects, args.block_shape)
         print(json.dumps(line))
     venv.close()
     if torch.distributed.is_initialized():
