@@ -256,7 +256,7 @@ MJS_DEV V3 any_perpendicular(V3 v) {
 }
 // Minkowski portal refinement on g1 - g2; true + (depth, normal g1 -> g2, pos) when the geoms overlap
 template <bool COOP>
-__device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
+MJS_DEV bool mpr_core(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
   MprVert v0, v1, v2, v3_, v4;
   v0.a = g1.c; v0.b = g2.c; v0.v = sub_nc(g1.c, g2.c);
   if (sqrt(dot_nc(v0.v, v0.v)) < 1e-12) v0.v.x = 1e-5;
@@ -314,6 +314,12 @@ __device__ __noinline__ bool mpr_penetration(const Geom& g1, const Geom& g2, dou
   }
   return false;
 }
+// serial version (reset / contact counting on single lanes): out of line. The group-parallel version of the hot path is inlined
+// into its one call site (a loop over the env's pairs) with the two geoms read from LDS into registers: as a by-reference call
+// every access to a geom was a scratch load by all 64 lanes (profiles/r02_g_*: 1.9 GB of HBM-side traffic per launch).
+__device__ __noinline__ bool mpr_penetration_serial(const Geom& g1, const Geom& g2, double& depth, V3& normal, V3& pos) {
+  return mpr_core<false>(g1, g2, depth, normal, pos);
+}
 MJS_DEV double rbound(const Geom& g) {
   return g.cat >= 0 ? MJS_HULL_RBOUND[g.cat] * g.s.x : g.box ? sqrt(g.s.x * g.s.x + g.s.y * g.s.y + g.s.z * g.s.z) : sqrt(g.s.x * g.s.x + g.s.y * g.s.y);
 }
@@ -322,7 +328,7 @@ MJS_DEV bool collide_convex(const Geom& g1, const Geom& g2, int ba, int bb, doub
   const double bound = rbound(g1) + rbound(g2);
   if (dot_nc(diff, diff) > bound * bound) return false;
   double depth;
-  if (!mpr_penetration<false>(g1, g2, depth, c.n, c.pos)) return false;
+  if (!mpr_penetration_serial(g1, g2, depth, c.n, c.pos)) return false;
   c.dist = -depth;
   c.ba = ba; c.bb = bb;
   c.tran = tran;
@@ -449,7 +455,7 @@ MJS_DEV PairHit convex_pair_group(const Geom& g1, const Geom& g2) {
   if (dot_nc(diff, diff) > bound * bound) return h;
   double depth;
   V3 nn, pp_;
-  if (!mpr_penetration<true>(g1, g2, depth, nn, pp_)) return h;
+  if (!mpr_core<true>(g1, g2, depth, nn, pp_)) return h;
   h.hit = true; h.dist = -depth; h.pos = pp_; h.n = nn;
   return h;
 }
@@ -1493,24 +1499,28 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (lane_ < EPW) dl.live[lane_] = live ? 1 : 0;
     MJS_WAVE_SYNC();
     if (dl.live[grp]) {  // group-uniform
-      Geom gg[NB + 2];
+      // one loop over the pairs (a single inlined copy of the MPR); slot k decodes to its two geoms, which are read from LDS
+#pragma unroll 1
+      for (int k = 0; k < NCVX; k++) {
+        int ia, ib;
+        if (k < NB) { ia = 0; ib = 2 + k; }
+        else if (k < 2 * NB) { ia = 1; ib = 2 + (k - NB); }
+        else {
+          ia = 2; ib = 3;
 #pragma unroll
-      for (int k = 0; k < NB + 2; k++) gg[k] = get_geom(dl.g[grp][k]);
-      auto run = [&](int ia, int ib, int slot) {
-        const PairHit h = convex_pair_group(gg[ia], gg[ib]);
+          for (int a = 0; a < NB; a++) {
+#pragma unroll
+            for (int b = a + 1; b < NB; b++)
+              if (pair_slot(a, b) == k) { ia = 2 + a; ib = 2 + b; }
+          }
+        }
+        if (ib - 2 >= nb) continue;  // ia < ib: both blocks exist
+        const Geom g1 = get_geom(dl.g[grp][ia]), g2 = get_geom(dl.g[grp][ib]);
+        const PairHit h = convex_pair_group(g1, g2);
         if ((lane_ & (LPE - 1)) == 0) {
-          double* o = dl.out[grp][slot];
+          double* o = dl.out[grp][k];
           o[0] = h.hit ? 1.0 : 0.0; o[1] = h.dist; o[2] = h.pos.x; o[3] = h.pos.y; o[4] = h.pos.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
         }
-      };
-#pragma unroll
-      for (int b = 0; b < NB; b++)
-        if (b < nb) { run(0, 2 + b, b); run(1, 2 + b, NB + b); }
-#pragma unroll
-      for (int a = 0; a < NB; a++) {
-#pragma unroll
-        for (int b = a + 1; b < NB; b++)
-          if (b < nb) run(2 + a, 2 + b, pair_slot(a, b));
       }
     }
     MJS_WAVE_SYNC();
