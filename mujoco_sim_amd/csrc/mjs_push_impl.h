@@ -437,6 +437,40 @@ MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
   }
   return fs;
 }
+// the same slots computed by all lanes of an env group together (identical arguments, identical result in every lane): the
+// candidates are dealt to the lanes, the (at most) four LOWEST candidate indices at or below the floor are found by group
+// minima, and every lane rebuilds their slot data. A block that is being pushed rocks on fewer than four bottom vertices, and
+// the serial scan then walks the whole hull (96 vertices) in every substep.
+#pragma clang fp contract(off)
+MJS_DEV FloorSlots floor_slots_group(const Geom& g, V3 origin) {
+  FloorSlots fs;
+#pragma unroll
+  for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
+  const int ncand = floor_candidates(g), sub = (int)(threadIdx.x & (LPE - 1));
+  constexpr int NONE = 1 << 20;
+  unsigned long long mine = 0;  // bit j: this lane's j-th candidate (index sub + j * LPE) is at or below the floor
+  for (int j = 0, i = sub; i < ncand; j++, i += LPE) {
+    const V3 lc = floor_candidate(g, i);
+    const double z = g.R.cx.z * lc.x + g.R.cy.z * lc.y + g.R.cz.z * lc.z + g.c.z;
+    if (!(z > 0.0)) mine |= 1ull << j;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int my = mine ? sub + (__ffsll((long long)mine) - 1) * LPE : NONE;
+    const int idx = group_min(my);
+    if (idx == NONE) break;  // group-uniform
+    if (my == idx) mine &= mine - 1;
+    const V3 lc = floor_candidate(g, idx);
+    const double lx = lc.x, ly = lc.y, lz = lc.z;
+    const V3 corner = v3(g.R.cx.x * lx + g.R.cy.x * ly + g.R.cz.x * lz + g.c.x, g.R.cx.y * lx + g.R.cy.y * ly + g.R.cz.y * lz + g.c.y,
+                         g.R.cx.z * lx + g.R.cy.z * ly + g.R.cz.z * lz + g.c.z);
+    const double dist = corner.z;
+    fs.on[k] = dist < 0.0; fs.dist[k] = dist;
+    fs.r[k] = v3(corner.x - origin.x, corner.y - origin.y, (corner.z - dist * 0.5) - origin.z);
+  }
+  return fs;
+}
+#pragma clang fp contract(on)
 // convex pairs of the scene in MuJoCo's pair order: wrist proxy - block b (NB slots), EEF - block b (NB), block a - block b
 // (a < b, row-major)
 constexpr int NCVX = 2 * NB + (NB * (NB - 1)) / 2;
@@ -803,7 +837,9 @@ MJS_DEV QuadLds& quad_lds() { return *reinterpret_cast<QuadLds*>(&coop_lds()); }
 constexpr int GEOM_DOUBLES = 17;  // c[3], R[9], s[3], box, cat
 struct DetLds {
   double g[EPW][NB + 2][GEOM_DOUBLES];
-  double out[EPW][NCVX][8];  // hit, dist, pos[3], n[3]
+  double org[EPW][NB][3];          // block body origins
+  double out[EPW][NCVX][8];        // hit, dist, pos[3], n[3]
+  double fl[EPW][NB][4][5];        // floor slots: on, dist, r[3]
   int live[EPW];
 };
 static_assert(sizeof(DetLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
@@ -1476,7 +1512,6 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     bg[b] = block_geom(s.b[b], Rb[b]);
-    fs[b] = floor_slots(bg[b], s.b[b].p);
   }
   {
     const Geom eg = eef_geom(ch), wg = wrist3_proxy_geom(ch);
@@ -1488,7 +1523,10 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     put_geom(dl.g[lane_][0], wg);
     put_geom(dl.g[lane_][1], eg);
 #pragma unroll
-    for (int b = 0; b < NB; b++) put_geom(dl.g[lane_][2 + b], bg[b]);
+    for (int b = 0; b < NB; b++) {
+      put_geom(dl.g[lane_][2 + b], bg[b]);
+      dl.org[lane_][b][0] = s.b[b].p.x; dl.org[lane_][b][1] = s.b[b].p.y; dl.org[lane_][b][2] = s.b[b].p.z;
+    }
   }
   }  // live (first part)
   {
@@ -1499,6 +1537,19 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (lane_ < EPW) dl.live[lane_] = live ? 1 : 0;
     MJS_WAVE_SYNC();
     if (dl.live[grp]) {  // group-uniform
+      // floor contacts of every block (static slots), by the whole group
+#pragma unroll 1
+      for (int b = 0; b < NB; b++) {
+        const Geom gb = get_geom(dl.g[grp][2 + b]);
+        const FloorSlots f = floor_slots_group(gb, v3(dl.org[grp][b][0], dl.org[grp][b][1], dl.org[grp][b][2]));
+        if ((lane_ & (LPE - 1)) == 0) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            double* o = dl.fl[grp][b][k];
+            o[0] = f.on[k] ? 1.0 : 0.0; o[1] = f.dist[k]; o[2] = f.r[k].x; o[3] = f.r[k].y; o[4] = f.r[k].z;
+          }
+        }
+      }
       // one loop over the pairs (a single inlined copy of the MPR); slot k decodes to its two geoms, which are read from LDS
 #pragma unroll 1
       for (int k = 0; k < NCVX; k++) {
@@ -1531,6 +1582,14 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     const int lane_ = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < NCVX; k++) { cvx.hit[k] = false; cvx.dist[k] = 0; cvx.pos[k] = v3(0, 0, 0); cvx.n[k] = v3(0, 0, 1); }
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const double* o = dl.fl[lane_][b][k];
+        fs[b].on[k] = o[0] != 0.0; fs[b].dist[k] = o[1]; fs[b].r[k] = v3(o[2], o[3], o[4]);
+      }
+    }
     auto take = [&](int slot) {
       const double* o = dl.out[lane_][slot];
       cvx.hit[slot] = o[0] != 0.0; cvx.dist[slot] = o[1]; cvx.pos[slot] = v3(o[2], o[3], o[4]); cvx.n[slot] = v3(o[5], o[6], o[7]);
