@@ -228,7 +228,7 @@ static void build_button(om_model* m) {
 
 /* Planar-Push scene (robot_planar_push.py:81-117): UR5e + CylinderEEF (cylinder.py:23-33) + n free blocks
  * (box stand-in for the cube mesh of google_block.py, deviation D-9); the target is a site (no collision). */
-double om_dbg_perturb = 0; /* test knob (tests only): offset added to block 0's x AND drop height z after the reset draws (the
+double om_dbg_perturb = 0; /* test knob (tests only): offset added to every block's x AND drop height z after the reset draws (the
                             * floor is translation-invariant in x: a pure x offset does not probe a lone block's tumbling) */
 static void build_push(om_model* m, int n_objects) {
   build_robot(m, 0);
@@ -422,7 +422,10 @@ static void episode_init(om_env* e) {
       om_forward(m, d);
       if (d->ncon == 0) break;
     }
-    if (om_dbg_perturb != 0) { d->qpos[6] += om_dbg_perturb; d->qpos[8] += om_dbg_perturb; om_forward(m, d); } /* test knob: sensitivity of the settle phase */
+    if (om_dbg_perturb != 0) { /* test knob: sensitivity of the settle phase (every block, offsets of different size) */
+      for (int i = 0; i < e->cfg.n_objects; i++) { d->qpos[6 + 7 * i] += om_dbg_perturb * (1 + i); d->qpos[6 + 7 * i + 2] += om_dbg_perturb * (1 + 0.5 * i); }
+      om_forward(m, d);
+    }
     for (int s = 0; s < MJS_PP_SETTLE_STEPS; s++) om_physics_step(m, d);
     return;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH) {

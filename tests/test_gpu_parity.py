@@ -1094,8 +1094,8 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
     assert sens.mean() < 0.2 and n_last >= N
 
 
-@pytest.mark.parametrize("n_objects", [3, 5])
-def test_planar_push_many_objects(oracle_mod, n_objects):
+@pytest.mark.parametrize("n_objects,shape", [(3, "box"), (5, "box"), (5, "mesh"), (4, "mesh")])
+def test_planar_push_many_objects(oracle_mod, n_objects, shape):
     """n_objects 3..5 (5 = RobotPushConfig's default, robot_planar_push.py:61) run the 5-slot kernel instance: 15-wide flat
     observation, up to 10 block-block pairs, nv = 36. Seeded episodes with pushes, step-limit truncations and
     device-side resets against the oracle, on the envs the oracle itself calls well-conditioned."""
@@ -1105,11 +1105,11 @@ def test_planar_push_many_objects(oracle_mod, n_objects):
 
     N, T, LIMIT = 16, 16, 7
     knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=77, n_objects=n_objects, max_episode_steps=LIMIT, block_shape="box")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=77, n_objects=n_objects, max_episode_steps=LIMIT, block_shape=shape)
     assert venv.obs_dim == 15 and venv.state_dim == 1 + 17 + 15 * 5
     assert venv.single_observation_space["block_positions"].shape == (2 * n_objects,)
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
-    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1 if shape == "box" else 0)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 77, n_objects=n_objects, max_episode_steps=LIMIT, nthreads=8, block_shape=1 if shape == "box" else 0)
     venv.reset()
     o = ob.reset()
     knob.value = 1e-13
@@ -1186,14 +1186,16 @@ def test_contact_tasks_shard_invariance(task, kw):
     assert (whole._buf["ncon"].cpu().numpy() > 0).any()
 
 
-def test_planar_push_camera_matches_oracle(oracle_mod):
+@pytest.mark.parametrize("shape", ["mesh", "box"])
+def test_planar_push_camera_matches_oracle(oracle_mod, shape):
     """Planar-Push scene camera (robot_planar_push.py:45,111-116: the FRONT_TILTED camera): arm, CylinderEEF, target
-    disc, blocks; same bar as the other robot scenes. Also the VISUAL_OBS observation dict (:140-142)."""
+    disc, blocks (a mesh block = the scaled bounding box of its hull in its sampled colour); same bar as the other robot
+    scenes. Also the VISUAL_OBS observation dict (:140-142)."""
     import mujoco_sim_amd as m
 
     N = 12
-    venv = m.HipVectorEnv("robot_planar_push", N, seed=2032, block_shape="box")
-    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2032, nthreads=4, block_shape=1)
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=2032, block_shape=shape)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 2032, nthreads=4, block_shape=1 if shape == "box" else 0)
     venv.reset()
     o = ob.reset()
     for t in range(4):
@@ -1209,7 +1211,7 @@ def test_planar_push_camera_matches_oracle(oracle_mod):
         assert (diff > 0).mean() < 2e-4 and diff.max() <= 2, (res, (diff > 0).mean(), diff.max())
         assert gpu.std() > 10
     venv.close()
-    vis = m.HipVectorEnv("robot_planar_push", 4, seed=1, observation_type="visual_observations", image_resolution=64, block_shape="box")
+    vis = m.HipVectorEnv("robot_planar_push", 4, seed=1, observation_type="visual_observations", image_resolution=64, block_shape=shape)
     obs, _ = vis.reset()
     assert list(obs) == ["ur5e/tcp_position", "Camera/rgb_image"] and obs["Camera/rgb_image"].shape == (4, 64, 64, 3)
     assert obs["Camera/rgb_image"].float().std() > 10
