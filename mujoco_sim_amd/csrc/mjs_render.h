@@ -525,6 +525,19 @@ MJS_DEV void hit_obb(F3 o, F3 d, F3 c, F3 u, F3 v, F3 half, F3 rgb, Surf& s) {
   s.rgb = rgb;
 }
 
+// A sphere or box that contains the eye can never be hit (hit_sphere: the near root is negative; hit_obb: no slab is
+// entered at t > 0), so both kernels drop it before any per-ray work. This is the camera's own body (camera_body_prims
+// puts a box and a lens sphere AT the camera position): without the rule every ray of the image runs both exact tests.
+MJS_DEV bool eye_inside(const float* pr, F3 eye) {
+  const int type = (int)pr[0];
+  const F3 oc = sub(eye, f3(pr[1], pr[2], pr[3]));
+  if (type == PRIM_SPHERE) return dotf(oc, oc) < pr[13] * pr[13] * 0.999f;
+  if (type != PRIM_BOX) return false;
+  const F3 u = f3(pr[4], pr[5], pr[6]), v = f3(pr[7], pr[8], pr[9]);
+  const F3 w = F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+  return fabsf(dotf(oc, u)) < pr[10] * 0.999f && fabsf(dotf(oc, v)) < pr[11] * 0.999f && fabsf(dotf(oc, w)) < pr[12] * 0.999f;
+}
+
 // One wavefront per 8x8 pixel tile (4 tiles per workgroup). The env's primitive list is staged in LDS once per
 // workgroup; lane k of every wavefront tests primitive k against the cone that bounds the tile's 64 rays, and the
 // ballot of that test is the list of primitives the wavefront walks (typically 0-3 of ~20). All of this only
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
       const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
       const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
       const float L2 = dotf(oc, oc), br = pr[17];
-      if (L2 <= br * br) c = true;  // the eye is inside the bound
+      if (L2 <= br * br) c = !eye_inside(pr, eye);  // the eye is inside the bound (inside the primitive itself: never hit)
       else {
         const float L = sqrtf(L2), cost = dotf(oc, dc) / L, sinb = br / L;
         const float cosb = sqrtf(fmaxf(0.0f, 1.0f - sinb * sinb)), sina = sqrtf(fmaxf(0.0f, 1.0f - cosa * cosa));
@@ -617,17 +630,44 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
 }
 
 
-// ---- primitive-major variant: one workgroup per band of rows of an env image --------------------------------------
+// ---- primitive-major variant: one workgroup per env image (fixed scene cameras, images up to 64x64, H and W multiples of 8)
 // The tile walk above makes every 8x8 tile test every primitive whose bound touches the tile's ray cone; at 64x64 a
 // tile is ~30 cm wide at the arm's distance, so most exact tests are for rays that miss. Here the loop is turned
 // inside out: each wavefront takes primitives, projects the primitive's bound to a pixel rectangle (exact tangent
 // extents of the end spheres, padded) and runs the exact test only on 8x8 blocks of that rectangle; the nearest hit
 // per pixel is an LDS ds_min_u64 on the key (float bits of t, primitive index) = "smallest t, first primitive
-// wins", which is what the sequential strict-< update of the tile walk / the oracle computes. A second pass shades:
-// floor hit, key lookup, the winner's exact test once more for its normal, Blinn-Phong, store. Same arithmetic per
-// ray and per test as the tile kernel: the image is identical.
-constexpr int RASTER_IMAGE_PIXELS = 64 * 64;  // 32 KB of depth keys: the launch uses one band = the whole image (see mjs_render in mjsim.hip)
-inline size_t raster_lds_bytes_host(int rows, int W) { return (size_t)rows * W * 8 + MAX_NPRIM * PRIM_FLOATS * 4 + MAX_NPRIM * 4 * 4; }
+// wins", which is what the sequential strict-< update of the tile walk / the oracle computes. A second pass shades the
+// pixels a primitive won (the winner's exact test once more for its normal, Blinn-Phong).
+//
+// Everything that does not depend on the env is computed ONCE per (camera, H, W) by scene_background_kernel and kept in
+// HBM/L2 (20 B per pixel): the normalised pixel ray, the floor's ray parameter and the shaded floor/background colour.
+// A fixed camera sees the same floor in every env, so the second pass shades only primitive pixels (a few % of the
+// image) and copies the rest. Same arithmetic per ray, per test and per shaded pixel as the tile kernel, evaluated by
+// the same functions: the image is identical (tests: test_scene_camera_kernels_agree_byte_for_byte).
+constexpr int RASTER_IMAGE_PIXELS = 64 * 64;  // 32 KB of depth keys
+inline size_t raster_lds_bytes_host(int H, int W) { return (size_t)H * W * 8 + MAX_NPRIM * PRIM_FLOATS * 4 + MAX_NPRIM * 4 * 4; }
+struct Background {
+  const float4* ray;    // [H*W] normalised ray direction (xyz) and the floor's ray parameter (w; +inf = no floor there)
+  const uint32_t* rgb;  // [H*W] shaded floor / background colour, r | g << 8 | b << 16
+};
+MJS_DEV uint32_t pack_rgb(F3 c) { return (uint32_t)to_u8(c.x) | ((uint32_t)to_u8(c.y) << 8) | ((uint32_t)to_u8(c.z) << 16); }
+__global__ __launch_bounds__(256) void scene_background_kernel(RenderParams p, float4* ray, uint32_t* rgb) {
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= p.H * p.W) return;
+  const int row = px / p.W, col = px - row * p.W;
+  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+  const F3 d = pixel_ray(p, row, col);
+  Surf s;
+  s.t = INFINITY;
+  s.n = f3(0, 0, 1);
+  s.rgb = f3(0, 0, 0);
+  hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+  F3 c = f3(0, 0, 0);
+  if (s.t < INFINITY) c = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
+  ray[px] = make_float4(d.x, d.y, d.z, s.t);
+  rgb[px] = pack_rgb(c);
+}
+
 extern __shared__ unsigned long long raster_lds[];
 MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   const int type = (int)pr[0];
@@ -638,10 +678,9 @@ MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
   else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
 }
-__global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p, const float* prims, int band_rows) {
-  const int env = blockIdx.y, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int band0 = blockIdx.x * band_rows, band1 = min(band0 + band_rows, p.H) - 1;  // rows [band0, band1] of the image
-  const int npix = (band1 - band0 + 1) * p.W;
+__global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p, const float* prims, Background bg) {
+  const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npix = p.H * p.W;
   unsigned long long* depth = raster_lds;
   float* lds_prims = reinterpret_cast<float*>(raster_lds + npix);
   int* bbox = reinterpret_cast<int*>(lds_prims + MAX_NPRIM * PRIM_FLOATS);  // r0, r1, c0, c1 per primitive
@@ -650,17 +689,10 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
     for (int k = tid; k < npix; k += 256) depth[k] = ~0ull;
   }
-  F3 eye;
+  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
   const float* right = p.cam.right;
   const float* up = p.cam.up;
   const float* back = p.cam.back;
-  if (p.env_cams) {
-    const float* cm = p.env_cams + (size_t)env * 12;
-    eye = f3(cm[0], cm[1], cm[2]);
-    right = cm + 3; up = cm + 6; back = cm + 9;
-  } else {
-    eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-  }
   __syncthreads();
   if (tid < nprim) {  // pixel rectangle of the primitive's bound: tangent extents of its bounding sphere(s), padded
     const float* pr = lds_prims + tid * PRIM_FLOATS;
@@ -669,7 +701,7 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     const float rad = two ? bound_radius(pr[13]) : pr[17];
     const float aspect = (float)p.W / (float)p.H, tx = p.cam.tan_half * aspect, ty = p.cam.tan_half;
     float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    bool everything = false, behind = true;  // behind: the whole bound lies behind the camera plane (most of the arm for the wrist camera)
+    bool everything = false, behind = true;  // behind: the whole bound lies behind the camera plane
     for (int e = 0; e < (two ? 2 : 1); e++) {
       const F3 v = sub(f3(pr[1 + 3 * e], pr[2 + 3 * e], pr[3 + 3 * e]), eye);
       const float x = v.x * right[0] + v.y * right[1] + v.z * right[2], y = v.x * up[0] + v.y * up[1] + v.z * up[2];
@@ -691,13 +723,11 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
       r0 = (int)floorf(fminf(fmaxf(rl, -1.0f), (float)p.H)) - 1; r1 = (int)ceilf(fminf(fmaxf(rh, -1.0f), (float)p.H)) + 1;
       c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, p.W - 1); r1 = min(r1, p.H - 1);
     }
-    r0 = max(r0, band0); r1 = min(r1, band1);  // this workgroup's band (possibly empty)
-    if (behind) r1 = r0 - 1;                   // nothing of it can be seen: empty rectangle
+    if (behind || eye_inside(pr, eye)) r1 = r0 - 1;  // nothing of it can be seen: empty rectangle
     bbox[4 * tid] = r0; bbox[4 * tid + 1] = r1; bbox[4 * tid + 2] = c0; bbox[4 * tid + 3] = c1;
   }
   __syncthreads();
-  int turn = 0;  // 8x8 blocks of all primitives are dealt round-robin to the 4 wavefronts (a primitive whose bound reaches
-                 // the camera plane covers the whole image: whole primitives per wavefront would leave three idle)
+  int turn = 0;  // 8x8 blocks of all primitives are dealt round-robin to the 4 wavefronts
   for (int k = 0; k < nprim; k++) {  // wave-uniform
     const float* pr = lds_prims + k * PRIM_FLOATS;
     const int type = (int)pr[0];
@@ -710,7 +740,8 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
         if (((turn++) & 3) != wave) continue;
         const int row = rb + (lane >> 3), col = cb + (lane & 7);
         const bool in = row <= r1 && col <= c1;
-        const F3 d = pixel_ray_axes(p, row, col, right, up, back);
+        const float4 r4 = bg.ray[in ? row * p.W + col : 0];
+        const F3 d = f3(r4.x, r4.y, r4.z);
         const float along = dotf(oc, d), off2 = ococ - along * along;  // per-ray bounding-sphere reject (as in the tile kernel)
         const bool pass = in && off2 <= br * br && along + br > 0.0f;
         if (!__any(pass)) continue;
@@ -720,34 +751,41 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
         s.rgb = f3(0, 0, 0);
         if (pass) exact_test(pr, eye, d, s);
         if (pass && s.t < INFINITY)
-          atomicMin(&depth[(row - band0) * p.W + col], ((unsigned long long)__float_as_uint(s.t) << 32) | (unsigned)k);
+          atomicMin(&depth[row * p.W + col], ((unsigned long long)__float_as_uint(s.t) << 32) | (unsigned)k);
       }
     }
   }
   __syncthreads();
-  for (int px = tid; px < npix; px += 256) {
-    const int lrow = px / p.W, col = px - lrow * p.W, row = band0 + lrow;
-    const F3 d = pixel_ray_axes(p, row, col, right, up, back);
-    Surf s;
-    s.t = INFINITY;
-    s.n = f3(0, 0, 1);
-    s.rgb = f3(0, 0, 0);
-    hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+  // second pass, one 8x8 tile per wavefront and turn (neighbouring pixels share the winner's type and the lights that reach
+  // them); the packed colour goes back into the pixel's own depth slot
+  const int tiles_x = p.W >> 3, ntiles = npix >> 6;
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int row = (tile / tiles_x) * 8 + (lane >> 3), col = (tile % tiles_x) * 8 + (lane & 7), px = row * p.W + col;
     const unsigned long long key = depth[px];
-    if (key != ~0ull && __uint_as_float((unsigned)(key >> 32)) < s.t) {
+    const float4 r4 = bg.ray[px];
+    uint32_t c = bg.rgb[px];
+    if (key != ~0ull && __uint_as_float((unsigned)(key >> 32)) < r4.w) {
+      const F3 d = f3(r4.x, r4.y, r4.z);
       Surf w;
       w.t = INFINITY;
       w.n = f3(0, 0, 1);
       w.rgb = f3(0, 0, 0);
       exact_test(lds_prims + (int)(key & 0xffffffffu) * PRIM_FLOATS, eye, d, w);  // the winner once more, for its normal
-      s = w;
+      F3 cc = f3(0, 0, 0);
+      if (w.t < INFINITY) cc = shade<6>(add(eye, mul(w.t, d)), w.n, eye, w.rgb, MJS_RR_LIGHT_POS);
+      c = pack_rgb(cc);
     }
-    F3 c = f3(0, 0, 0);
-    if (s.t < INFINITY) c = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
-    uint8_t* o = p.out + ((size_t)env * p.H * p.W + (size_t)band0 * p.W + px) * 3;
-    o[0] = to_u8(c.x);
-    o[1] = to_u8(c.y);
-    o[2] = to_u8(c.z);
+    reinterpret_cast<uint32_t*>(depth)[2 * px] = c;
+  }
+  __syncthreads();
+  // write-out: 4 pixels = 12 bytes = 3 dwords per lane and turn, consecutive lanes write consecutive addresses
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + (size_t)env * npix * 3);
+  for (int q = tid; q < (npix >> 2); q += 256) {
+    const uint32_t* cs = reinterpret_cast<const uint32_t*>(depth) + 8 * q;
+    const uint32_t a = cs[0], b = cs[2], c = cs[4], d = cs[6];
+    o32[3 * q + 0] = a | (b << 24);
+    o32[3 * q + 1] = (b >> 8) | (c << 16);
+    o32[3 * q + 2] = (c >> 16) | (d << 8);
   }
 }
 

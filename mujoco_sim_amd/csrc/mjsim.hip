@@ -28,6 +28,9 @@ struct mjs_handle {
   int32_t* rng_pos;  // [N]
   unsigned long long* stamps;  // diagnostic builds only
   float* prims;                // [N][nprim][PRIM_FLOATS] render primitive list (robot scenes)
+  float4* bg_ray = nullptr;    // [bg_H * bg_W] scene-camera ray table (rend::Background), built at the first render of a size
+  uint32_t* bg_rgb = nullptr;
+  int bg_H = 0, bg_W = 0;
   float* cams;                 // [N][12] wrist-camera poses (Button-Push)
   std::string err;
 };
@@ -328,6 +331,8 @@ void mjs_destroy(mjs_handle* h) {
   if (h->rng_mt) (void)hipFree(h->rng_mt);
   if (h->rng_pos) (void)hipFree(h->rng_pos);
   if (h->prims) (void)hipFree(h->prims);
+  if (h->bg_ray) (void)hipFree(h->bg_ray);
+  if (h->bg_rgb) (void)hipFree(h->bg_rgb);
   if (h->cams) (void)hipFree(h->cams);
   delete h;
 }
@@ -417,15 +422,26 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
   const int tiles = ((height + 7) / 8) * ((width + 7) / 8);  // robot scenes: one wavefront per 8x8 tile
   dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
-  // robot scenes: the primitive-major kernel (one workgroup per env image, depth keys in LDS) for the fixed scene
-  // cameras up to 64x64 pixels. Measured (profiles/r01_j_render_ab.txt): 17-37 % faster there; slower than the tile walk
-  // for larger images (bands of rows repeat the per-primitive work, one workgroup per image starves the CUs of waves)
-  // and for the wrist camera (the gripper's bounds reach the camera plane: whole-image passes per primitive).
-  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && !wrist && h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
-  const int band_rows = height;
-  const size_t raster_lds = rend::raster_lds_bytes_host(band_rows, width);
+  // robot scenes: the primitive-major kernel (one workgroup per env image, depth keys in LDS, env-independent rays and
+  // floor colours from a table computed once per camera and size) for the fixed scene cameras up to 64x64 pixels.
+  // Slower than the tile walk for the wrist camera (the gripper's bounds reach the camera plane: whole-image passes per
+  // primitive; profiles/r02_g_render_ladder.txt), not applicable to larger images (32 KB of LDS depth keys per image).
+  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && height % 8 == 0 && width % 8 == 0 && !wrist &&
+                      h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
+  if (raster && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
+    if (h->bg_ray) (void)hipFree(h->bg_ray);
+    if (h->bg_rgb) (void)hipFree(h->bg_rgb);
+    h->bg_ray = nullptr; h->bg_rgb = nullptr; h->bg_H = h->bg_W = 0;
+    HIP_TRY(h, hipMalloc(&h->bg_ray, sizeof(float4) * height * width));
+    HIP_TRY(h, hipMalloc(&h->bg_rgb, sizeof(uint32_t) * height * width));
+    rend::scene_background_kernel<<<(unsigned)((height * width + 255) / 256), 256, 0, (hipStream_t)stream>>>(p, h->bg_ray, h->bg_rgb);
+    HIP_TRY(h, hipGetLastError());
+    HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));  // once per size: later renders may come on another stream
+    h->bg_H = height; h->bg_W = width;
+  }
+  const size_t raster_lds = rend::raster_lds_bytes_host(height, width);
   auto robot_scene = [&]() {
-    if (raster) rend::robot_scene_raster_kernel<<<dim3((unsigned)((height + band_rows - 1) / band_rows), (unsigned)p.N), 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, band_rows);
+    if (raster) rend::robot_scene_raster_kernel<<<(unsigned)p.N, 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
     else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   };
   const bool fresh = h->prims_valid && h->prims_stream == stream;  // same state, same stream: the list is still good
