@@ -668,6 +668,64 @@ __global__ __launch_bounds__(256) void scene_background_kernel(RenderParams p, f
   rgb[px] = pack_rgb(c);
 }
 
+// Tan-space bounding rectangle (x / depth, y / depth) of an oriented box clipped at the near plane depth = zn, for
+// primitives whose bounding spheres reach the camera plane (the gripper next to the wrist camera): the extremes of a
+// linear-fractional function over a convex polytope lie at its vertices, so the rectangle of the clipped box's vertices
+// (corners in front of the plane + edge crossings) bounds every ray that can hit it at depth >= zn. Returns false if
+// the whole box is behind the plane. C, A, B, D: box centre and scaled half-axes in camera coordinates (x right, y up,
+// z depth).
+MJS_DEV bool clipped_box_rect(const float* C, const float* A, const float* B, const float* D, float zn, float& xlo, float& xhi, float& ylo, float& yhi) {
+  xlo = ylo = INFINITY;
+  xhi = yhi = -INFINITY;
+  bool any = false;
+  for (int i = 0; i < 8; i++) {
+    const float sa = (i & 1) ? 1.0f : -1.0f, sb = (i & 2) ? 1.0f : -1.0f, sd = (i & 4) ? 1.0f : -1.0f;
+    const float P[3] = {C[0] + sa * A[0] + sb * B[0] + sd * D[0], C[1] + sa * A[1] + sb * B[1] + sd * D[1], C[2] + sa * A[2] + sb * B[2] + sd * D[2]};
+    if (!(P[2] > zn)) continue;
+    any = true;
+    const float iz = 1.0f / P[2];
+    xlo = fminf(xlo, P[0] * iz); xhi = fmaxf(xhi, P[0] * iz);
+    ylo = fminf(ylo, P[1] * iz); yhi = fmaxf(yhi, P[1] * iz);
+    for (int e = 0; e < 3; e++) {  // the three edges leaving this corner: towards a corner at or behind the plane?
+      const float* E = e == 0 ? A : e == 1 ? B : D;
+      const float se = -2.0f * (e == 0 ? sa : e == 1 ? sb : sd);
+      const float Q2 = P[2] + se * E[2];
+      if (Q2 > zn) continue;
+      const float f = (P[2] - zn) / (P[2] - Q2);  // in (0, 1]
+      const float X = (P[0] + f * se * E[0]) / zn, Y = (P[1] + f * se * E[1]) / zn;
+      xlo = fminf(xlo, X); xhi = fmaxf(xhi, X);
+      ylo = fminf(ylo, Y); yhi = fmaxf(yhi, Y);
+    }
+  }
+  return any;
+}
+// the primitive as an oriented box (centre c, unit axes u v w, half sizes h), inflated for float32 safety
+MJS_DEV void prim_box(const float* pr, F3 eye, F3& c, F3& u, F3& v, F3& w, F3& h) {
+  const int type = (int)pr[0];
+  if (type == PRIM_BOX) {
+    c = f3(pr[1], pr[2], pr[3]); u = f3(pr[4], pr[5], pr[6]); v = f3(pr[7], pr[8], pr[9]);
+    w = F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    h = f3(pr[10], pr[11], pr[12]);
+  } else if (type == PRIM_SPHERE) {
+    c = f3(pr[1], pr[2], pr[3]); u = f3(1, 0, 0); v = f3(0, 1, 0); w = f3(0, 0, 1);
+    h = f3(pr[13], pr[13], pr[13]);
+  } else {  // capsule / cylinder: the box around the segment and its radius (a capsule's round caps reach a radius further)
+    const F3 pa = f3(pr[1], pr[2], pr[3]), pb = f3(pr[4], pr[5], pr[6]), ba = sub(pb, pa);
+    const float len = sqrtf(dotf(ba, ba));
+    c = mul(0.5f, add(pa, pb));
+    u = len > 1.0e-6f ? mul(1.0f / len, ba) : f3(0, 0, 1);
+    // radial axes: v towards the eye (a round primitive has no preferred ones; this choice keeps the box's corners, which
+    // stick out of the round surface, away from an eye that is close to it)
+    const F3 ce = sub(eye, c);
+    const F3 perp = sub(ce, mul(dotf(ce, u), u));
+    const F3 e = fabsf(u.x) < 0.9f ? f3(1, 0, 0) : f3(0, 1, 0);
+    v = dotf(perp, perp) > 1.0e-10f ? normalize(perp) : normalize(F3{u.y * e.z - u.z * e.y, u.z * e.x - u.x * e.z, u.x * e.y - u.y * e.x});
+    w = F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    h = f3(0.5f * len + (type == PRIM_CAPSULE ? pr[13] : 0.0f), pr[13], pr[13]);
+  }
+  h = f3(h.x * 1.02f + 1.0e-3f, h.y * 1.02f + 1.0e-3f, h.z * 1.02f + 1.0e-3f);
+}
+
 extern __shared__ unsigned long long raster_lds[];
 MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   const int type = (int)pr[0];
@@ -678,6 +736,64 @@ MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
   else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
 }
+// Pixel rectangle [r0, r1] x [c0, c1] that bounds every pixel whose ray can hit the primitive (empty: r1 < r0). Far
+// primitives: tangent extents of the bounding sphere(s); primitives whose spheres reach the camera plane (the gripper and
+// the last wrist links next to the wrist camera): the primitive's box clipped at 1 mm depth; both when both apply.
+// Conservative by construction: it only SKIPS exact tests that cannot hit.
+MJS_DEV void prim_rect(const RenderParams& p, const float* pr, F3 eye, const float* right, const float* up, const float* back, int* rect) {
+  const int type = (int)pr[0];
+  const bool two = type == PRIM_CAPSULE || type == PRIM_CYLINDER;
+  const float rad = two ? bound_radius(pr[13]) : pr[17];
+  const float aspect = (float)p.W / (float)p.H, tx = p.cam.tan_half * aspect, ty = p.cam.tan_half;
+  float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
+  bool everything = false, behind = true;  // behind: the whole bound lies behind the camera plane
+  float zmin = INFINITY;
+  for (int e = 0; e < (two ? 2 : 1); e++) {
+    const F3 v = sub(f3(pr[1 + 3 * e], pr[2 + 3 * e], pr[3 + 3 * e]), eye);
+    const float x = v.x * right[0] + v.y * right[1] + v.z * right[2], y = v.x * up[0] + v.y * up[1] + v.z * up[2];
+    const float z = -(v.x * back[0] + v.y * back[1] + v.z * back[2]);
+    zmin = fminf(zmin, z);
+    if (z + rad * 1.05f + 1.0e-3f > 0.0f) behind = false;
+    if (!(z > rad * 1.05f + 1.0e-3f)) { everything = true; continue; }  // the bound reaches the camera plane
+    const float den = z * z - rad * rad;
+    const float sx = rad * sqrtf(x * x + den), sy = rad * sqrtf(y * y + den);
+    xlo = fminf(xlo, (x * z - sx) / den); xhi = fmaxf(xhi, (x * z + sx) / den);
+    ylo = fminf(ylo, (y * z - sy) / den); yhi = fmaxf(yhi, (y * z + sy) / den);
+  }
+  if (!behind && zmin < 4.0f * rad) {  // near the camera plane: the spheres' tangent extents are loose or void, clip the box
+    F3 bc, bu, bv, bw, bh;
+    prim_box(pr, eye, bc, bu, bv, bw, bh);
+    const F3 rel = sub(bc, eye), R = f3(right[0], right[1], right[2]), U = f3(up[0], up[1], up[2]), Bk = f3(back[0], back[1], back[2]);
+    const float lu = dotf(rel, bu), lv = dotf(rel, bv), lw = dotf(rel, bw);
+    // the eye within 5 mm of the box: rays may hit it nearer than the clip depth, keep what the spheres gave
+    const bool near = fabsf(lu) < bh.x + 5.0e-3f && fabsf(lv) < bh.y + 5.0e-3f && fabsf(lw) < bh.z + 5.0e-3f;
+    if (!near) {
+      const float Cc[3] = {dotf(rel, R), dotf(rel, U), -dotf(rel, Bk)};
+      const float Ac[3] = {bh.x * dotf(bu, R), bh.x * dotf(bu, U), -bh.x * dotf(bu, Bk)};
+      const float Bc[3] = {bh.y * dotf(bv, R), bh.y * dotf(bv, U), -bh.y * dotf(bv, Bk)};
+      const float Dc[3] = {bh.z * dotf(bw, R), bh.z * dotf(bw, U), -bh.z * dotf(bw, Bk)};
+      float bxlo, bxhi, bylo, byhi;
+      if (!clipped_box_rect(Cc, Ac, Bc, Dc, 1.0e-3f, bxlo, bxhi, bylo, byhi)) behind = true;
+      else if (everything) { xlo = bxlo; xhi = bxhi; ylo = bylo; yhi = byhi; everything = false; }
+      else { xlo = fmaxf(xlo, bxlo); xhi = fminf(xhi, bxhi); ylo = fmaxf(ylo, bylo); yhi = fminf(yhi, byhi); }
+    }
+  }
+  int r0 = 0, r1 = p.H - 1, c0 = 0, c1 = p.W - 1;
+  if (!everything) {
+    // px = (2 (col + 0.5) / W - 1) tx,  py = (1 - 2 (row + 0.5) / H) ty   (pixel_ray_axes)
+    const float cl = (xlo / tx + 1.0f) * 0.5f * (float)p.W - 0.5f, ch = (xhi / tx + 1.0f) * 0.5f * (float)p.W - 0.5f;
+    const float rl = (1.0f - yhi / ty) * 0.5f * (float)p.H - 0.5f, rh = (1.0f - ylo / ty) * 0.5f * (float)p.H - 0.5f;
+    // wholly outside the image (with the one-pixel pad), or an empty intersection of the two bounds
+    if (!(ch >= -1.5f) || !(cl <= (float)p.W + 0.5f) || !(rh >= -1.5f) || !(rl <= (float)p.H + 0.5f) || cl > ch || rl > rh) behind = true;
+    // clamp in float first (the extents can be huge for bounds near the camera plane), then pad by a pixel
+    c0 = (int)floorf(fminf(fmaxf(cl, -1.0f), (float)p.W)) - 1; c1 = (int)ceilf(fminf(fmaxf(ch, -1.0f), (float)p.W)) + 1;
+    r0 = (int)floorf(fminf(fmaxf(rl, -1.0f), (float)p.H)) - 1; r1 = (int)ceilf(fminf(fmaxf(rh, -1.0f), (float)p.H)) + 1;
+    c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, p.W - 1); r1 = min(r1, p.H - 1);
+  }
+  if (behind || eye_inside(pr, eye)) r1 = r0 - 1;  // nothing of it can be seen: empty rectangle
+  rect[0] = r0; rect[1] = r1; rect[2] = c0; rect[3] = c1;
+}
+
 __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p, const float* prims, Background bg) {
   const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npix = p.H * p.W;
@@ -690,42 +806,8 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
     for (int k = tid; k < npix; k += 256) depth[k] = ~0ull;
   }
   const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-  const float* right = p.cam.right;
-  const float* up = p.cam.up;
-  const float* back = p.cam.back;
   __syncthreads();
-  if (tid < nprim) {  // pixel rectangle of the primitive's bound: tangent extents of its bounding sphere(s), padded
-    const float* pr = lds_prims + tid * PRIM_FLOATS;
-    const int type = (int)pr[0];
-    const bool two = type == PRIM_CAPSULE || type == PRIM_CYLINDER;
-    const float rad = two ? bound_radius(pr[13]) : pr[17];
-    const float aspect = (float)p.W / (float)p.H, tx = p.cam.tan_half * aspect, ty = p.cam.tan_half;
-    float xlo = INFINITY, xhi = -INFINITY, ylo = INFINITY, yhi = -INFINITY;
-    bool everything = false, behind = true;  // behind: the whole bound lies behind the camera plane
-    for (int e = 0; e < (two ? 2 : 1); e++) {
-      const F3 v = sub(f3(pr[1 + 3 * e], pr[2 + 3 * e], pr[3 + 3 * e]), eye);
-      const float x = v.x * right[0] + v.y * right[1] + v.z * right[2], y = v.x * up[0] + v.y * up[1] + v.z * up[2];
-      const float z = -(v.x * back[0] + v.y * back[1] + v.z * back[2]);
-      if (z + rad * 1.05f + 1.0e-3f > 0.0f) behind = false;
-      if (!(z > rad * 1.05f + 1.0e-3f)) { everything = true; continue; }  // the bound reaches the camera plane
-      const float den = z * z - rad * rad;
-      const float sx = rad * sqrtf(x * x + den), sy = rad * sqrtf(y * y + den);
-      xlo = fminf(xlo, (x * z - sx) / den); xhi = fmaxf(xhi, (x * z + sx) / den);
-      ylo = fminf(ylo, (y * z - sy) / den); yhi = fmaxf(yhi, (y * z + sy) / den);
-    }
-    int r0 = 0, r1 = p.H - 1, c0 = 0, c1 = p.W - 1;
-    if (!everything) {
-      // px = (2 (col + 0.5) / W - 1) tx,  py = (1 - 2 (row + 0.5) / H) ty   (pixel_ray_axes)
-      const float cl = (xlo / tx + 1.0f) * 0.5f * (float)p.W - 0.5f, ch = (xhi / tx + 1.0f) * 0.5f * (float)p.W - 0.5f;
-      const float rl = (1.0f - yhi / ty) * 0.5f * (float)p.H - 0.5f, rh = (1.0f - ylo / ty) * 0.5f * (float)p.H - 0.5f;
-      // clamp in float first (the extents can be huge for bounds near the camera plane), then pad by a pixel
-      c0 = (int)floorf(fminf(fmaxf(cl, -1.0f), (float)p.W)) - 1; c1 = (int)ceilf(fminf(fmaxf(ch, -1.0f), (float)p.W)) + 1;
-      r0 = (int)floorf(fminf(fmaxf(rl, -1.0f), (float)p.H)) - 1; r1 = (int)ceilf(fminf(fmaxf(rh, -1.0f), (float)p.H)) + 1;
-      c0 = max(c0, 0); r0 = max(r0, 0); c1 = min(c1, p.W - 1); r1 = min(r1, p.H - 1);
-    }
-    if (behind || eye_inside(pr, eye)) r1 = r0 - 1;  // nothing of it can be seen: empty rectangle
-    bbox[4 * tid] = r0; bbox[4 * tid + 1] = r1; bbox[4 * tid + 2] = c0; bbox[4 * tid + 3] = c1;
-  }
+  if (tid < nprim) prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, p.cam.right, p.cam.up, p.cam.back, bbox + 4 * tid);
   __syncthreads();
   int turn = 0;  // 8x8 blocks of all primitives are dealt round-robin to the 4 wavefronts
   for (int k = 0; k < nprim; k++) {  // wave-uniform
@@ -783,6 +865,69 @@ __global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p,
   for (int q = tid; q < (npix >> 2); q += 256) {
     const uint32_t* cs = reinterpret_cast<const uint32_t*>(depth) + 8 * q;
     const uint32_t a = cs[0], b = cs[2], c = cs[4], d = cs[6];
+    o32[3 * q + 0] = a | (b << 24);
+    o32[3 * q + 1] = (b >> 8) | (c << 16);
+    o32[3 * q + 2] = (c >> 16) | (d << 8);
+  }
+}
+
+// ---- per-env camera (the Button-Push wrist camera), images up to 64x64 with H and W multiples of 8 ------------------------
+// One workgroup per env image. The camera sits on the flange: the gripper and the last wrist links are a few cm from the
+// lens, their bounding spheres contain the eye or reach the camera plane, and the tile walk's cone test keeps them as
+// candidates for every tile. Here each primitive gets its pixel rectangle once per image (prim_rect), a tile's candidate
+// list is the ballot of "rectangle overlaps the tile", and the walk itself is the tile kernel's: ascending primitive
+// index, strict-< update, normals kept in registers (no depth keys, no second test). Same arithmetic per ray, per test
+// and per shaded pixel: the image is identical to the tile walk's.
+__global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams p, const float* prims) {
+  __shared__ float lds_prims[MAX_NPRIM * PRIM_FLOATS];
+  __shared__ int bbox[MAX_NPRIM * 4];
+  __shared__ uint32_t image[RASTER_IMAGE_PIXELS];  // packed colours, written out coalesced at the end
+  const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int npix = p.H * p.W;
+  {
+    const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
+    for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
+  }
+  const float* cm = p.env_cams + (size_t)env * 12;
+  const F3 eye = f3(cm[0], cm[1], cm[2]);
+  const float* right = cm + 3;
+  const float* up = cm + 6;
+  const float* back = cm + 9;
+  __syncthreads();
+  if (tid < nprim) prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, right, up, back, bbox + 4 * tid);
+  __syncthreads();
+  const int tiles_x = p.W >> 3, ntiles = npix >> 6;
+  for (int tile = wave; tile < ntiles; tile += 4) {
+    const int row0 = (tile / tiles_x) * 8, col0 = (tile % tiles_x) * 8;
+    const int row = row0 + (lane >> 3), col = col0 + (lane & 7);
+    bool c = false;
+    if (lane < nprim) c = bbox[4 * lane] <= row0 + 7 && bbox[4 * lane + 1] >= row0 && bbox[4 * lane + 2] <= col0 + 7 && bbox[4 * lane + 3] >= col0;
+    unsigned cand = (unsigned)__ballot(c);
+    const F3 d = pixel_ray_axes(p, row, col, right, up, back);
+    Surf s;
+    s.t = INFINITY;
+    s.n = f3(0, 0, 1);
+    s.rgb = f3(0, 0, 0);
+    hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+    while (cand) {  // ascending primitive index = the oracle's test order
+      const int k = __ffs(cand) - 1;
+      cand &= cand - 1;
+      const float* pr = lds_prims + k * PRIM_FLOATS;
+      const int type = (int)pr[0];
+      const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+      const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
+      const float along = dotf(oc, d), off2 = dotf(oc, oc) - along * along, br = pr[17];  // per-ray bounding-sphere reject
+      if (!(off2 <= br * br && along + br > 0.0f)) continue;
+      exact_test(pr, eye, d, s);
+    }
+    F3 cc = f3(0, 0, 0);
+    if (s.t < INFINITY) cc = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
+    image[row * p.W + col] = pack_rgb(cc);
+  }
+  __syncthreads();
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + (size_t)env * npix * 3);
+  for (int q = tid; q < (npix >> 2); q += 256) {
+    const uint32_t a = image[4 * q], b = image[4 * q + 1], c = image[4 * q + 2], d = image[4 * q + 3];
     o32[3 * q + 0] = a | (b << 24);
     o32[3 * q + 1] = (b >> 8) | (c << 16);
     o32[3 * q + 2] = (c >> 16) | (d << 8);

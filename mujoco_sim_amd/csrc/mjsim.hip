@@ -424,11 +424,11 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
   // robot scenes: the primitive-major kernel (one workgroup per env image, depth keys in LDS, env-independent rays and
   // floor colours from a table computed once per camera and size) for the fixed scene cameras up to 64x64 pixels.
-  // Slower than the tile walk for the wrist camera (the gripper's bounds reach the camera plane: whole-image passes per
-  // primitive; profiles/r02_g_render_ladder.txt), not applicable to larger images (32 KB of LDS depth keys per image).
-  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && height % 8 == 0 && width % 8 == 0 && !wrist &&
+  // The per-env wrist camera takes the rectangle walk (same per-primitive rectangles, the tile walk's registers-only
+  // nearest hit). Larger images keep the 8x8-tile walk (32 KB of LDS depth keys / 16 KB of staged colours per image).
+  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && height % 8 == 0 && width % 8 == 0 &&
                       h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
-  if (raster && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
+  if (raster && !wrist && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
     if (h->bg_ray) (void)hipFree(h->bg_ray);
     if (h->bg_rgb) (void)hipFree(h->bg_rgb);
     h->bg_ray = nullptr; h->bg_rgb = nullptr; h->bg_H = h->bg_W = 0;
@@ -441,7 +441,8 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   }
   const size_t raster_lds = rend::raster_lds_bytes_host(height, width);
   auto robot_scene = [&]() {
-    if (raster) rend::robot_scene_raster_kernel<<<(unsigned)p.N, 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
+    if (raster && p.env_cams) rend::robot_scene_rect_walk_kernel<<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims);
+    else if (raster) rend::robot_scene_raster_kernel<<<(unsigned)p.N, 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
     else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   };
   const bool fresh = h->prims_valid && h->prims_stream == stream;  // same state, same stream: the list is still good

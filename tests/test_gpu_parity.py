@@ -1224,15 +1224,24 @@ def test_scene_camera_kernels_agree_byte_for_byte(task):
     run; its image must equal the 8x8-tile walk's (kernel_variant 1) byte for byte."""
     import mujoco_sim_amd as m
 
-    N = 48
+    N = 256
     a = m.HipVectorEnv(task, N, seed=77)
     b = m.HipVectorEnv(task, N, seed=77, kernel_variant=1)
     a.reset()
     b.reset()
-    for hh, ww in ((32, 32), (64, 64), (48, 64), (40, 24)):  # square and non-square, all within the primitive-major kernel's 4096-pixel limit
-        ia, ib = a.render(hh, ww).cpu().numpy(), b.render(hh, ww).cpu().numpy()
-        assert np.array_equal(ia, ib), (task, hh, ww, int((ia != ib).sum()))
-        assert ia.std() > 10
+    rng = np.random.RandomState(5)
+    cams = (0, 1) if task == "robot_push_button" else (0,)  # 1 = the wrist camera (per-env pose, the gripper next to the lens)
+    for rnd in range(4):  # arms in varied poses: the culling rules see primitives near, behind and across the camera plane
+        for hh, ww in ((32, 32), (64, 64), (48, 64), (40, 24)):  # square and non-square, within the primitive-major kernel's 4096-pixel limit
+            for cam in cams:
+                ia, ib = a.render(hh, ww, camera=cam).cpu().numpy(), b.render(hh, ww, camera=cam).cpu().numpy()
+                assert np.array_equal(ia, ib), (task, rnd, cam, hh, ww, int((ia != ib).sum()))
+                assert ia.std() > 10
+        for _ in range(6):
+            lo, hi = np.asarray(a.action_low, dtype=np.float64), np.asarray(a.action_high, dtype=np.float64)
+            act = torch.as_tensor(lo + rng.uniform(0, 1, (N, a.action_dim)) * (hi - lo), device="cuda")
+            a.step(act)
+            b.step(act)
     a.close()
     b.close()
 
