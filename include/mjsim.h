@@ -44,7 +44,7 @@ enum { MJS_STEP_FIRST = 0, MJS_STEP_MID = 1, MJS_STEP_LAST = 2 };
 enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_DISABLED = 2 };
 /* kernel variants (results identical up to rounding; used for A/B profiles). Variant 1 = the first-generation kernels:
  * the single-wavefront step kernels of Robot-Reach / Button-Push (default: two role-specialised wavefronts) and the
- * 8x8-tile camera kernel for every image (default: the primitive-major kernel for scene cameras up to 64x64) */
+ * 8x8-tile camera kernel for every image (default: the rectangle walk for images up to 64x64) */
 enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1, MJS_VARIANT_TWO_ROLES = 2 /* Robot-Reach: round 1's two-wavefront kernel */ };
 /* mjs_outputs.fault bits */
 enum {

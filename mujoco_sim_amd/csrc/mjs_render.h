@@ -630,22 +630,24 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
 }
 
 
-// ---- primitive-major variant: one workgroup per env image (fixed scene cameras, images up to 64x64, H and W multiples of 8)
-// The tile walk above makes every 8x8 tile test every primitive whose bound touches the tile's ray cone; at 64x64 a
-// tile is ~30 cm wide at the arm's distance, so most exact tests are for rays that miss. Here the loop is turned
-// inside out: each wavefront takes primitives, projects the primitive's bound to a pixel rectangle (exact tangent
-// extents of the end spheres, padded) and runs the exact test only on 8x8 blocks of that rectangle; the nearest hit
-// per pixel is an LDS ds_min_u64 on the key (float bits of t, primitive index) = "smallest t, first primitive
-// wins", which is what the sequential strict-< update of the tile walk / the oracle computes. A second pass shades the
-// pixels a primitive won (the winner's exact test once more for its normal, Blinn-Phong).
+// ---- rectangle walk: one workgroup per env image (images up to 64x64 pixels, H and W multiples of 8) ---------------------
+// The 8x8-tile walk above makes every tile test every primitive whose bounding sphere touches the tile's ray cone. For
+// primitives a few cm from the lens (the wrist camera sits on the flange next to the gripper and the last wrist links) the
+// spheres contain the eye or reach the camera plane and the cone test keeps them for every tile; at 64x64 a tile is also
+// ~30 cm wide at the arm's distance from the scene camera, so most exact tests are for rays that miss. Here each primitive
+// gets its pixel rectangle once per image (prim_rect: tangent extents of the bounding spheres, or the primitive's box
+// clipped at the near plane), a tile's candidate list is the ballot of "rectangle overlaps the tile", and the walk itself
+// is the tile kernel's: ascending primitive index, strict-< update, normals kept in registers. Tiles are taken from an
+// LDS counter by whichever wavefront is free (the arm covers a few columns of tiles: a static split leaves three
+// wavefronts waiting for the fourth), colours are packed into LDS and written out as whole dwords.
 //
-// Everything that does not depend on the env is computed ONCE per (camera, H, W) by scene_background_kernel and kept in
-// HBM/L2 (20 B per pixel): the normalised pixel ray, the floor's ray parameter and the shaded floor/background colour.
-// A fixed camera sees the same floor in every env, so the second pass shades only primitive pixels (a few % of the
-// image) and copies the rest. Same arithmetic per ray, per test and per shaded pixel as the tile kernel, evaluated by
-// the same functions: the image is identical (tests: test_scene_camera_kernels_agree_byte_for_byte).
-constexpr int RASTER_IMAGE_PIXELS = 64 * 64;  // 32 KB of depth keys
-inline size_t raster_lds_bytes_host(int H, int W) { return (size_t)H * W * 8 + MAX_NPRIM * PRIM_FLOATS * 4 + MAX_NPRIM * 4 * 4; }
+// Fixed scene cameras: everything that does not depend on the env is computed ONCE per (camera, H, W) by
+// scene_background_kernel and kept in HBM/L2 (20 B per pixel): the normalised pixel ray, the floor's ray parameter and
+// the shaded floor / background colour. A fixed camera sees the same floor in every env, so only tiles a primitive's
+// rectangle touches are visited and only pixels a primitive wins are shaded; the rest is a copy of the table.
+// Same arithmetic per ray, per test and per shaded pixel as the tile kernel, evaluated by the same functions: the image
+// is identical (tests: test_scene_camera_kernels_agree_byte_for_byte, both cameras, varied poses).
+constexpr int RECT_WALK_MAX_PIXELS = 64 * 64;  // 16 KB of packed colours in LDS
 struct Background {
   const float4* ray;    // [H*W] normalised ray direction (xyz) and the floor's ray parameter (w; +inf = no floor there)
   const uint32_t* rgb;  // [H*W] shaded floor / background colour, r | g << 8 | b << 16
@@ -726,7 +728,6 @@ MJS_DEV void prim_box(const float* pr, F3 eye, F3& c, F3& u, F3& v, F3& w, F3& h
   h = f3(h.x * 1.02f + 1.0e-3f, h.y * 1.02f + 1.0e-3f, h.z * 1.02f + 1.0e-3f);
 }
 
-extern __shared__ unsigned long long raster_lds[];
 MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   const int type = (int)pr[0];
   const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
@@ -794,121 +795,60 @@ MJS_DEV void prim_rect(const RenderParams& p, const float* pr, F3 eye, const flo
   rect[0] = r0; rect[1] = r1; rect[2] = c0; rect[3] = c1;
 }
 
-__global__ __launch_bounds__(256) void robot_scene_raster_kernel(RenderParams p, const float* prims, Background bg) {
-  const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int npix = p.H * p.W;
-  unsigned long long* depth = raster_lds;
-  float* lds_prims = reinterpret_cast<float*>(raster_lds + npix);
-  int* bbox = reinterpret_cast<int*>(lds_prims + MAX_NPRIM * PRIM_FLOATS);  // r0, r1, c0, c1 per primitive
-  {
-    const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
-    for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
-    for (int k = tid; k < npix; k += 256) depth[k] = ~0ull;
-  }
-  const F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
-  __syncthreads();
-  if (tid < nprim) prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, p.cam.right, p.cam.up, p.cam.back, bbox + 4 * tid);
-  __syncthreads();
-  int turn = 0;  // 8x8 blocks of all primitives are dealt round-robin to the 4 wavefronts
-  for (int k = 0; k < nprim; k++) {  // wave-uniform
-    const float* pr = lds_prims + k * PRIM_FLOATS;
-    const int type = (int)pr[0];
-    const int r0 = bbox[4 * k], r1 = bbox[4 * k + 1], c0 = bbox[4 * k + 2], c1 = bbox[4 * k + 3];
-    const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
-    const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
-    const float ococ = dotf(oc, oc), br = pr[17];
-    for (int rb = r0; rb <= r1; rb += 8) {
-      for (int cb = c0; cb <= c1; cb += 8) {
-        if (((turn++) & 3) != wave) continue;
-        const int row = rb + (lane >> 3), col = cb + (lane & 7);
-        const bool in = row <= r1 && col <= c1;
-        const float4 r4 = bg.ray[in ? row * p.W + col : 0];
-        const F3 d = f3(r4.x, r4.y, r4.z);
-        const float along = dotf(oc, d), off2 = ococ - along * along;  // per-ray bounding-sphere reject (as in the tile kernel)
-        const bool pass = in && off2 <= br * br && along + br > 0.0f;
-        if (!__any(pass)) continue;
-        Surf s;
-        s.t = INFINITY;
-        s.n = f3(0, 0, 1);
-        s.rgb = f3(0, 0, 0);
-        if (pass) exact_test(pr, eye, d, s);
-        if (pass && s.t < INFINITY)
-          atomicMin(&depth[row * p.W + col], ((unsigned long long)__float_as_uint(s.t) << 32) | (unsigned)k);
-      }
-    }
-  }
-  __syncthreads();
-  // second pass, one 8x8 tile per wavefront and turn (neighbouring pixels share the winner's type and the lights that reach
-  // them); the packed colour goes back into the pixel's own depth slot
-  const int tiles_x = p.W >> 3, ntiles = npix >> 6;
-  for (int tile = wave; tile < ntiles; tile += 4) {
-    const int row = (tile / tiles_x) * 8 + (lane >> 3), col = (tile % tiles_x) * 8 + (lane & 7), px = row * p.W + col;
-    const unsigned long long key = depth[px];
-    const float4 r4 = bg.ray[px];
-    uint32_t c = bg.rgb[px];
-    if (key != ~0ull && __uint_as_float((unsigned)(key >> 32)) < r4.w) {
-      const F3 d = f3(r4.x, r4.y, r4.z);
-      Surf w;
-      w.t = INFINITY;
-      w.n = f3(0, 0, 1);
-      w.rgb = f3(0, 0, 0);
-      exact_test(lds_prims + (int)(key & 0xffffffffu) * PRIM_FLOATS, eye, d, w);  // the winner once more, for its normal
-      F3 cc = f3(0, 0, 0);
-      if (w.t < INFINITY) cc = shade<6>(add(eye, mul(w.t, d)), w.n, eye, w.rgb, MJS_RR_LIGHT_POS);
-      c = pack_rgb(cc);
-    }
-    reinterpret_cast<uint32_t*>(depth)[2 * px] = c;
-  }
-  __syncthreads();
-  // write-out: 4 pixels = 12 bytes = 3 dwords per lane and turn, consecutive lanes write consecutive addresses
-  uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + (size_t)env * npix * 3);
-  for (int q = tid; q < (npix >> 2); q += 256) {
-    const uint32_t* cs = reinterpret_cast<const uint32_t*>(depth) + 8 * q;
-    const uint32_t a = cs[0], b = cs[2], c = cs[4], d = cs[6];
-    o32[3 * q + 0] = a | (b << 24);
-    o32[3 * q + 1] = (b >> 8) | (c << 16);
-    o32[3 * q + 2] = (c >> 16) | (d << 8);
-  }
-}
-
-// ---- per-env camera (the Button-Push wrist camera), images up to 64x64 with H and W multiples of 8 ------------------------
-// One workgroup per env image. The camera sits on the flange: the gripper and the last wrist links are a few cm from the
-// lens, their bounding spheres contain the eye or reach the camera plane, and the tile walk's cone test keeps them as
-// candidates for every tile. Here each primitive gets its pixel rectangle once per image (prim_rect), a tile's candidate
-// list is the ballot of "rectangle overlaps the tile", and the walk itself is the tile kernel's: ascending primitive
-// index, strict-< update, normals kept in registers (no depth keys, no second test). Same arithmetic per ray, per test
-// and per shaded pixel: the image is identical to the tile walk's.
-__global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams p, const float* prims) {
+template <bool FIXED>  // FIXED: the task's scene camera with its ray / floor table (Background); otherwise p.env_cams
+__global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams p, const float* prims, Background bg) {
   __shared__ float lds_prims[MAX_NPRIM * PRIM_FLOATS];
   __shared__ int bbox[MAX_NPRIM * 4];
-  __shared__ uint32_t image[RASTER_IMAGE_PIXELS];  // packed colours, written out coalesced at the end
+  __shared__ uint32_t image[RECT_WALK_MAX_PIXELS];  // packed colours, written out coalesced at the end
+  __shared__ int next_tile;                        // tiles are taken in turn by whichever wavefront is free
   const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int npix = p.H * p.W;
   {
     const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
     for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
+    if (tid == 0) next_tile = 0;
+    if (FIXED)  // the env-independent image first; only tiles a primitive touches are revisited
+      for (int k = tid; k < npix; k += 256) image[k] = bg.rgb[k];
   }
-  const float* cm = p.env_cams + (size_t)env * 12;
-  const F3 eye = f3(cm[0], cm[1], cm[2]);
-  const float* right = cm + 3;
-  const float* up = cm + 6;
-  const float* back = cm + 9;
+  F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
+  const float* right = p.cam.right;
+  const float* up = p.cam.up;
+  const float* back = p.cam.back;
+  if (!FIXED) {
+    const float* cm = p.env_cams + (size_t)env * 12;
+    eye = f3(cm[0], cm[1], cm[2]);
+    right = cm + 3; up = cm + 6; back = cm + 9;
+  }
   __syncthreads();
   if (tid < nprim) prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, right, up, back, bbox + 4 * tid);
   __syncthreads();
   const int tiles_x = p.W >> 3, ntiles = npix >> 6;
-  for (int tile = wave; tile < ntiles; tile += 4) {
+  for (;;) {
+    int tile = 0;
+    if (lane == 0) tile = atomicAdd(&next_tile, 1);
+    tile = __builtin_amdgcn_readfirstlane(tile);
+    if (tile >= ntiles) break;
     const int row0 = (tile / tiles_x) * 8, col0 = (tile % tiles_x) * 8;
     const int row = row0 + (lane >> 3), col = col0 + (lane & 7);
     bool c = false;
     if (lane < nprim) c = bbox[4 * lane] <= row0 + 7 && bbox[4 * lane + 1] >= row0 && bbox[4 * lane + 2] <= col0 + 7 && bbox[4 * lane + 3] >= col0;
     unsigned cand = (unsigned)__ballot(c);
-    const F3 d = pixel_ray_axes(p, row, col, right, up, back);
+    F3 d;
     Surf s;
     s.t = INFINITY;
     s.n = f3(0, 0, 1);
     s.rgb = f3(0, 0, 0);
-    hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+    float t_floor = INFINITY;
+    if (FIXED) {  // the env-independent part comes from the table: a tile no primitive touches is a copy
+      if (!cand) continue;
+      const float4 r4 = bg.ray[row * p.W + col];
+      d = f3(r4.x, r4.y, r4.z);
+      t_floor = r4.w;
+      s.t = t_floor;  // the floor's hit bounds the walk exactly as in the sequential test order (floor first)
+    } else {
+      d = pixel_ray_axes(p, row, col, right, up, back);
+      hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
+    }
     while (cand) {  // ascending primitive index = the oracle's test order
       const int k = __ffs(cand) - 1;
       cand &= cand - 1;
@@ -920,9 +860,13 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
       if (!(off2 <= br * br && along + br > 0.0f)) continue;
       exact_test(pr, eye, d, s);
     }
-    F3 cc = f3(0, 0, 0);
-    if (s.t < INFINITY) cc = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
-    image[row * p.W + col] = pack_rgb(cc);
+    if (FIXED) {
+      if (s.t < t_floor) image[row * p.W + col] = pack_rgb(shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS));  // a primitive won the pixel
+    } else {
+      F3 cc = f3(0, 0, 0);
+      if (s.t < INFINITY) cc = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
+      image[row * p.W + col] = pack_rgb(cc);
+    }
   }
   __syncthreads();
   uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + (size_t)env * npix * 3);

@@ -422,13 +422,12 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
   const int tiles = ((height + 7) / 8) * ((width + 7) / 8);  // robot scenes: one wavefront per 8x8 tile
   dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
-  // robot scenes: the primitive-major kernel (one workgroup per env image, depth keys in LDS, env-independent rays and
-  // floor colours from a table computed once per camera and size) for the fixed scene cameras up to 64x64 pixels.
-  // The per-env wrist camera takes the rectangle walk (same per-primitive rectangles, the tile walk's registers-only
-  // nearest hit). Larger images keep the 8x8-tile walk (32 KB of LDS depth keys / 16 KB of staged colours per image).
-  const bool raster = height * width <= rend::RASTER_IMAGE_PIXELS && height % 8 == 0 && width % 8 == 0 &&
+  // robot scenes up to 64x64 pixels: the rectangle walk (one workgroup per env image, per-primitive pixel rectangles,
+  // colours staged in 16 KB of LDS); the fixed scene cameras add the table of env-independent rays and floor colours,
+  // computed once per size. Larger images keep the 8x8-tile walk. Ladder: profiles/r02_g_render_ladder.txt.
+  const bool rect_walk = height * width <= rend::RECT_WALK_MAX_PIXELS && height % 8 == 0 && width % 8 == 0 &&
                       h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
-  if (raster && !wrist && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
+  if (rect_walk && !wrist && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
     if (h->bg_ray) (void)hipFree(h->bg_ray);
     if (h->bg_rgb) (void)hipFree(h->bg_rgb);
     h->bg_ray = nullptr; h->bg_rgb = nullptr; h->bg_H = h->bg_W = 0;
@@ -439,10 +438,9 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
     HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream));  // once per size: later renders may come on another stream
     h->bg_H = height; h->bg_W = width;
   }
-  const size_t raster_lds = rend::raster_lds_bytes_host(height, width);
   auto robot_scene = [&]() {
-    if (raster && p.env_cams) rend::robot_scene_rect_walk_kernel<<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims);
-    else if (raster) rend::robot_scene_raster_kernel<<<(unsigned)p.N, 256, raster_lds, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
+    if (rect_walk && p.env_cams) rend::robot_scene_rect_walk_kernel<false><<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{nullptr, nullptr});
+    else if (rect_walk) rend::robot_scene_rect_walk_kernel<true><<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
     else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   };
   const bool fresh = h->prims_valid && h->prims_stream == stream;  // same state, same stream: the list is still good
