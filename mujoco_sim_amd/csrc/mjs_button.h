@@ -437,21 +437,30 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
 }
 
-// can this lane get constraint rows during the next control step? A joint near its range (rr::joint_near_range: 0.6 rad
-// + the distance covered at the current joint velocity), or the gripper stand-in within reach of the floor / the switch:
-// 0.12 m (what the force-clamped servos add within 0.1 s from rest) + the distance the stand-in covers at its CURRENT
-// Cartesian speed |J(q) v| in one control step (mjs_set_state can inject any velocity). The fast path also re-checks its
-// final state (a posteriori, in the kernel): a joint outside its range or a touching stand-in after a row-free step is
-// reported as MJS_FAULT_FASTPATH_VIOLATED.
-MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch, V3 sw) {
+// can this lane get constraint rows within the next `h` seconds? A joint within reach of its range, or the gripper
+// stand-in within reach of the floor / the switch, where "reach" is what the force-clamped servos add from rest
+// (12 h^2 m: 0.12 m per 0.1 s control step; 60 h^2 rad for a joint) plus the distance covered at the CURRENT speed (the
+// stand-in's Cartesian |J(q) v|; mjs_set_state can inject any velocity). The kernel asks for the whole control step first;
+// a workgroup that fails that asks again before every segment of 5 substeps (a fast swing far from everything passes
+// these) and only hands over to the robust path from the segment that fails. The fast path also re-checks its final state
+// (a posteriori, in the kernel): a joint outside its range or a touching stand-in after a row-free step is reported as
+// MJS_FAULT_FASTPATH_VIOLATED.
+constexpr int SEGMENT_SUBSTEPS = 5;
+static_assert(MJS_RR_NSUB % SEGMENT_SUBSTEPS == 0, "segments tile the control step");
+MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch, V3 sw, double h) {
   const V3 c = proxy_centre(ch);
   V3 vel = v3(0, 0, 0);
+  bool near = false;
 #pragma unroll
-  for (int j = 0; j < NJ; j++) vel += v[j] * cross(rr::joint_axis(ch, j), c - ch.p[j + 1]);
-  const double travel = 0.12 + MJS_RR_CONTROL_DT * sqrt(dot(vel, vel));
+  for (int j = 0; j < NJ; j++) {
+    vel += v[j] * cross(rr::joint_axis(ch, j), c - ch.p[j + 1]);
+    const double margin = 60.0 * h * h + h * fabs(v[j]);
+    near = near || (q[j] - MJS_UR_JNT_RANGE[j][0] < margin) || (MJS_UR_JNT_RANGE[j][1] - q[j] < margin);
+  }
+  const double travel = 12.0 * h * h + h * sqrt(dot(vel, vel));
   const V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
   const double reach = 0.08 + travel;
-  return rr::joint_near_range(q, v) || c.z < 0.03 + travel || dot(d, d) < reach * reach;
+  return near || c.z < 0.03 + travel || dot(d, d) < reach * reach;
 }
 
 // Switch._update_activation (switch.py:51-60)
@@ -524,6 +533,7 @@ struct SoloIn {
   double q[NJ], v[NJ], q0[NJ], q1[NJ], cs[NJ], sn[NJ], time, t0, t1, sw[3];
   uint8_t flags;
   bool maybe_rows;
+  int first_substep;  // the substeps before it were taken on the row-free path
 };
 struct SoloOut {
   double q[NJ], v[NJ], cs[NJ], sn[NJ], time;
@@ -542,7 +552,7 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
   bool bad = false, rows_active = false;
   int ncon_proxy = 0;
 #pragma unroll 1
-  for (int s = 0; s < MJS_RR_NSUB; s++) {
+  for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
     double t = fmin(fmax(time, t0), t1);
     double ctrl[NJ], qacc[NJ], touch;
 #pragma unroll
@@ -627,9 +637,83 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
   rr::fk_cs(cs, sn, c);
-  const bool maybe_rows = rows_possible(st.q, st.v, c, sw);
-  const bool solo = (ROLES == 1) || __any(maybe_rows);  // both roles: same data, same decision
-  if (solo) {
+  // Which path? Both roles evaluate the same predicates on the same data, so the decisions agree without an exchange.
+  const bool guarded = __any(rows_possible(st.q, st.v, c, sw, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
+  int solo_from = (ROLES == 1) ? 0 : MJS_RR_NSUB;                                    // first substep of the robust path
+  if constexpr (ROLES == 2) {
+#pragma unroll 1
+    for (int seg = 0; seg < MJS_RR_NSUB / SEGMENT_SUBSTEPS; seg++) {
+      if (guarded) {  // wave-uniform: the steady state never enters
+        if (seg > 0) rr::fk_cs(cs, sn, c);
+        if (__any(rows_possible(st.q, st.v, c, sw, SEGMENT_SUBSTEPS * MJS_RR_PHYSICS_DT))) {
+          solo_from = seg * SEGMENT_SUBSTEPS;
+          break;
+        }
+      }
+#pragma unroll 1
+      for (int s = 0; s < SEGMENT_SUBSTEPS; s++) {
+        double qacc[NJ];
+        const double t = fmin(fmax(st.time, t0), t1);
+        double ctrl[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+        if (role == 1) {
+          double bias[NJ], fact[NJ];
+          rr::actuator_forces(st.q, st.v, ctrl, fact);
+          ur5e_bp_bias_gen(cs, sn, st.v, bias);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+          __syncthreads();  // qfrc_smooth published
+          __syncthreads();  // qacc published
+#pragma unroll
+          for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
+        } else {
+          double fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+          const int clamped = rr::actuator_forces(st.q, st.v, ctrl, fdummy);
+          ur5e_bp_M_gen(cs, sn, M);
+#pragma unroll
+          for (int r = 0; r < NJ; r++) {
+#pragma unroll
+            for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+          }
+          rr::factor_system(A, clamped, Dinv);
+          rr::invert_unit_upper(A, W);
+#pragma unroll
+          for (int r = 0; r < NJ; r++) {  // opaque register uses pin the whole factorisation before the barrier
+            asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+            for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+          }
+          __syncthreads();  // qfrc_smooth published
+#pragma unroll
+          for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
+          rr::apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
+          __syncthreads();  // qacc published
+        }
+        double acc2 = 0, dq2 = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+          acc2 = fma(qacc[j], qacc[j], acc2);
+          st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+          double dq = MJS_RR_PHYSICS_DT * st.v[j];
+          st.q[j] += dq;
+          dq2 = fma(dq, dq, dq2);
+          rr::rotate_small(cs[j], sn[j], dq);
+        }
+        bad = bad || !(acc2 <= 1e20);
+        if (!(dq2 <= 0.01)) {
+#pragma unroll
+          for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+        }
+        st.time += MJS_RR_PHYSICS_DT;
+      }
+    }
+    // no contact was possible on these substeps: the touch sensor read 0 after each of them (Switch.after_substep)
+    if (solo_from > 0) flags = (uint8_t)(flags & ~FLAG_SWITCH_PRESSED);
+  }
+  if (solo_from < MJS_RR_NSUB) {
     if (role != 0) return;
     SoloIn in;
 #pragma unroll
@@ -637,78 +721,17 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     in.time = st.time; in.t0 = t0; in.t1 = t1;
     in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
     in.flags = flags;
-    in.maybe_rows = true;  // the whole wavefront runs the robust path anyway: detect contacts for every lane of it (a lane's own a-priori
-                           // bound can be exceeded by a far joint target: saturated servos add up to ~0.25 m in one step from rest)
+    in.maybe_rows = true;  // the whole wavefront runs the robust path from here: detect contacts for every lane of it
+    in.first_substep = solo_from;
     SoloOut o = solo_control_step(in);
 #pragma unroll
     for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
     st.time = o.time;
     flags = o.flags;
-    bad = o.bad;
+    bad = bad || o.bad;
     rows_active = o.rows_active;
-  } else if constexpr (ROLES == 2) {
-#pragma unroll 1
-    for (int s = 0; s < MJS_RR_NSUB; s++) {
-      double qacc[NJ];
-      const double t = fmin(fmax(st.time, t0), t1);
-      double ctrl[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-      if (role == 1) {
-        double bias[NJ], fact[NJ];
-        rr::actuator_forces(st.q, st.v, ctrl, fact);
-        ur5e_bp_bias_gen(cs, sn, st.v, bias);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
-        __syncthreads();  // qfrc_smooth published
-        __syncthreads();  // qacc published
-#pragma unroll
-        for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
-      } else {
-        double fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
-        const int clamped = rr::actuator_forces(st.q, st.v, ctrl, fdummy);
-        ur5e_bp_M_gen(cs, sn, M);
-#pragma unroll
-        for (int r = 0; r < NJ; r++) {
-#pragma unroll
-          for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
-        }
-        rr::factor_system(A, clamped, Dinv);
-        rr::invert_unit_upper(A, W);
-#pragma unroll
-        for (int r = 0; r < NJ; r++) {  // opaque register uses pin the whole factorisation before the barrier
-          asm volatile("" : "+v"(Dinv[r]));
-#pragma unroll
-          for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
-        }
-        __syncthreads();  // qfrc_smooth published
-#pragma unroll
-        for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
-        rr::apply_inverse(W, Dinv, rhs, qacc);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
-        __syncthreads();  // qacc published
-      }
-      double acc2 = 0, dq2 = 0;
-#pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        acc2 = fma(qacc[j], qacc[j], acc2);
-        st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
-        double dq = MJS_RR_PHYSICS_DT * st.v[j];
-        st.q[j] += dq;
-        dq2 = fma(dq, dq, dq2);
-        rr::rotate_small(cs[j], sn[j], dq);
-      }
-      bad = bad || !(acc2 <= 1e20);
-      if (!(dq2 <= 0.01)) {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-      }
-      st.time += MJS_RR_PHYSICS_DT;
-    }
-    // no contact was possible: the touch sensor read 0 after every substep (Switch.after_substep)
-    flags = (uint8_t)(flags & ~FLAG_SWITCH_PRESSED);
   }
+  const bool solo = solo_from < MJS_RR_NSUB;
   if (role != 0) return;
   // after_step (robot_push_button.py:159-165): rand() is drawn only for an active, released switch
   if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = disturb(p.rng, i, flags);
