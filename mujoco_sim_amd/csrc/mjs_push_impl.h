@@ -818,8 +818,50 @@ extern __shared__ double pp_lds_raw[];
 MJS_DEV CoopLds& coop_lds() { return reinterpret_cast<CoopLds*>(pp_lds_raw)[threadIdx.x >> 6]; }
 static_assert(sizeof(CoopLds) % sizeof(double) == 0, "the hull tables follow the workspaces");
 constexpr int HULL_LDS_DOUBLES = MJS_HULL_NCAT * MJS_HULL_MAXV * 3;
-constexpr size_t LDS_BYTES = sizeof(CoopLds) * WAVES + sizeof(double) * HULL_LDS_DOUBLES;  // dynamic LDS of a launch
 MJS_DEV const double* hull_lds() { return pp_lds_raw + (sizeof(CoopLds) * WAVES) / sizeof(double); }
+// Per-env substep state: the env's world, servo set-point, joint sines / cosines and step flags live in LDS for the
+// length of the substep loop, one slot per env lane (+ one dummy slot shared by a wavefront's helper lanes). The
+// substep is a non-inlined function: state handed to it by reference sat in per-lane scratch and every access was a
+// FLAT load / store behind L2 (184 + 56 per substep, ~0.7 GB of HBM-side traffic per 4096-env launch).
+constexpr bool SPLIT_DETECT = NB <= 2;
+struct EnvLds {
+  World w;
+  double ctrl[NJ], cs[NJ], sn[NJ];
+  StepInfo info;
+  // results of the substep's detection phase (detect_phase), read by the solve / integrate phase; the 5-slot instance has
+  // no LDS left for them (17 slots x 2.6 KB per wavefront) and keeps the substep in one function
+  double Rb[SPLIT_DETECT ? NB : 1][9];      // block rotations (columns cx, cy, cz)
+  double fl[SPLIT_DETECT ? NB : 1][4][5];   // floor slots: on, dist, r[3]
+  double cv[SPLIT_DETECT ? NCVX : 1][8];    // convex pairs: hit, dist, pos[3], n[3]
+  int arm_in, blk_in[NB];
+  double Marm[SPLIT_DETECT ? 21 : 1], qacc[SPLIT_DETECT ? NV : 1];  // arm mass matrix (packed), qfrc_smooth -> qacc of the substep
+};
+MJS_DEV FloorSlots env_fs(const EnvLds& e, int b) {
+  FloorSlots f;
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const double* o = e.fl[b][k];
+    f.on[k] = o[0] != 0.0; f.dist[k] = o[1]; f.r[k] = v3(o[2], o[3], o[4]);
+  }
+  return f;
+}
+MJS_DEV ConvexHits env_cvx(const EnvLds& e) {
+  ConvexHits c;
+#pragma unroll
+  for (int k = 0; k < NCVX; k++) {
+    const double* o = e.cv[k];
+    c.hit[k] = o[0] != 0.0; c.dist[k] = o[1]; c.pos[k] = v3(o[2], o[3], o[4]); c.n[k] = v3(o[5], o[6], o[7]);
+  }
+  return c;
+}
+MJS_DEV M3 env_Rb(const EnvLds& e, int b) { return M3{v3(e.Rb[b][0], e.Rb[b][1], e.Rb[b][2]), v3(e.Rb[b][3], e.Rb[b][4], e.Rb[b][5]), v3(e.Rb[b][6], e.Rb[b][7], e.Rb[b][8])}; }
+constexpr size_t ENV_LDS_OFFSET = sizeof(CoopLds) * WAVES + sizeof(double) * HULL_LDS_DOUBLES;
+constexpr size_t LDS_BYTES = ENV_LDS_OFFSET + sizeof(EnvLds) * WAVES * (EPW + 1);  // dynamic LDS of a launch
+MJS_DEV EnvLds& env_lds() {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  return reinterpret_cast<EnvLds*>(pp_lds_raw + ENV_LDS_OFFSET / sizeof(double))[wave * (EPW + 1) + (lane < EPW ? lane : EPW)];
+}
+static_assert(sizeof(EnvLds) % sizeof(double) == 0, "slots are arrays of doubles");
 // exchange area of the lane-parallel decoupled solves (quad_block_floor); shares the wavefront's workspace with the
 // cooperative solver, which runs after it
 struct QuadIn {
@@ -1437,7 +1479,18 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
     MJS_WAVE_SYNC();
     unsigned long long tp = 0;
     PP_TIC(tp);
-    if (lane == owner) publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in, meaninertia);
+    if (lane == owner) {
+      if constexpr (SPLIT_DETECT) {  // the detection results are read from the env's LDS slot here, where they are needed
+        const EnvLds& env = env_lds();
+        FloorSlots fs_l[NB];
+        M3 Rb_l[NB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) { fs_l[b] = env_fs(env, b); Rb_l[b] = env_Rb(env, b); }
+        const ConvexHits cvx_l = env_cvx(env);
+        publish_problem(s, cs, sn, Marm, qacc, nb, fs_l, cvx_l, Rb_l, arm_in, blk_in, meaninertia);
+      } else
+        publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in, meaninertia);
+    }
     MJS_WAVE_SYNC();
     // mj_solPrimal's stopping rules are scaled by the WHOLE model (meaninertia, nv) of the owner env, also when a sub-system is solved
     const double scale = 1 / (sh.meaninertia * nv_all);
@@ -1484,18 +1537,15 @@ MJS_DEV void sincos_small(double x, double* s, double* c) {
 // dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
 // `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
 // neighbours (all 64 lanes of the workgroup must call this function together).
-__device__ __noinline__ void physics_step(World& s, const double* ctrl, double* cs, double* sn, int nb, StepInfo& info, bool live) {
-  const int nv = NJ + 6 * nb;
-  double Marm[21], qacc[NV];
-  int clamped = 0;
-  bool coupled = false, arm_in = false, blk_in[NB];
-#pragma unroll
-  for (int b = 0; b < NB; b++) blk_in[b] = false;
-  ConvexHits cvx;
-  FloorSlots fs[NB];
-  M3 Rb[NB];
-  unsigned long long tt = 0;
-  PP_TIC(tt);
+// Substep phase 1 (its own function in the 2-slot instance: the group-parallel MPR is the most register-hungry code of the substep and nothing of
+// it is needed afterwards): kinematics, collision detection by the env groups, the coupled sub-system. Results go to the
+// env's LDS slot.
+MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& cvx, bool& arm_in, bool* blk_in) {
+  EnvLds& env = env_lds();
+  World& s = env.w;
+  double* cs = env.cs;
+  double* sn = env.sn;
+  StepInfo& info = env.info;
   if (live) {
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
@@ -1622,7 +1672,75 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
       }
     }
   }
+  }  // live
+}
+
+__device__ __noinline__ void detect_phase(int nb, bool live) {
+  EnvLds& env = env_lds();
+  bool arm_in = false, blk_in[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) blk_in[b] = false;
+  ConvexHits cvx;
+  FloorSlots fs[NB];
+  M3 Rb[NB];
+  detect_body(nb, live, Rb, fs, cvx, arm_in, blk_in);
+  if constexpr (SPLIT_DETECT) {
+  if (live) {
+    // hand the results to the next phase through the env's LDS slot
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      env.Rb[b][0] = Rb[b].cx.x; env.Rb[b][1] = Rb[b].cx.y; env.Rb[b][2] = Rb[b].cx.z; env.Rb[b][3] = Rb[b].cy.x; env.Rb[b][4] = Rb[b].cy.y; env.Rb[b][5] = Rb[b].cy.z;
+      env.Rb[b][6] = Rb[b].cz.x; env.Rb[b][7] = Rb[b].cz.y; env.Rb[b][8] = Rb[b].cz.z;
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double* o = env.fl[b][k];
+        o[0] = fs[b].on[k] ? 1.0 : 0.0; o[1] = fs[b].dist[k]; o[2] = fs[b].r[k].x; o[3] = fs[b].r[k].y; o[4] = fs[b].r[k].z;
+      }
+      env.blk_in[b] = blk_in[b] ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) {
+      double* o = env.cv[k];
+      o[0] = cvx.hit[k] ? 1.0 : 0.0; o[1] = cvx.dist[k]; o[2] = cvx.pos[k].x; o[3] = cvx.pos[k].y; o[4] = cvx.pos[k].z; o[5] = cvx.n[k].x; o[6] = cvx.n[k].y; o[7] = cvx.n[k].z;
+    }
+    env.arm_in = arm_in ? 1 : 0;
+  }
+  }
+}
+
+// The substep is inlined into its two call sites (the control-step loop and the same-step auto-reset's settle loop): as a
+// non-inlined function it saved and restored ~130 callee-saved registers per call, every lane, every substep.
+__device__ __forceinline__ void physics_step(int nb, bool live) {
+  if constexpr (SPLIT_DETECT) detect_phase(nb, live);
+  EnvLds& env = env_lds();
+  World& s = env.w;
+  const double* ctrl = env.ctrl;
+  double* cs = env.cs;
+  double* sn = env.sn;
+  StepInfo& info = env.info;
+  const int nv = NJ + 6 * nb;
+  double Marm_l[SPLIT_DETECT ? 1 : 21], qacc_l[SPLIT_DETECT ? 1 : NV];
+  double* Marm = SPLIT_DETECT ? env.Marm : Marm_l;
+  double* qacc = SPLIT_DETECT ? env.qacc : qacc_l;
+  int clamped = 0;
+  bool coupled = false, arm_in = false, blk_in[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) blk_in[b] = false;
+  ConvexHits cvx;        // 5-slot instance only (one function: the results are locals)
+  FloorSlots fs[NB];
+  M3 Rb[NB];
+  auto get_Rb = [&](int b) { if constexpr (SPLIT_DETECT) return env_Rb(env, b); else return Rb[b]; };
+  auto get_fs = [&](int b) { if constexpr (SPLIT_DETECT) return env_fs(env, b); else return fs[b]; };
+  unsigned long long tt = 0;
+  PP_TIC(tt);
+  if constexpr (!SPLIT_DETECT) detect_body(nb, live, Rb, fs, cvx, arm_in, blk_in);
   PP_ACC(info, 0, tt);
+  if (live) {
+    if constexpr (SPLIT_DETECT) {  // the detection results stay in the env's LDS slot and are read where they are used
+#pragma unroll
+      for (int b = 0; b < NB; b++) blk_in[b] = env.blk_in[b] != 0;
+      arm_in = env.arm_in != 0;
+    }
   // arm smooth dynamics
   double bias[NJ], fact[NJ];
   ur5e_pp_M_gen(cs, sn, Marm);
@@ -1640,7 +1758,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
   if (coupled) info.rows_active = true;
 #pragma unroll
   for (int b = 0; b < NB; b++)
-    if (b < nb) block_smooth_force(Rb[b], s.b[b].w, shape_of(s.b[b]), qacc + NJ + 6 * b);
+    if (b < nb) block_smooth_force(get_Rb(b), s.b[b].w, shape_of(s.b[b]), qacc + NJ + 6 * b);
   }  // live
   // mj_setConst's meaninertia of THIS env's model: the arm's share + every block's (shape-dependent) share
   double meaninertia = UR5E_PP_MEANINERTIA * NJ;
@@ -1656,21 +1774,23 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (lane < EPW) {
 #pragma unroll
       for (int b = 0; b < NB; b++) {
-        const bool need = live && !blk_in[b] && b < nb && (fs[b].on[0] || fs[b].on[1] || fs[b].on[2] || fs[b].on[3]);
+        const FloorSlots fsb = get_fs(b);
+        const bool need = live && !blk_in[b] && b < nb && (fsb.on[0] || fsb.on[1] || fsb.on[2] || fsb.on[3]);
         QuadIn& in = qx.in[lane][b];
         in.need = need;
         if (need) {
+          const M3 Rbb = get_Rb(b);
           info.rows_active = true;
           in.shape = s.b[b].shape; in.scale = s.b[b].scale; in.meaninertia = meaninertia;
-          in.R[0] = Rb[b].cx.x; in.R[1] = Rb[b].cx.y; in.R[2] = Rb[b].cx.z; in.R[3] = Rb[b].cy.x; in.R[4] = Rb[b].cy.y; in.R[5] = Rb[b].cy.z;
-          in.R[6] = Rb[b].cz.x; in.R[7] = Rb[b].cz.y; in.R[8] = Rb[b].cz.z;
+          in.R[0] = Rbb.cx.x; in.R[1] = Rbb.cx.y; in.R[2] = Rbb.cx.z; in.R[3] = Rbb.cy.x; in.R[4] = Rbb.cy.y; in.R[5] = Rbb.cy.z;
+          in.R[6] = Rbb.cz.x; in.R[7] = Rbb.cz.y; in.R[8] = Rbb.cz.z;
           in.qv[0] = s.b[b].v.x; in.qv[1] = s.b[b].v.y; in.qv[2] = s.b[b].v.z; in.qv[3] = s.b[b].w.x; in.qv[4] = s.b[b].w.y; in.qv[5] = s.b[b].w.z;
 #pragma unroll
           for (int k = 0; k < 6; k++) in.f[k] = qacc[NJ + 6 * b + k];
 #pragma unroll
           for (int k = 0; k < 4; k++) {
-            in.on[k] = fs[b].on[k]; in.dist[k] = fs[b].dist[k];
-            in.r[k][0] = fs[b].r[k].x; in.r[k][1] = fs[b].r[k].y; in.r[k][2] = fs[b].r[k].z;
+            in.on[k] = fsb.on[k]; in.dist[k] = fsb.dist[k];
+            in.r[k][0] = fsb.r[k].x; in.r[k][1] = fsb.r[k].y; in.r[k][2] = fsb.r[k].z;
           }
         }
       }
@@ -1730,7 +1850,7 @@ __device__ __noinline__ void physics_step(World& s, const double* ctrl, double* 
     if (b >= nb) continue;
     const int o = NJ + 6 * b;
     double x[6];
-    block_minv(Rb[b], shape_of(s.b[b]), qacc + o, x);
+    block_minv(get_Rb(b), shape_of(s.b[b]), qacc + o, x);
 #pragma unroll
     for (int i = 0; i < 6; i++) { qacc[o + i] = x[i]; acc2 = fma(x[i], x[i], acc2); }
   }
@@ -1900,87 +2020,104 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
   int nmax = nsub;
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) nmax = max(nmax, __shfl_xor(nmax, m));
+  EnvLds& env = env_lds();
+  bool bad = false, terminate = false, again = false;
+  // Two passes through ONE substep loop (the substep is inlined: a single call site keeps one copy of it in the
+  // instruction cache): pass 0 = this control step (or the reset's settle steps), pass 1 = the settle steps of the
+  // same-step auto-reset (SB3 VecEnv convention) of the lanes whose episode just ended; the others idle through it.
 #pragma unroll 1
-  for (int sub = 0; sub < nmax; sub++) {
-    double ctrl[NJ];
-    if (stepping) {
-      const double t = fmin(fmax(s.time, t0), t1);
-      for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    } else {
-      for (int j = 0; j < NJ; j++) ctrl[j] = ctrl0[j];
-    }
-    physics_step(s, ctrl, cs, sn, nb, info, sub < nsub);
-  }
+  for (int pass = 0; pass < 2; pass++) {
+    int nloop = nmax;
+    if (pass == 1) {
+      if (IS_RESET || p.autoreset != MJS_AUTORESET_SAME_STEP || !__any(stepping && terminate)) break;
+      again = stepping && terminate;
+      if (again) {
+        if (valid && p.out.terminal_obs)
+          for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+        episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
+        for (int j = 0; j < NJ; j++) { ctrl0[j] = s.q[j]; sincos(s.q[j], &sn[j], &cs[j]); }
+      }
+      info = StepInfo{false, false, false, 0};
 #ifdef MJS_STAMPS
-  if (p.stamps && threadIdx.x == 0 && !IS_RESET)
-    for (int k = 0; k < 16; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
+      for (int k = 0; k < 16; k++) info.cyc[k] = 0;
 #endif
-  bool bad = info.bad, terminate = false;
-  if (resetting) {
-    const int ncon = count_contacts(s, cs, sn, nb);
-    if (valid) {
-      store_world(p, i, s);
-      p.flags[i] = 0;
-      make_obs(s, cs, sn, nb, obs);
-      write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
+      nloop = MJS_PP_SETTLE_STEPS;
     }
-  } else if (stepping) {
-    for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
-    for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
-    make_obs(s, cs, sn, nb, obs);
-    // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
-    double sum = 0, nearest = INFINITY;
-    int inside = 0;
-    for (int b = 0; b < nb; b++) {
-      const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
-      const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
-      sum += dt;
-      inside += dt < MJS_PP_TARGET_RADIUS;
-      nearest = fmin(nearest, dr);
-    }
-    const bool success = inside == nb;
-    double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
-    double discount = success ? 0.0 : 1.0;
-    terminate = success || s.episode_step >= (double)p.max_episode_steps;
-    if (bad) { reward = 0; discount = 0; terminate = true; }
-    if (s.time >= p.time_limit) terminate = true;
-    const int ncon = count_contacts(s, cs, sn, nb);
-    const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-                      (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
-    const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-    if (valid) {
-      store_world(p, i, s);
-      p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
-      write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
-    }
-  }
-  // same-step auto-reset (SB3 VecEnv convention): the lanes whose episode just ended run a reset, the others idle
-  if (!IS_RESET && p.autoreset == MJS_AUTORESET_SAME_STEP && __any(stepping && terminate)) {
-    const bool again = stepping && terminate;
-    if (again) {
-      if (valid && p.out.terminal_obs)
-        for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
-      episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
-      for (int j = 0; j < NJ; j++) { ctrl0[j] = s.q[j]; sincos(s.q[j], &sn[j], &cs[j]); }
-    }
-    StepInfo info2{false, false, false, 0};
-#ifdef MJS_STAMPS
-    for (int k = 0; k < 16; k++) info2.cyc[k] = 0;
-#endif
+    env.w = s;
+    for (int j = 0; j < NJ; j++) { env.cs[j] = cs[j]; env.sn[j] = sn[j]; }
+    env.info = info;
+    const bool lerp = stepping && pass == 0;
 #pragma unroll 1
-    for (int sub = 0; sub < MJS_PP_SETTLE_STEPS; sub++) physics_step(s, ctrl0, cs, sn, nb, info2, again && valid);
-    if (again) {
-      const int ncon2 = count_contacts(s, cs, sn, nb);
+    for (int sub = 0; sub < nloop; sub++) {
+      if (lerp) {
+        const double t = fmin(fmax(env.w.time, t0), t1);
+        for (int j = 0; j < NJ; j++) env.ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+      } else {
+        for (int j = 0; j < NJ; j++) env.ctrl[j] = ctrl0[j];
+      }
+      physics_step(nb, pass == 0 ? sub < nsub : (again && valid));
+    }
+    s = env.w;
+    for (int j = 0; j < NJ; j++) { cs[j] = env.cs[j]; sn[j] = env.sn[j]; }
+    info = env.info;
+    if (pass == 1) {
+      if (again) {
+        const int ncon2 = count_contacts(s, cs, sn, nb);
+        if (valid) {
+          store_world(p, i, s);
+          p.flags[i] = 0;
+          make_obs(s, cs, sn, nb, obs);
+          if (p.out.obs)
+            for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+          if (p.out.ncon) p.out.ncon[i] = ncon2;
+        }
+      }
+      break;
+    }
+#ifdef MJS_STAMPS
+    if (p.stamps && threadIdx.x == 0 && !IS_RESET)
+      for (int k = 0; k < 16; k++) p.stamps[(size_t)blockIdx.x * 16 + k] = info.cyc[k];
+#endif
+    bad = info.bad;
+    if (resetting) {
+      const int ncon = count_contacts(s, cs, sn, nb);
       if (valid) {
         store_world(p, i, s);
         p.flags[i] = 0;
         make_obs(s, cs, sn, nb, obs);
-        if (p.out.obs)
-          for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-        if (p.out.ncon) p.out.ncon[i] = ncon2;
+        write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);
+      }
+    } else if (stepping) {
+      for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);
+      for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z) || bad_value(s.b[b].v.x) || bad_value(s.b[b].v.y) || bad_value(s.b[b].v.z);
+      make_obs(s, cs, sn, nb, obs);
+      // reward / accomplished / step limit (robot_planar_push.py:203-241, base.py:47-57)
+      double sum = 0, nearest = INFINITY;
+      int inside = 0;
+      for (int b = 0; b < nb; b++) {
+        const double dx = s.b[b].p.x - s.target[0], dy = s.b[b].p.y - s.target[1], rx = obs[0] - s.b[b].p.x, ry = obs[1] - s.b[b].p.y;
+        const double dt = sqrt(dx * dx + dy * dy), dr = sqrt(rx * rx + ry * ry);
+        sum += dt;
+        inside += dt < MJS_PP_TARGET_RADIUS;
+        nearest = fmin(nearest, dr);
+      }
+      const bool success = inside == nb;
+      double reward = p.reward_type == MJS_REW_SPARSE ? (double)inside : (-sum / nb - MJS_PP_NEAREST_COEF * nearest) * MJS_PP_REWARD_SCALE;
+      double discount = success ? 0.0 : 1.0;
+      terminate = success || s.episode_step >= (double)p.max_episode_steps;
+      if (bad) { reward = 0; discount = 0; terminate = true; }
+      if (s.time >= p.time_limit) terminate = true;
+      const int ncon = count_contacts(s, cs, sn, nb);
+      const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+                        (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
+      const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+      if (valid) {
+        store_world(p, i, s);
+        p.flags[i] = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
+        write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
       }
     }
-  }
+}
 }
 
 }  // namespace MJS_PP_NS
