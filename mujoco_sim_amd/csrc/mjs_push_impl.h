@@ -1767,7 +1767,6 @@ __device__ __noinline__ void detect_phase(int nb, bool live) {
 // The substep is inlined into its two call sites (the control-step loop and the same-step auto-reset's settle loop): as a
 // non-inlined function it saved and restored ~130 callee-saved registers per call, every lane, every substep.
 __device__ __forceinline__ void physics_step(int nb, bool live) {
-  if constexpr (SPLIT_DETECT) detect_phase(nb, live);
   EnvLds& env = env_lds();
   World& s = env.w;
   const double* ctrl = env.ctrl;
@@ -1789,7 +1788,8 @@ __device__ __forceinline__ void physics_step(int nb, bool live) {
   auto get_fs = [&](int b) { if constexpr (SPLIT_DETECT) return env_fs(env, b); else return fs[b]; };
   unsigned long long tt = 0;
   PP_TIC(tt);
-  if constexpr (!SPLIT_DETECT) detect_body(nb, live, Rb, fs, cvx, arm_in, blk_in);
+  if constexpr (SPLIT_DETECT) detect_phase(nb, live);
+  else detect_body(nb, live, Rb, fs, cvx, arm_in, blk_in);
   PP_ACC(info, 0, tt);
   if (live) {
     if constexpr (SPLIT_DETECT) {  // the detection results stay in the env's LDS slot and are read where they are used
