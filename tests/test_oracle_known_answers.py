@@ -528,3 +528,96 @@ def test_joint_space_move_converges_like_reference_test(oracle_mod):
         r = b.step(a)
     assert np.abs(r["obs"][:, :6] - target).max() < 1e-2
     assert not r["fault"].any()
+
+
+def test_scene_constants_match_reference_data_files():
+    """The scene constants tagged [REF] and the block hull tables against the DATA FILES the reference holds
+    (mujoco_sim/mjcf/walled_pointmass_arena.xml, google_language_table_blocks/*.xml, *.obj), read into
+    tests/golden/reference_scene_data.json by tests/golden/make_reference_data_pins.py in the build container."""
+    import json
+    import re
+
+    ref = json.loads((GOLDEN / "reference_scene_data.json").read_text())
+    inc = GOLDEN.parents[1] / "include"
+    spec, hulls = (inc / "mjs_scene_spec.h").read_text(), (inc / "mjs_block_hulls.h").read_text()
+
+    def arr(text, name, shape=None):
+        m = re.search(r"\b" + name + r"\b(?:\[[^=]*)?\s*=\s*(\{.*?\}|[^;]*);", text, re.S)
+        assert m, name
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        vals = np.array([float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", body.replace("f,", ",").replace("f}", "}"))])
+        return vals.reshape(shape) if shape else vals
+
+    a = ref["arena"]
+    # walled arena: ground half-size, wall planes at +-0.5 facing inwards with half-height 0.02, lights, colours
+    lo, hi, wz = arr(spec, "MJS_PM_ARENA_LO")[0], arr(spec, "MJS_PM_ARENA_HI")[0], arr(spec, "MJS_PM_WALL_Z")[0]
+    assert a["planes"]["ground"]["size"][:2] == [hi, hi] and lo == -hi
+    for name, axis, sign in (("wall_x", 0, -1), ("wall_y", 1, -1), ("wall_neg_x", 0, 1), ("wall_neg_y", 1, 1)):
+        w = a["planes"][name]
+        assert w["pos"][axis] == sign * hi and w["pos"][2] == wz and w["zaxis"][axis] == -sign and w["size"][2] == wz, name
+    np.testing.assert_allclose(arr(spec, "MJS_PM_LIGHT_POS", (2, 3)), a["lights"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(arr(spec, "MJS_PM_GRID_RGB1"), a["grid_rgb1"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(arr(spec, "MJS_PM_GRID_RGB2"), a["grid_rgb2"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(arr(spec, "MJS_PM_WALL_RGB"), a["decoration_rgba"][:3], rtol=0, atol=1e-7)
+    # blocks: mesh geoms turned z-up by quat (1 1 0 0); the hull tables' bounding boxes are the meshes' (a convex hull keeps
+    # the extremes), a hull has no more vertices than its mesh, every hull vertex lies inside the mesh's box
+    ncat = int(re.search(r"#define MJS_HULL_NCAT (\d+)", hulls).group(1))
+    maxv = int(re.search(r"#define MJS_HULL_MAXV (\d+)", hulls).group(1))
+    cats = ("cube", "moon", "pentagon", "star")
+    assert ncat == len(cats) == len(ref["blocks"])
+    nv = arr(hulls, "MJS_HULL_NV").astype(int)
+    blo, bhi = arr(hulls, "MJS_HULL_BOX_LO", (ncat, 3)), arr(hulls, "MJS_HULL_BOX_HI", (ncat, 3))
+    vert = arr(hulls, "MJS_HULL_VERT", (ncat, maxv, 3))
+    for c, cat in enumerate(cats):
+        b = ref["blocks"][cat]
+        assert b["geom_type"] == "mesh" and b["quat"] == [1.0, 1.0, 0.0, 0.0], cat
+        assert 4 <= nv[c] <= b["n_vertices"], cat
+        np.testing.assert_allclose(blo[c], b["body_frame_bbox_lo"], rtol=0, atol=1e-12, err_msg=cat)
+        np.testing.assert_allclose(bhi[c], b["body_frame_bbox_hi"], rtol=0, atol=1e-12, err_msg=cat)
+        v = vert[c, :nv[c]]
+        np.testing.assert_allclose(v.min(0), b["body_frame_bbox_lo"], rtol=0, atol=1e-12, err_msg=cat)
+        np.testing.assert_allclose(v.max(0), b["body_frame_bbox_hi"], rtol=0, atol=1e-12, err_msg=cat)
+
+
+def test_scene_constants_match_reference_source_literals():
+    """Every [REF] constant of include/mjs_scene_spec.h that restates a numeric literal of the reference's task / entity
+    sources against the numbers tests/golden/make_reference_data_pins.py read from those lines (file and line recorded in
+    tests/golden/reference_scene_data.json)."""
+    import json
+    import re
+
+    lit = json.loads((GOLDEN / "reference_scene_data.json").read_text())["literals"]
+    spec = (GOLDEN.parents[1] / "include" / "mjs_scene_spec.h").read_text()
+
+    def const(name):
+        m = re.search(r"\b" + name + r"\b(?:\[[^=]*)?\s*=\s*(\{.*?\}|[^;]*);", spec, re.S)
+        assert m, name
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S).replace("f,", ",").replace("f}", "}")
+        return [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", re.sub(r"(?<=\d)f\b", "", body))]
+
+    def box(prefix):  # EuclideanSpace((x0, x1), (y0, y1), (z0, z1)) -> LO, HI
+        lo, hi = const(prefix + "_LO"), const(prefix + "_HI")
+        return [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]
+
+    checked = 0
+    for name, pin in lit.items():
+        where = f"{name} vs {pin['file']}:{pin['line']}"
+        if name.startswith("MJS_"):
+            got = [v for n in name.split() for v in const(n)]
+        elif name.endswith("_SPACE"):
+            got = box({"BP_ROBOT_SPACE": "MJS_BP_ROBOT_SPACE", "BP_SWITCH_SPACE": "MJS_BP_SWITCH_SPACE", "RR_SPACE": "MJS_RR_SPACE",
+                       "PP_ROBOT_SPACE": "MJS_PP_ROBOT_SPACE", "PP_OBJECT_SPACE": "MJS_PP_OBJECT_SPACE", "PP_TARGET_SPACE": "MJS_PP_TARGET_SPACE"}[name])
+        elif name == "SW_BOX_SIZE":      # box geom half sizes = box_size / 2, button radius = box_size / 2.5 (switch.py:27,34)
+            got = [2 * const("MJS_SW_BOX_HALF")[0]]
+            assert abs(const("MJS_SW_BUTTON_RADIUS")[0] - pin["numbers"][0] / 2.5) < 1e-15, where
+        elif name == "SW_BOX_HEIGHT":    # button geom and site at z = box_height (switch.py:36,39)
+            got = const("MJS_SW_BUTTON_Z")
+        elif name.startswith("BLOCK_COLOR_"):
+            idx = ("RED", "BLUE", "GREEN", "YELLOW", "ORANGE", "PURPLE").index(name[len("BLOCK_COLOR_"):])
+            got = const("MJS_BLOCK_COLORS")[3 * idx:3 * idx + 3] + [1.0]
+        else:
+            raise AssertionError(f"unmapped pin {name}")
+        assert len(got) == len(pin["numbers"]), where
+        np.testing.assert_allclose(got, pin["numbers"], rtol=0, atol=1e-7, err_msg=where)  # float32 colour literals
+        checked += 1
+    assert checked == len(lit) >= 40
