@@ -165,6 +165,17 @@ MJS_K double MJS_G2F85_DIAGINERTIA[3] = {0.0011, 0.0009, 0.0005};
 MJS_K double MJS_G2F85_TCP_Z = 0.174;          /* [REF] gripper.py:46-48 */
 MJS_K double MJS_G2F85_OPEN = 0.085;           /* [REF] gripper.py:50-52 */
 MJS_K double MJS_G2F85_MAX_DRIVER = 0.8;       /* [REF] gripper.py:38 */
+/* [MEN] robotiq 2f85.xml (absent package robot_descriptions): `fingers_actuator` = general actuator on the fixed tendon
+ * "split" (0.5 right_driver_joint + 0.5 left_driver_joint): gainprm 0.3137255 (= 80 / 255), biasprm 0 -100 -10, ctrlrange
+ * 0 255, forcerange -5 5; driver joints: armature 0.005, damping 0.1, range 0 0.8. The reduced gripper keeps
+ * the driver angle of the two equality-coupled fingers as its one coordinate: inertia 2 x armature, damping 2 x damping. */
+MJS_K double MJS_G2F85_ACT_GAIN = 0.3137255;
+MJS_K double MJS_G2F85_ACT_KP = 100.0;
+MJS_K double MJS_G2F85_ACT_KV = 10.0;
+MJS_K double MJS_G2F85_ACT_FORCE = 5.0;
+MJS_K double MJS_G2F85_CTRL_MAX = 255.0;
+MJS_K double MJS_G2F85_DRIVER_ARMATURE = 0.005;
+MJS_K double MJS_G2F85_DRIVER_DAMPING = 0.1;
 /* cylinder EEF [REF] entities/eef/cylinder.py:17-41 */
 MJS_K double MJS_CYL_RADIUS = 0.02;
 MJS_K double MJS_CYL_HALFLEN = 0.05;

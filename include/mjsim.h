@@ -32,7 +32,9 @@ enum {
   MJS_TASK_BUTTON_PUSH = 3      /* tasks/robot_push_button.py */
 };
 /* Button-Push action spaces (robot_push_button.py:35-36,143-157): absolute joints + gripper (7-D, the
- * registered default) or absolute TCP position + gripper (4-D). Other tasks ignore the field. */
+ * registered default) or absolute TCP position + gripper (4-D). The last component is the commanded finger opening in
+ * metres, [0, 0.085] (Robotiq2f85.move, gripper.py:77-84): it drives the reduced 2F-85 of this build (driver angle and
+ * velocity = rows 16, 17 of the Button-Push state). Other tasks ignore the field. */
 enum { MJS_ACTION_ABS_JOINT = 0, MJS_ACTION_ABS_EEF = 1 };
 /* reward types: point_reach.py:11-14, robot_reach.py:37-38 */
 enum { MJS_REW_SPARSE = 0, MJS_REW_DENSE_POTENTIAL = 1, MJS_REW_DENSE_NEG_DISTANCE = 2, MJS_REW_DENSE_BIASED_NEG_DISTANCE = 3 };

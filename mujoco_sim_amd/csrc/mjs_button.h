@@ -9,10 +9,11 @@
 //       entities/props/switch.py:51-60,71-72 Switch._update_activation on the touch sensor
 //   robot_push_button.py:167-170,205-219 reward / goal / termination / discount,
 //   robot_push_button.py:126-134 + switch.py:62-65 initialize_episode (6 uniforms + IK + switch pose)
-// Deviation D-1 applies: the 2F-85 is a rigid lump; its CLOSED finger tips are represented by one
-// collision sphere whose lowest point is the TCP (include/mjs_scene_spec.h MJS_G2F85_PROXY_RADIUS), so
-// the contacts that exist are sphere-floor, sphere-switch box and sphere-button cylinder, pyramidal
-// condim 3. One wavefront per 64 envs (lane per env); the contact / joint-limit rows go through a
+// Deviation D-1b applies: the 2F-85 is reduced to its driver angle (state rows S_GRIP: angle, velocity; the action's last
+// component goes through Robotiq2f85.move's map to the fingers_actuator ctrl); its finger pads are two collision spheres
+// (include/mjs_scene_spec.h MJS_G2F85_PROXY_RADIUS, lowest point = the TCP plane) at +-(opening / 2 + r) along the
+// gripper's y, so the contacts that exist are sphere-floor, sphere-switch box and sphere-button cylinder per tip,
+// pyramidal condim 3. One wavefront per 64 envs (lane per env); the contact / joint-limit rows go through a
 // generic in-lane primal Newton solver that is only entered by lanes that have active rows.
 #pragma once
 #include "mjs_kernel_common.h"
@@ -21,7 +22,7 @@
 namespace bp {
 
 using rr::NJ;
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, STATE_DIM = 16;
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16, STATE_DIM = 18;  // S_GRIP: driver angle, velocity of the reduced 2F-85
 constexpr int OBS_DIM = 13, ACT_DIM_JOINT = 7, ACT_DIM_EEF = 4;
 enum { FLAG_SWITCH_ACTIVE = 4, FLAG_SWITCH_PRESSED = 8 };
 
@@ -35,25 +36,27 @@ MJS_DEV void make_frame(V3 n, V3& t1, V3& t2) {
   t2 = cross(n, t1);
 }
 
+constexpr int NCS = 6;  // contact slots: finger tip t (0: +y, 1: -y of the gripper frame) x (floor, switch box, button cylinder) = 3 t + k
 struct ContactSet {
-  int n;             // number of detected contacts (dist <= 0) of the stand-in sphere
-  bool hit[3];       // fixed slots in MuJoCo's detection order: 0 floor, 1 switch box, 2 button cylinder
-  double dist[3];
-  V3 pos[3], nrm[3];
-  double sgn[3];     // +1: the sphere is geom2 (plane-sphere), -1: the sphere is geom1
-  bool on_switch[3];
+  int n;             // number of detected contacts (dist <= 0) of the two finger-tip spheres
+  bool hit[NCS];     // fixed slots, per tip in MuJoCo's detection order: floor, switch box, button cylinder
+  double dist[NCS];
+  V3 pos[NCS], nrm[NCS];
+  double sgn[NCS];   // +1: the sphere is geom2 (plane-sphere), -1: the sphere is geom1
+  bool on_switch[NCS];
 };
 
-// collision of the gripper stand-in sphere (centre c) with floor, switch box, button cylinder, in the
-// oracle's pair order (mjc_PlaneSphere, mjc_SphereBox, mjc_SphereCylinder; normals geom1 -> geom2)
-MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
+// collision of one finger-tip sphere (centre c) with floor, switch box, button cylinder (mjc_PlaneSphere, mjc_SphereBox,
+// mjc_SphereCylinder; normals geom1 -> geom2) into the slots base .. base + 2; adds to cs.n
+MJS_DEV void detect_tip(V3 c, V3 sw, ContactSet& cs, int base) {
   const double rp = MJS_G2F85_PROXY_RADIUS;
-  cs.n = 0;
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    cs.hit[k] = false; cs.dist[k] = 0; cs.nrm[k] = v3(0, 0, 1); cs.pos[k] = v3(0, 0, 0); cs.sgn[k] = k == 0 ? 1.0 : -1.0; cs.on_switch[k] = k != 0;
+    cs.hit[base + k] = false; cs.dist[base + k] = 0; cs.nrm[base + k] = v3(0, 0, 1); cs.pos[base + k] = v3(0, 0, 0);
+    cs.sgn[base + k] = k == 0 ? 1.0 : -1.0; cs.on_switch[base + k] = k != 0;
   }
-  auto add = [&](int k, double dist, V3 n) {
+  auto add = [&](int k_, double dist, V3 n) {
+    const int k = base + k_;
     cs.n++;
     cs.hit[k] = true; cs.dist[k] = dist; cs.nrm[k] = n;
     cs.pos[k] = cs.sgn[k] > 0 ? madd(c, -(rp + 0.5 * dist), n) : madd(c, rp + 0.5 * dist, n);
@@ -107,25 +110,59 @@ MJS_DEV void detect_contacts(V3 c, V3 sw, ContactSet& cs) {
   }
 }
 
+// point of the tool axis at the height of the finger-tip centres (the tips sit at +-(opening / 2 + r) along the gripper's y)
 MJS_DEV V3 proxy_centre(const rr::Chain& c) {
   return madd(c.p[6], MJS_UR_FLANGE_POS[1] + MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS, c.R[6].cy);
 }
 
-// Constraint stage of one physics step for a lane that has rows: joint limits + stand-in sphere contacts.
+// ---- reduced Robotiq 2F-85 (gripper.py:36-98; oracle/om_tasks.c gripper_*) ------------------------------
+// One coordinate per gripper: the driver angle of the two equality-coupled fingers. ctrl = Robotiq2f85.move's map of the
+// commanded opening, force = the menagerie fingers_actuator, integrated as mj_implicit (fast) integrates a dof with joint
+// damping and an affine actuator; opening = the reference's own sine map; the two finger-tip spheres follow it.
+struct Grip { double th, vel; };
+MJS_DEV double grip_ctrl_of_opening(double finger_distance) {  // gripper.py:77-84, arcsin argument and ctrl clamped
+  const double a = clampd((1 - finger_distance / MJS_G2F85_OPEN) * sin(MJS_G2F85_MAX_DRIVER), -1.0, 1.0);
+  return clampd(asin(a) / MJS_G2F85_MAX_DRIVER * MJS_G2F85_CTRL_MAX, 0.0, MJS_G2F85_CTRL_MAX);
+}
+MJS_DEV double grip_opening(double th) { return MJS_G2F85_OPEN * (1 - sin(th) / sin(MJS_G2F85_MAX_DRIVER)); }  // gripper.py:73-75
+MJS_DEV void grip_integrate(Grip& g, double ctrl) {
+  const double h = MJS_RR_PHYSICS_DT, inertia = 2 * MJS_G2F85_DRIVER_ARMATURE, damping = 2 * MJS_G2F85_DRIVER_DAMPING;
+  double F = MJS_G2F85_ACT_GAIN * ctrl - MJS_G2F85_ACT_KP * g.th - MJS_G2F85_ACT_KV * g.vel;
+  bool clamped = false;
+  if (F > MJS_G2F85_ACT_FORCE) { F = MJS_G2F85_ACT_FORCE; clamped = true; }
+  if (F < -MJS_G2F85_ACT_FORCE) { F = -MJS_G2F85_ACT_FORCE; clamped = true; }
+  const double f = F - damping * g.vel;
+  g.vel += h * f / (inertia + h * (damping + (clamped ? 0.0 : MJS_G2F85_ACT_KV)));
+  g.th += h * g.vel;
+}
+// both finger tips against the scene: slots 0-2 = tip +y, 3-5 = tip -y (gripper frame y = -wrist_3 z)
+MJS_DEV void detect_contacts(const rr::Chain& ch, double th, V3 sw, ContactSet& cs) {
+  const V3 mid = proxy_centre(ch);
+  const double off = 0.5 * grip_opening(th) + MJS_G2F85_PROXY_RADIUS;
+  cs.n = 0;
+  detect_tip(madd(mid, -off, ch.R[6].cz), sw, cs, 0);
+  detect_tip(madd(mid, off, ch.R[6].cz), sw, cs, 3);
+}
+
+// Constraint stage of one physics step for a lane that has rows: joint limits + finger-tip sphere contacts.
 // STATIC row slots, everything unrolled (no indexed memory): 12 limit slots (2j = lower side of joint j, 2j+1 =
-// upper; J = +-e_j) and 3 contact slots (floor, switch box, button: the only pairs of this scene, in MuJoCo's
-// detection order) with 4 pyramid edges each, stored as the contact-frame Jacobian (normal, tangent 1, tangent 2)
+// upper; J = +-e_j) and 6 contact slots (per finger tip: floor, switch box, button: the only pairs of this scene)
+// with 4 pyramid edges each, stored as the contact-frame Jacobian (normal, tangent 1, tangent 2)
 // so that edge e = Jn +- mu * Jt: the oracle's row order. Primal Newton of mj_solPrimal (cost, gradient, exact
 // Hessian, Cholesky, 1-D Newton line search with MuJoCo's stopping rules), cold-started at qacc_smooth.
 // Cold path (noinline, works on copies): `Mf` = full symmetric M + armature, `qs` = qfrc_smooth in, += qfrc_constraint out.
-constexpr int NCS = 3;
+// The two finger tips have 6 possible contacts but rarely more than two at once: the stage works on NACT compact slots,
+// filled per lane with its ACTIVE contacts in detection order (branch-free selects), so that its unrolled static-slot code
+// and register footprint stay those of a 4-contact scene. A lane with more active contacts than slots drops the rest and
+// reports MJS_FAULT_UNSUPPORTED_CONTACT (both tips wedged between floor, box and button at once).
+constexpr int NACT = 4;
 struct ContactRows {
-  bool on[NCS];
-  double Jc[NCS][3][NJ];  // rows: normal, tangent 1, tangent 2 (already signed: geom2 - geom1)
-  double D[NCS], aref[NCS][4];
+  bool on[NACT];
+  double Jc[NACT][3][NJ];  // rows: normal, tangent 1, tangent 2 (already signed: geom2 - geom1)
+  double D[NACT], aref[NACT][4];
 };
-__device__ __noinline__ void constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, const double (*Mf)[NJ],
-                                              double* qs, double& touch) {
+__device__ __noinline__ bool constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, double grip_th,
+                                              const double (*Mf)[NJ], double* qs, double& touch) {
   const double mu = MJS_GEOM_FRICTION_SLIDE;
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
   const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
@@ -149,18 +186,39 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
   }
   // wave-uniform slot masks: a slot no lane of the wavefront uses costs nothing below (scalar branches)
   const bool use_lim = __any(any_lim);
-  bool use_c[NCS];
+  bool use_c[NACT], overflow;
   ContactRows cr;
-  V3 cpos[NCS];
-  bool on_switch[NCS];
+  V3 cpos[NACT];
+  bool on_switch[NACT];
   {
     rr::Chain ch;
     rr::fk_cs(cs, sn, ch);
-    ContactSet con;
-    detect_contacts(proxy_centre(ch), sw, con);
+    ContactSet all;
+    detect_contacts(ch, grip_th, sw, all);
+    // compact the active contacts (detected with dist < 0; dist == margin creates no rows) into the NACT slots
+    struct { bool hit[NACT]; double dist[NACT], sgn[NACT]; V3 pos[NACT], nrm[NACT]; bool on_switch[NACT]; } con;
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
-      cr.on[c] = con.hit[c] && con.dist[c] < 0.0;  // detected but dist == margin creates no rows
+    for (int j = 0; j < NACT; j++) { con.hit[j] = false; con.dist[j] = 0; con.sgn[j] = 1; con.pos[j] = v3(0, 0, 0); con.nrm[j] = v3(0, 0, 1); con.on_switch[j] = false; }
+    int cnt = 0;
+#pragma unroll
+    for (int k = 0; k < NCS; k++) {
+      const bool act = all.hit[k] && all.dist[k] < 0.0;
+#pragma unroll
+      for (int j = 0; j < NACT; j++) {
+        const bool take = act && cnt == j;
+        con.hit[j] = take ? true : con.hit[j];
+        con.dist[j] = take ? all.dist[k] : con.dist[j];
+        con.sgn[j] = take ? all.sgn[k] : con.sgn[j];
+        con.pos[j] = take ? all.pos[k] : con.pos[j];
+        con.nrm[j] = take ? all.nrm[k] : con.nrm[j];
+        con.on_switch[j] = take ? all.on_switch[k] : con.on_switch[j];
+      }
+      cnt += act ? 1 : 0;
+    }
+    overflow = cnt > NACT;
+#pragma unroll
+    for (int c = 0; c < NACT; c++) {
+      cr.on[c] = con.hit[c];
       use_c[c] = __any(cr.on[c]);
       cpos[c] = con.pos[c];
       on_switch[c] = con.on_switch[c];
@@ -186,8 +244,8 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
     }
   }
   // ---- Newton
-  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], ljar[rr::NLIM], lforce[rr::NLIM], cjar[NCS][4], cforce[NCS][4];
-  bool lact[rr::NLIM], cact[NCS][4];
+  double L[NJ][NJ], a[NJ], a_s[NJ], Ma[NJ], ljar[rr::NLIM], lforce[rr::NLIM], cjar[NACT][4], cforce[NACT][4];
+  bool lact[rr::NLIM], cact[NACT][4];
 #pragma unroll
   for (int i = 0; i < NJ; i++) {
 #pragma unroll
@@ -220,7 +278,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
       for (int k = 0; k < rr::NLIM; k++) ljar[k] = -laref[k] + ((k & 1) ? -a[k >> 1] : a[k >> 1]);
     }
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (!use_c[c]) continue;
       double ja[4];
       edge_values(a, c, ja);
@@ -240,7 +298,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
       }
     }
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (!use_c[c]) continue;
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -259,7 +317,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
 #pragma unroll
     for (int i = 0; i < NJ; i++) f[i] = use_lim ? lforce[2 * i] - lforce[2 * i + 1] : 0.0;
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (!use_c[c]) continue;
       const double fn = cforce[c][0] + cforce[c][1] + cforce[c][2] + cforce[c][3];
       const double f1 = mu * (cforce[c][0] - cforce[c][1]), f2 = mu * (cforce[c][2] - cforce[c][3]);
@@ -284,7 +342,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
       if (use_lim && lact[2 * i + 1]) H[i][i] += lD[2 * i + 1];
     }
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (!use_c[c]) continue;
       // sum over active edges of D (Jn + s mu Jt_k)(Jn + s mu Jt_k)^T
       const double n0 = cact[c][0], n1 = cact[c][1], n2 = cact[c][2], n3 = cact[c][3];
@@ -313,9 +371,9 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
 #pragma unroll
     for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - qs[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
     if (sqrt(snorm) < MJS_MINVAL) break;
-    double cjv[NCS][4];
+    double cjv[NACT][4];
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (use_c[c]) edge_values(search, c, cjv[c]);
     }
     const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
@@ -332,7 +390,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
         }
       }
 #pragma unroll
-      for (int c = 0; c < NCS; c++) {
+      for (int c = 0; c < NACT; c++) {
         if (!use_c[c]) continue;
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -356,7 +414,7 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
       for (int k = 0; k < rr::NLIM; k++) ljar[k] += alpha * ((k & 1) ? -search[k >> 1] : search[k >> 1]);
     }
 #pragma unroll
-    for (int c = 0; c < NCS; c++) {
+    for (int c = 0; c < NACT; c++) {
       if (!use_c[c]) continue;
 #pragma unroll
       for (int e = 0; e < 4; e++) cjar[c][e] += alpha * cjv[c][e];
@@ -380,17 +438,18 @@ __device__ __noinline__ void constraint_stage(const double* q, const double* v, 
   const double sr = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE, sh = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
   touch = 0;
 #pragma unroll
-  for (int c = 0; c < NCS; c++) {
+  for (int c = 0; c < NACT; c++) {
     const V3 loc = cpos[c] - v3(sw.x, sw.y, sw.z + MJS_SW_BUTTON_Z);
     const bool in_site = !(loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh);
     if (use_c[c] && cr.on[c] && on_switch[c] && in_site) touch += cforce[c][0] + cforce[c][1] + cforce[c][2] + cforce[c][3];
   }
+  return overflow;
 }
 
 // One Physics.step() of a lane: smooth dynamics (generated, Button-Push payload variant), constraint
 // stage when `maybe_rows`, implicitfast solve. Returns the integrator's acceleration.
-MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, bool maybe_rows,
-                            double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active) {
+MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, double grip_th,
+                            bool maybe_rows, double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow) {
   double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
   ur5e_bp_M_gen(cs, sn, M);
   ur5e_bp_bias_gen(cs, sn, v, bias);
@@ -405,17 +464,17 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   touch = 0;
   ncon_proxy = 0;
   if (maybe_rows) {
-    // cheap in-line detection: any joint beyond its range, any active contact of the stand-in sphere?
+    // cheap in-line detection: any joint beyond its range, any active contact of a finger-tip sphere?
     bool rows = false;
 #pragma unroll
     for (int j = 0; j < NJ; j++) rows = rows || (q[j] < MJS_UR_JNT_RANGE[j][0]) || (q[j] > MJS_UR_JNT_RANGE[j][1]);
     rr::Chain ch;
     rr::fk_cs(cs, sn, ch);
     ContactSet con;
-    detect_contacts(proxy_centre(ch), sw, con);
+    detect_contacts(ch, grip_th, sw, con);
     ncon_proxy = con.n;
 #pragma unroll
-    for (int c = 0; c < 3; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
+    for (int c = 0; c < NCS; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
     if (rows) {  // rare: hand copies to the out-of-line constraint stage, nothing of the hot path lives in memory
       double Mf[NJ][NJ], qs[NJ];
 #pragma unroll
@@ -425,7 +484,7 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
         Mf[i][i] += MJS_UR_ARMATURE;
         qs[i] = rhs[i];
       }
-      constraint_stage(q, v, cs, sn, sw, Mf, qs, touch);
+      slot_overflow = constraint_stage(q, v, cs, sn, sw, grip_th, Mf, qs, touch) || slot_overflow;
 #pragma unroll
       for (int i = 0; i < NJ; i++) rhs[i] = qs[i];
       rows_active = true;
@@ -437,8 +496,8 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   for (int j = 0; j < NJ; j++) qacc_int[j] = rhs[j];
 }
 
-// can this lane get constraint rows within the next `h` seconds? A joint within reach of its range, or the gripper
-// stand-in within reach of the floor / the switch, where "reach" is what the force-clamped servos add from rest
+// can this lane get constraint rows within the next `h` seconds? A joint within reach of its range, or a finger tip
+// within reach of the floor / the switch, where "reach" is what the force-clamped servos add from rest
 // (12 h^2 m: 0.12 m per 0.1 s control step; 60 h^2 rad for a joint) plus the distance covered at the CURRENT speed (the
 // stand-in's Cartesian |J(q) v|; mjs_set_state can inject any velocity). The kernel asks for the whole control step first;
 // a workgroup that fails that asks again before every segment of 5 substeps (a fast swing far from everything passes
@@ -447,20 +506,35 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
 // MJS_FAULT_FASTPATH_VIOLATED.
 constexpr int SEGMENT_SUBSTEPS = 5;
 static_assert(MJS_RR_NSUB % SEGMENT_SUBSTEPS == 0, "segments tile the control step");
-MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch, V3 sw, double h) {
-  const V3 c = proxy_centre(ch);
+MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch, V3 sw, Grip grip, double grip_ctrl, double h) {
+  const V3 mid = proxy_centre(ch);  // the tool-axis point between the finger tips
   V3 vel = v3(0, 0, 0);
+  double spin = 0;
   bool near = false;
 #pragma unroll
   for (int j = 0; j < NJ; j++) {
-    vel += v[j] * cross(rr::joint_axis(ch, j), c - ch.p[j + 1]);
+    vel += v[j] * cross(rr::joint_axis(ch, j), mid - ch.p[j + 1]);
+    spin += fabs(v[j]);
     const double margin = 60.0 * h * h + h * fabs(v[j]);
     near = near || (q[j] - MJS_UR_JNT_RANGE[j][0] < margin) || (MJS_UR_JNT_RANGE[j][1] - q[j] < margin);
   }
-  const double travel = 12.0 * h * h + h * sqrt(dot(vel, vel));
-  const V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
+  // a finger tip sits `off` beside that point along the gripper's y. Within h it moves sideways by at most what the driver
+  // can turn (|d off / d theta| <= 0.06 m/rad; velocity now + the force range over the reduced inertia: 300 h^2 rad) and never
+  // past the commanded opening (the servo is over-damped; 3 mm cover its clamp chatter), and it is carried round the axis
+  // point by the arm's rotation (|omega| <= sum |v_j|)
+  const double off = 0.5 * grip_opening(grip.th) + MJS_G2F85_PROXY_RADIUS;
+  const double off_cmd = 0.5 * grip_opening(grip_ctrl * (MJS_G2F85_MAX_DRIVER / MJS_G2F85_CTRL_MAX)) + MJS_G2F85_PROXY_RADIUS;
+  const double sideways = fmin(fabs(off_cmd - off), 0.06 * (fabs(grip.vel) * h + 300.0 * h * h)) + 0.003;
+  const double travel = 12.0 * h * h + h * sqrt(dot(vel, vel)) + sideways + off * spin * h;
   const double reach = 0.08 + travel;
-  return near || c.z < 0.03 + travel || dot(d, d) < reach * reach;
+  bool close = false;
+#pragma unroll
+  for (int t = 0; t < 2; t++) {
+    const V3 c = madd(mid, t == 0 ? -off : off, ch.R[6].cz);
+    const V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
+    close = close || c.z < 0.03 + travel || dot(d, d) < reach * reach;
+  }
+  return near || close;
 }
 
 // Switch._update_activation (switch.py:51-60)
@@ -488,7 +562,7 @@ struct ResetOut {
   rr::State st;
   uint8_t flags;
   int ncon;
-};
+};  // the gripper of a fresh episode: driver angle 0 (open), at rest (mj_resetData)
 __device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_flags) {
   ResetOut o;
   RngCursor c = rng_open(rng, i);
@@ -509,7 +583,8 @@ __device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_fla
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(o.st.q[j], &sn[j], &cs[j]);
   V3 sw = v3(o.st.target[0], o.st.target[1], o.st.target[2]);
-  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, true, qacc, touch, ncp, rows);
+  bool overflow_ = false;
+  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, 0.0, true, qacc, touch, ncp, rows, overflow_);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   switch_update(touch, f);                      // with _is_active = False
   o.flags = f;
@@ -534,11 +609,12 @@ struct SoloIn {
   uint8_t flags;
   bool maybe_rows;
   int first_substep;  // the substeps before it were taken on the row-free path
+  double grip_th, grip_vel, grip_ctrl;
 };
 struct SoloOut {
-  double q[NJ], v[NJ], cs[NJ], sn[NJ], time;
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], time, grip_th, grip_vel;
   uint8_t flags;
-  bool bad, rows_active;
+  bool bad, rows_active, slot_overflow;
 };
 __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
   double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ];
@@ -548,8 +624,9 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
   const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
   const V3 sw = v3(in.sw[0], in.sw[1], in.sw[2]);
   const bool maybe_rows = in.maybe_rows;
+  Grip grip{in.grip_th, in.grip_vel};
   uint8_t flags = in.flags;
-  bool bad = false, rows_active = false;
+  bool bad = false, rows_active = false, slot_overflow = false;
   int ncon_proxy = 0;
 #pragma unroll 1
   for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
@@ -557,7 +634,8 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
     double ctrl[NJ], qacc[NJ], touch;
 #pragma unroll
     for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    physics_forces(q, v, ctrl, cs, sn, sw, maybe_rows, qacc, touch, ncon_proxy, rows_active);
+    physics_forces(q, v, ctrl, cs, sn, sw, grip.th, maybe_rows, qacc, touch, ncon_proxy, rows_active, slot_overflow);
+    grip_integrate(grip, in.grip_ctrl);
     double acc2 = 0, dq2 = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
@@ -580,9 +658,11 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
 #pragma unroll
   for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; }
   o.time = time;
+  o.grip_th = grip.th; o.grip_vel = grip.vel;
   o.flags = flags;
   o.bad = bad;
   o.rows_active = rows_active;
+  o.slot_overflow = slot_overflow;
   return o;
 }
 
@@ -605,6 +685,8 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
     ResetOut r = episode_init(p.rng, i, flags);
     rr::store_state(p, i, r.st);
+    p.state[(size_t)S_GRIP * p.N + i] = 0.0;  // mj_resetData: gripper open, at rest
+    p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
     p.flags[i] = r.flags;
     rr::fk(r.st.q, c);
     make_obs(r.st, c, r.flags, obs);
@@ -612,6 +694,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     return;
   }
   rr::State st = rr::load_state(p, i);
+  Grip grip{p.state[(size_t)S_GRIP * p.N + i], p.state[(size_t)(S_GRIP + 1) * p.N + i]};
   const V3 sw = v3(st.target[0], st.target[1], st.target[2]);
   // before_step (robot_push_button.py:143-157); evaluated by both roles (same result)
   const int adim = p.action_type == MJS_ACTION_ABS_EEF ? ACT_DIM_EEF : ACT_DIM_JOINT;
@@ -629,23 +712,25 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < NJ; j++) q1[j] = p.actions[(size_t)i * adim + j];  // servoJ(a[:6]); a[6] drives the (lumped) fingers only
+    for (int j = 0; j < NJ; j++) q1[j] = p.actions[(size_t)i * adim + j];  // servoJ(a[:6])
   }
+  // gripper.move(a[-1]) (robot_push_button.py:147,155): the commanded finger opening -> fingers_actuator ctrl
+  const double grip_ctrl = grip_ctrl_of_opening(p.actions[(size_t)i * adim + (adim - 1)]);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
-  bool bad = false, rows_active = false;
+  bool bad = false, rows_active = false, slot_overflow = false;
   double cs[NJ], sn[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
   rr::fk_cs(cs, sn, c);
   // Which path? Both roles evaluate the same predicates on the same data, so the decisions agree without an exchange.
-  const bool guarded = __any(rows_possible(st.q, st.v, c, sw, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
+  const bool guarded = __any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
   int solo_from = (ROLES == 1) ? 0 : MJS_RR_NSUB;                                    // first substep of the robust path
   if constexpr (ROLES == 2) {
 #pragma unroll 1
     for (int seg = 0; seg < MJS_RR_NSUB / SEGMENT_SUBSTEPS; seg++) {
       if (guarded) {  // wave-uniform: the steady state never enters
         if (seg > 0) rr::fk_cs(cs, sn, c);
-        if (__any(rows_possible(st.q, st.v, c, sw, SEGMENT_SUBSTEPS * MJS_RR_PHYSICS_DT))) {
+        if (__any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, SEGMENT_SUBSTEPS * MJS_RR_PHYSICS_DT))) {
           solo_from = seg * SEGMENT_SUBSTEPS;
           break;
         }
@@ -708,6 +793,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
           for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
         }
         st.time += MJS_RR_PHYSICS_DT;
+        grip_integrate(grip, grip_ctrl);  // both roles, same arithmetic: no exchange
       }
     }
     // no contact was possible on these substeps: the touch sensor read 0 after each of them (Switch.after_substep)
@@ -723,13 +809,16 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     in.flags = flags;
     in.maybe_rows = true;  // the whole wavefront runs the robust path from here: detect contacts for every lane of it
     in.first_substep = solo_from;
+    in.grip_th = grip.th; in.grip_vel = grip.vel; in.grip_ctrl = grip_ctrl;
     SoloOut o = solo_control_step(in);
 #pragma unroll
     for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
     st.time = o.time;
+    grip.th = o.grip_th; grip.vel = o.grip_vel;
     flags = o.flags;
     bad = bad || o.bad;
     rows_active = o.rows_active;
+    slot_overflow = o.slot_overflow;
   }
   const bool solo = solo_from < MJS_RR_NSUB;
   if (role != 0) return;
@@ -746,22 +835,24 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   bool terminate = success;
   if (bad) { reward = 0; discount = 0; terminate = true; }
   if (st.time >= p.time_limit) terminate = true;
-  // ncon after the step (mj_step1 of the last substep): arm-vs-floor + stand-in sphere contacts
+  // ncon after the step (mj_step1 of the last substep): arm-vs-floor + finger-tip sphere contacts
   int ncon = rr::count_floor_contacts(c);
   const bool arm_touches_floor = ncon > 0;  // detected and counted, not solved: reported below
   int ncon_proxy;
   {
     ContactSet con;
-    detect_contacts(proxy_centre(c), sw, con);
+    detect_contacts(c, grip.th, sw, con);
     ncon_proxy = con.n;
     ncon += con.n;
   }
   const bool violated = !solo && (ncon_proxy > 0 || rr::joint_outside_range(st.q));  // a-posteriori check of the row-free path (solo: every lane detects)
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-              (arm_touches_floor ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
+              ((arm_touches_floor || slot_overflow) ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0));
   rr::store_state(p, i, st);
+  p.state[(size_t)S_GRIP * p.N + i] = grip.th;
+  p.state[(size_t)(S_GRIP + 1) * p.N + i] = grip.vel;
   p.flags[i] = newflags;
   write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
   if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
@@ -771,6 +862,8 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     }
     ResetOut r = episode_init(p.rng, i, newflags);
     rr::store_state(p, i, r.st);
+    p.state[(size_t)S_GRIP * p.N + i] = 0.0;
+    p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
     p.flags[i] = r.flags;
     rr::fk(r.st.q, c);
     make_obs(r.st, c, r.flags, obs);

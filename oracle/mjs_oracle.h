@@ -73,6 +73,8 @@ typedef struct {
   /* equality: weld only */
   int eq_body1[OM_MAXEQ], eq_body2[OM_MAXEQ];
   double eq_data[OM_MAXEQ][11], eq_solref[OM_MAXEQ][2], eq_solimp[OM_MAXEQ][5];
+  /* reduced 2F-85 (Button-Push): the two finger-tip sphere geoms, re-placed from the driver angle in every substep (-1 none) */
+  int gr_geom[2];
   /* touch sensor: site index (-1 none) and its cylinder size (radius, half-height) */
   int touch_site;
   double touch_size[2];
@@ -176,6 +178,9 @@ typedef struct {
   /* Switch entity state (entities/props/switch.py:10-16,51-60) */
   int switch_active, switch_pressed, switch_num_pressed;
   double switch_pos[3];
+  /* reduced Robotiq 2F-85 (gripper.py:36-98): driver angle of the two equality-coupled fingers, its
+   * velocity, and the fingers_actuator ctrl that Robotiq2f85.move set in before_step */
+  double gr_theta, gr_vel, gr_ctrl;
   /* Planar-Push: RobotTask.episode_step (base.py:29-32) */
   int episode_step;
   /* Planar-Push: the blocks of this episode (GoogleBlockProp.sample_random_object, google_block.py:55-68) */
@@ -205,6 +210,9 @@ int om_debug_arm_floor_seen(om_env* e);
 void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale);
 void om_debug_get_block_shape(const om_env* e, int* cat, int* color, double* scale);
 void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);
+/* reduced gripper of Button-Push: driver angle and velocity (set: re-places the finger tips, then mj_forward) */
+void om_debug_get_gripper(const om_env* e, double* theta_vel);
+void om_debug_set_gripper(om_env* e, double theta, double vel);
 void om_debug_substeps(om_env* e, int n);
 int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,
                     const double* mat2, double* out);

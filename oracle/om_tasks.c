@@ -50,6 +50,7 @@ static void model_defaults(om_model* m) {
   m->solimp[3] = MJS_SOLIMP_MIDPOINT; m->solimp[4] = MJS_SOLIMP_POWER;
   m->nbody = 1; /* world */
   m->touch_site = -1;
+  m->gr_geom[0] = m->gr_geom[1] = -1;
   m->body_mocapid[0] = -1;
   m->body_quat[0][0] = m->body_iquat[0][0] = 1;
 }
@@ -195,16 +196,55 @@ void om_build_ur5e_alone(om_model* m, int eef_gripper, double dt) {
   om_set_const(m);
 }
 
-/* Button-Push scene (robot_push_button.py:66-108): UR5e + lumped gripper (+ collision stand-in sphere
- * for the closed finger tips) + wrist-camera geoms' mass + static switch (box, button cylinder, touch
+/* ---- reduced Robotiq 2F-85 ------------------------------------------------------------------------
+ * One coordinate: the driver angle theta of the two fingers (the reference model couples them by a joint equality and
+ * closes each four-bar by a connect constraint; here the closure holds by construction). Its ctrl is what
+ * Robotiq2f85.move computes (gripper.py:80-84), its force the menagerie actuator's (MJS_G2F85_ACT_*), integrated like
+ * mj_implicit (fast) integrates a dof with joint damping and an affine actuator. The finger opening follows the
+ * reference's own map (gripper.py:73-75) and places the two finger-tip spheres. The fingers' inertia stays lumped in the
+ * gripper body; their motion does not react on the arm. */
+static double gripper_ctrl_of_opening(double finger_distance) {
+  /* gripper.py:77-84; arcsin argument and ctrl clamped to their ranges (MuJoCo clamps ctrl to ctrlrange) */
+  double a = (1 - finger_distance / MJS_G2F85_OPEN) * sin(MJS_G2F85_MAX_DRIVER);
+  a = a < -1 ? -1 : a > 1 ? 1 : a;
+  double c = asin(a) / MJS_G2F85_MAX_DRIVER * MJS_G2F85_CTRL_MAX;
+  return c < 0 ? 0 : c > MJS_G2F85_CTRL_MAX ? MJS_G2F85_CTRL_MAX : c;
+}
+static double gripper_opening(double theta) { return MJS_G2F85_OPEN * (1 - sin(theta) / sin(MJS_G2F85_MAX_DRIVER)); } /* gripper.py:73-75 */
+static void gripper_place_tips(om_env* e) {
+  const double y = 0.5 * gripper_opening(e->gr_theta) + MJS_G2F85_PROXY_RADIUS;
+  e->m.geom_pos[e->m.gr_geom[0]][1] = y;
+  e->m.geom_pos[e->m.gr_geom[1]][1] = -y;
+}
+static void gripper_integrate(om_env* e) {
+  const double h = e->m.dt, inertia = 2 * MJS_G2F85_DRIVER_ARMATURE, damping = 2 * MJS_G2F85_DRIVER_DAMPING;
+  double F = MJS_G2F85_ACT_GAIN * e->gr_ctrl - MJS_G2F85_ACT_KP * e->gr_theta - MJS_G2F85_ACT_KV * e->gr_vel;
+  int clamped = 0;
+  if (F > MJS_G2F85_ACT_FORCE) { F = MJS_G2F85_ACT_FORCE; clamped = 1; }
+  if (F < -MJS_G2F85_ACT_FORCE) { F = -MJS_G2F85_ACT_FORCE; clamped = 1; }
+  const double f = F - damping * e->gr_vel;
+  e->gr_vel += h * f / (inertia + h * (damping + (clamped ? 0.0 : MJS_G2F85_ACT_KV)));
+  e->gr_theta += h * e->gr_vel;
+}
+/* one Physics.step() of the Button-Push scene: mj_step2 (arm + gripper), finger tips re-placed, mj_step1 */
+static void button_physics_step(om_env* e) {
+  om_step2(&e->m, &e->d);
+  gripper_integrate(e);
+  gripper_place_tips(e);
+  om_step1(&e->m, &e->d);
+}
+
+/* Button-Push scene (robot_push_button.py:66-108): UR5e + lumped gripper (+ the reduced 2F-85's two finger-tip
+ * spheres) + wrist-camera geoms' mass + static switch (box, button cylinder, touch
  * site). The switch body position is a MODEL field rewritten at every reset (Entity.set_pose). */
 static void build_button(om_model* m) {
   build_robot(m, 1);
   const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
   int payload = m->nbody - 1, wrist3 = m->body_parent[payload];
-  /* proxy sphere on the gripper body: tip at the TCP */
+  /* finger-tip spheres on the gripper body (tips at the TCP plane), placed from the driver angle by gripper_place_tips */
   const double ppos[3] = {0, 0, MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS};
-  add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
+  m->gr_geom[0] = add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
+  m->gr_geom[1] = add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
   /* wrist camera body: box + sphere of default density, concentric at MJS_WCAM_POS (mass only) */
   double bx = MJS_CAM_BOX_HALF[0], by = MJS_CAM_BOX_HALF[1], bz = MJS_CAM_BOX_HALF[2], rs = MJS_CAM_SPHERE_RADIUS;
   double mb = MJS_GEOM_DENSITY * 8 * bx * by * bz, ms = MJS_GEOM_DENSITY * 4.0 / 3.0 * 3.14159265358979323846 * rs * rs * rs;
@@ -436,6 +476,8 @@ static void episode_init(om_env* e) {
       for (int j = 0; j < 6; j++) { d->qpos[j] = q[j]; d->qvel[j] = 0; d->ctrl[j] = q[j]; }
     for (int k = 0; k < 3; k++) e->switch_pos[k] = om_rng_uniform(&e->rng, MJS_BP_SWITCH_SPACE_LO[k], MJS_BP_SWITCH_SPACE_HI[k]);
     memcpy(m->body_pos[m->site_body[m->touch_site]], e->switch_pos, sizeof e->switch_pos);
+    e->gr_theta = e->gr_vel = e->gr_ctrl = 0; /* mj_resetData: gripper joints at qpos0 (open), ctrl 0 */
+    gripper_place_tips(e);
     om_forward(m, d);
     /* Switch.initialize_episode (switch.py:62-65) */
     e->switch_num_pressed = 0;
@@ -505,8 +547,8 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     e->traj_t1 = d->time + MJS_RR_CONTROL_DT;
     e->traj_active = 1;
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.action_type == OM_ACTION_ABS_JOINT) {
-    /* robot_push_button.py:151-157: gripper.move(a[6]) only sets the finger actuator's ctrl (no finger
-     * DoF under D-1); servoJ(a[:6]) -> robot.py:227-259 */
+    /* robot_push_button.py:151-157: gripper.move(a[6]) sets the finger actuator's ctrl; servoJ(a[:6]) -> robot.py:227-259 */
+    e->gr_ctrl = gripper_ctrl_of_opening(action[6]);
     memcpy(e->traj_q0, d->qpos, sizeof e->traj_q0);
     memcpy(e->traj_q1, action, sizeof e->traj_q1);
     e->traj_t0 = d->time;
@@ -514,6 +556,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     e->traj_active = 1;
   } else {
     /* robot_reach.py:159-169 / robot_push_button.py:143-149 -> robot.py:218-259 */
+    if (e->cfg.task == OM_TASK_BUTTON_PUSH) e->gr_ctrl = gripper_ctrl_of_opening(action[3]); /* gripper.move(a[3]), :147 */
     double q_now[6], q_ik[6];
     memcpy(q_now, d->qpos, sizeof q_now);
     if (!tcp_pose_to_joints(action, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, q_now, q_ik)) {
@@ -533,7 +576,8 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
       double t = fmin(fmax(d->time, e->traj_t0), e->traj_t1);
       for (int j = 0; j < 6; j++) d->ctrl[j] = e->traj_q0[j] + (e->traj_q1[j] - e->traj_q0[j]) * (t - e->traj_t0) / (e->traj_t1 - e->traj_t0);
     }
-    om_physics_step(m, d);
+    if (e->cfg.task == OM_TASK_BUTTON_PUSH) button_physics_step(e);
+    else om_physics_step(m, d);
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) switch_update(e); /* Switch.after_substep (switch.py:71-72) */
     if (e->cfg.task != OM_TASK_POINTMASS) /* test knob: a floor contact of one of the arm's own collision geoms (ids 1..10) */
       for (int c = 0; c < d->ncon; c++)
@@ -687,6 +731,11 @@ void om_debug_set_state(om_env* e, const double* qpos, const double* qvel) {
   e->traj_active = 0;
   e->reset_pending = 0;
   om_forward(&e->m, &e->d);
+}
+void om_debug_get_gripper(const om_env* e, double* theta_vel) { theta_vel[0] = e->gr_theta; theta_vel[1] = e->gr_vel; }
+void om_debug_set_gripper(om_env* e, double theta, double vel) {
+  e->gr_theta = theta; e->gr_vel = vel;
+  if (e->cfg.task == OM_TASK_BUTTON_PUSH) { gripper_place_tips(e); om_forward(&e->m, &e->d); }
 }
 void om_debug_substeps(om_env* e, int n) {
   for (int s = 0; s < n; s++) om_physics_step(&e->m, &e->d);

@@ -289,6 +289,28 @@ class OracleBatch:
         nv = nq - (nq - 6) // 7 if nq > 6 else nq
         return qp[:, :nq].copy(), qv[:, :nv].copy(), tm
 
+    def get_gripper(self):
+        """Button-Push: (driver angle, driver velocity) of the reduced 2F-85 per env, [N, 2]."""
+        L = lib()
+        L.om_debug_get_gripper.argtypes = [C.c_void_p, C.c_void_p]
+        L.om_debug_get_gripper.restype = None
+        L.om_batch_env.restype = C.c_void_p
+        L.om_batch_env.argtypes = [C.c_void_p, C.c_int]
+        out = np.zeros((self.n, 2))
+        for i in range(self.n):
+            L.om_debug_get_gripper(L.om_batch_env(self._h, i), out[i].ctypes.data)
+        return out
+
+    def set_gripper(self, theta_vel):
+        L = lib()
+        L.om_debug_set_gripper.argtypes = [C.c_void_p, C.c_double, C.c_double]
+        L.om_debug_set_gripper.restype = None
+        L.om_batch_env.restype = C.c_void_p
+        L.om_batch_env.argtypes = [C.c_void_p, C.c_int]
+        tv = np.asarray(theta_vel, dtype=np.float64).reshape(self.n, 2)
+        for i in range(self.n):
+            L.om_debug_set_gripper(L.om_batch_env(self._h, i), float(tv[i, 0]), float(tv[i, 1]))
+
     def set_state(self, qpos, qvel):
         """debug: overwrite qpos [N, nq] / qvel [N, nv] of every env (ctrl = arm joints), then mj_forward"""
         L = lib()

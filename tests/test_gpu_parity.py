@@ -566,6 +566,75 @@ def test_button_push_demonstration_policy(oracle_mod, action_type, disturb):
     assert (n_disturbed > 0) == disturb, n_disturbed
 
 
+def test_button_push_gripper_follows_the_reference_map(oracle_mod):
+    """Reduced 2F-85: the commanded finger opening goes through Robotiq2f85.move's map (gripper.py:77-84) to the
+    fingers_actuator ctrl; the driver angle (state rows 16, 17) follows the actuator and must equal the oracle's at every step;
+    at rest the opening the reference reads back (gripper.py:73-75, get_finger_opening) is the commanded one."""
+    import mujoco_sim_amd as m
+
+    N = 32
+    venv = m.HipVectorEnv("robot_push_button", N, seed=5, autoreset="disabled")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 5, autoreset=2, nthreads=4)
+    venv.reset()
+    ob.reset()
+    rng = np.random.RandomState(2)
+    home = np.array([-np.pi / 2, -np.pi / 2, np.pi / 2, -np.pi / 2, -np.pi / 2, -np.pi / 2])
+    target = rng.uniform(0.0, 0.085, N)
+    for t in range(30):
+        if t == 15:
+            target = rng.uniform(0.0, 0.085, N)  # re-command: opening and closing motions
+        a = np.concatenate([np.tile(home, (N, 1)) + rng.uniform(-0.05, 0.05, (N, 6)), target[:, None]], axis=1)
+        venv.step(torch.from_numpy(a))
+        ob.step(a)
+        g = venv.get_state().cpu().numpy()[16:18].T
+        np.testing.assert_allclose(g, ob.get_gripper(), rtol=0, atol=1e-12, err_msg=f"step {t}")
+        if t in (14, 29):  # 1.5 s after the command: at rest at the commanded opening ...
+            theta, settled = g[:, 0], np.abs(g[:, 1]) < 5e-2
+            # ... unless the force-clamped actuator chatters: at the reference's 5 ms step a move can end in a +-5 N limit
+            # cycle of ~0.006 rad (kv |v| alone exceeds the force range, and a clamped actuator contributes no implicit damping: DESIGN.md D-1b)
+            assert settled.mean() > 0.6, settled.mean()
+            np.testing.assert_allclose(theta[settled], np.arcsin((1 - target[settled] / 0.085) * np.sin(0.8)), rtol=0, atol=2e-3)
+            np.testing.assert_allclose(0.085 * (1 - np.sin(theta[settled]) / np.sin(0.8)), target[settled], rtol=0, atol=2e-4)
+    venv.close()
+
+
+def test_button_push_gripper_action_changes_the_contact_outcome(oracle_mod):
+    """the gripper component of the action is honoured and decides what touches the button. The scripted
+    policy (robot_push_button.py:231-298) descends on the button with the gripper CLOSED (its last action component is 0):
+    the finger tips meet over the button and press it. The same arm motion with the gripper held OPEN (0.085 m) straddles
+    the 40 mm button and the 50 mm switch box: nothing is pressed. Both runs are held to the oracle step by step."""
+    import mujoco_sim_amd as m
+
+    N = 64
+    task = m.RobotPushButtonTask(observation_type="state_observations", action_type="absolute_eef_action")
+    rates = {}
+    for name, opening in (("closed", 0.0), ("open", 0.085)):
+        venv = m.HipVectorEnv("robot_push_button", N, seed=31, autoreset="disabled", action_type="absolute_eef_action")
+        ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 31, autoreset=2, nthreads=8, action_type=1)
+        venv.reset()
+        ob.reset()
+        done, success, touched = np.zeros(N, bool), np.zeros(N, bool), np.zeros(N, bool)
+        for t in range(100):
+            a = task.demonstration_actions(venv).cpu().numpy()
+            a[:, 3] = opening
+            venv.step(torch.from_numpy(a))
+            o = ob.step(a)
+            g = _gpu_result(venv)
+            live = ~done
+            np.testing.assert_allclose(g["obs"][live], o["obs"][live], rtol=0, atol=1e-8, err_msg=f"{name} step {t}")
+            for k in ("step_type", "terminated", "is_success", "ncon"):
+                assert np.array_equal(np.asarray(g[k])[live].astype(int), np.asarray(o[k])[live].astype(int)), (name, k, t)
+            touched |= live & (g["obs"][:, 12] != 0)  # the switch became active
+            success |= live & g["is_success"].astype(bool)
+            done |= g["step_type"] == 2
+            if done.all():
+                break
+        rates[name] = (touched.mean(), success.mean())
+        venv.close()
+    print("button activated / episode solved, gripper closed:", rates["closed"], "open:", rates["open"])
+    assert rates["closed"][0] > 0.5 and rates["open"][0] < 0.1, rates
+
+
 def test_button_push_state_env_id(oracle_mod):
     # single-env gymnasium-style surface: dict keys follow the action type (robot_push_button.py:113-119)
     import mujoco_sim_amd as m
