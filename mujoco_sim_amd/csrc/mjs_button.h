@@ -161,8 +161,20 @@ struct ContactRows {
   double Jc[NACT][3][NJ];  // rows: normal, tangent 1, tangent 2 (already signed: geom2 - geom1)
   double D[NACT], aref[NACT][4];
 };
-__device__ __noinline__ bool constraint_stage(const double* q, const double* v, const double* cs, const double* sn, V3 sw, double grip_th,
-                                              const double (*Mf)[NJ], double* qs, double& touch) {
+// By-value interface (the arguments travel in registers): through pointers every use of M, q, v was a FLAT load from the
+// caller's scratch frame that could not be kept in a register across the stage's own scratch stores.
+struct StageIn { double q[NJ], v[NJ], cs[NJ], sn[NJ], sw[3], grip_th, M[21] /* lower triangle of M + armature */, qs[NJ]; };
+struct StageOut { double qs[NJ], touch; bool overflow; };
+__device__ __noinline__ StageOut constraint_stage(StageIn in) {
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], qs[NJ], Mf[NJ][NJ], touch;
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+    q[i] = in.q[i]; v[i] = in.v[i]; cs[i] = in.cs[i]; sn[i] = in.sn[i]; qs[i] = in.qs[i];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? in.M[i * (i + 1) / 2 + j] : in.M[j * (j + 1) / 2 + i];
+  }
+  const V3 sw = v3(in.sw[0], in.sw[1], in.sw[2]);
+  const double grip_th = in.grip_th;
   const double mu = MJS_GEOM_FRICTION_SLIDE;
   const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
   const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
@@ -443,7 +455,12 @@ __device__ __noinline__ bool constraint_stage(const double* q, const double* v, 
     const bool in_site = !(loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh);
     if (use_c[c] && cr.on[c] && on_switch[c] && in_site) touch += cforce[c][0] + cforce[c][1] + cforce[c][2] + cforce[c][3];
   }
-  return overflow;
+  StageOut out;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) out.qs[j] = qs[j];
+  out.touch = touch;
+  out.overflow = overflow;
+  return out;
 }
 
 // One Physics.step() of a lane: smooth dynamics (generated, Button-Push payload variant), constraint
@@ -476,17 +493,20 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
 #pragma unroll
     for (int c = 0; c < NCS; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
     if (rows) {  // rare: hand copies to the out-of-line constraint stage, nothing of the hot path lives in memory
-      double Mf[NJ][NJ], qs[NJ];
+      StageIn in;
 #pragma unroll
       for (int i = 0; i < NJ; i++) {
+        in.q[i] = q[i]; in.v[i] = v[i]; in.cs[i] = cs[i]; in.sn[i] = sn[i]; in.qs[i] = rhs[i];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) Mf[i][j] = i >= j ? A[i][j] : A[j][i];
-        Mf[i][i] += MJS_UR_ARMATURE;
-        qs[i] = rhs[i];
+        for (int j = 0; j <= i; j++) in.M[i * (i + 1) / 2 + j] = A[i][j] + (i == j ? MJS_UR_ARMATURE : 0.0);
       }
-      slot_overflow = constraint_stage(q, v, cs, sn, sw, grip_th, Mf, qs, touch) || slot_overflow;
+      in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
+      in.grip_th = grip_th;
+      const StageOut out = constraint_stage(in);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) rhs[i] = qs[i];
+      for (int i = 0; i < NJ; i++) rhs[i] = out.qs[i];
+      touch = out.touch;
+      slot_overflow = slot_overflow || out.overflow;
       rows_active = true;
     }
   }
