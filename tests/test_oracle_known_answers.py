@@ -621,3 +621,60 @@ def test_scene_constants_match_reference_source_literals():
         np.testing.assert_allclose(got, pin["numbers"], rtol=0, atol=1e-7, err_msg=where)  # float32 colour literals
         checked += 1
     assert checked == len(lit) >= 40
+
+
+def test_static_equilibrium_closed_form(oracle_mod):
+    """Closed-form pin of gravity compensation, the position servos and the kinematic chain together: a stand-alone UR5e held
+    at q_home by its servos. Bare arm: every arm body has gravcomp 1 (robot.py:312-318), so nothing sags (q == ctrl). With
+    the 0.925 kg gripper lump (not compensated) the servos settle where kp (ctrl - q) = -J_com(q)^T m g, evaluated here
+    independently with numpy from include/mjs_scene_spec.h (no oracle code in the right-hand side)."""
+    import re
+
+    om = oracle_mod
+    spec = (GOLDEN.parents[1] / "include" / "mjs_scene_spec.h").read_text()
+
+    def arr(name, shape):
+        m = re.search(r"\b" + name + r"\b(?:\[[^=]*)?\s*=\s*(\{.*?\}|[^;]*);", spec, re.S)
+        vals = [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S))]
+        return np.array(vals).reshape(shape)
+
+    pos, quat, axis = arr("MJS_UR_BODY_POS", (7, 3)), arr("MJS_UR_BODY_QUAT", (7, 4)), arr("MJS_UR_JNT_AXIS", (6, 3))
+    fpos, fquat, kp = arr("MJS_UR_FLANGE_POS", (3,)), arr("MJS_UR_FLANGE_QUAT", (4,)), arr("MJS_UR_ACT_KP", (6,))
+    mass, ipos, home = arr("MJS_G2F85_MASS", (1,))[0], arr("MJS_G2F85_IPOS", (3,)), arr("MJS_UR_HOME_Q", (6,))
+    grav = arr("MJS_GRAVITY_Z", (1,))[0]
+
+    def q2m(q):
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def rot(ax, ang):  # Rodrigues
+        ax = ax / np.linalg.norm(ax)
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * K @ K
+
+    def gravity_torque(q):
+        R, p = q2m(quat[0]), pos[0].copy()
+        anchors, axes = [], []
+        for b in range(1, 7):
+            p = p + R @ pos[b]
+            R = R @ q2m(quat[b])
+            anchors.append(p.copy())
+            axes.append(R @ axis[b - 1])
+            R = R @ rot(axis[b - 1], q[b - 1])
+        pf, Rf = p + R @ fpos, R @ q2m(fquat)
+        com = pf + Rf @ ipos
+        f = np.array([0.0, 0.0, mass * grav])
+        return np.array([np.dot(np.cross(axes[j], com - anchors[j]), f) for j in range(6)])
+
+    for eef in (om.UR_EEF_NONE, om.UR_EEF_GRIPPER):
+        st, _, _ = om.ur_robot_run(om.ur_robot_state(home), np.zeros(7), om.UR_CMD_NONE, 0.0, 6000, eef=eef, dt=0.002)
+        q, v = st[0:6], st[6:12]
+        assert np.abs(v).max() < 1e-9
+        if eef == om.UR_EEF_NONE:
+            np.testing.assert_allclose(q, home, rtol=0, atol=1e-10)  # gravcomp: the bare arm does not sag
+        else:
+            tau = gravity_torque(q)
+            assert np.abs(tau).max() > 0.5  # the lump does load the joints
+            np.testing.assert_allclose(kp * (home - q), -tau, rtol=0, atol=1e-6)
