@@ -594,7 +594,10 @@ def test_button_push_gripper_follows_the_reference_map(oracle_mod):
             # cycle of ~0.006 rad (kv |v| alone exceeds the force range, and a clamped actuator contributes no implicit damping: DESIGN.md D-1b)
             assert settled.mean() > 0.6, settled.mean()
             np.testing.assert_allclose(theta[settled], np.arcsin((1 - target[settled] / 0.085) * np.sin(0.8)), rtol=0, atol=2e-3)
-            np.testing.assert_allclose(0.085 * (1 - np.sin(theta[settled]) / np.sin(0.8)), target[settled], rtol=0, atol=2e-4)
+            from mujoco_sim_amd.entities.eef.gripper import Robotiq2f85Batch
+
+            opening = Robotiq2f85Batch(venv).get_finger_opening().cpu().numpy()  # gripper.py:67-68 on the batch
+            np.testing.assert_allclose(opening[settled], target[settled], rtol=0, atol=2e-4)
     venv.close()
 
 

@@ -216,3 +216,17 @@ def test_lerobot_recorder_schema_and_round_trip(tmp_path):
                     np.zeros(7, np.float32), 0.0, k == 2, {})
     rec2.save_episode()
     assert rec2.n_recorded_episodes == 1
+
+
+def test_gripper_maps_match_the_reference_formulas():
+    """mujoco_sim/entities/eef/gripper.py:73-84 on batches: opening <-> driver angle are inverse maps, move() spans ctrl 0..255."""
+    import torch
+
+    from mujoco_sim_amd.entities.eef import gripper as g
+
+    d = torch.linspace(0.0, 0.085, 18, dtype=torch.float64)
+    th = g.finger_distance_to_joint_angle(d)
+    assert torch.allclose(g.joint_angle_to_finger_distance(th), d, atol=1e-15)
+    assert abs(float(th[0]) - 0.8) < 1e-15 and abs(float(th[-1])) < 1e-15  # closed: driver at its range end; open: 0
+    np.testing.assert_allclose(g.move_ctrl(d).numpy(), np.arcsin((1 - d.numpy() / 0.085) * np.sin(0.8)) / 0.8 * 255, rtol=0, atol=1e-12)
+    assert float(g.move_ctrl(torch.tensor([-1.0], dtype=torch.float64))) == 255.0 and float(g.move_ctrl(torch.tensor([1.0], dtype=torch.float64))) == 0.0
