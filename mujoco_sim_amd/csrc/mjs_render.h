@@ -630,7 +630,7 @@ __global__ __launch_bounds__(256) void robot_scene_kernel(RenderParams p, const 
 }
 
 
-// ---- rectangle walk: one workgroup per env image (images up to 64x64 pixels, H and W multiples of 8) ---------------------
+// ---- rectangle walk: one workgroup per env image, or per band of rows of a larger one (H and W multiples of 8) ------------
 // The 8x8-tile walk above makes every tile test every primitive whose bounding sphere touches the tile's ray cone. For
 // primitives a few cm from the lens (the wrist camera sits on the flange next to the gripper and the last wrist links) the
 // spheres contain the eye or reach the camera plane and the cone test keeps them for every tile; at 64x64 a tile is also
@@ -796,19 +796,22 @@ MJS_DEV void prim_rect(const RenderParams& p, const float* pr, F3 eye, const flo
 }
 
 template <bool FIXED>  // FIXED: the task's scene camera with its ray / floor table (Background); otherwise p.env_cams
-__global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams p, const float* prims, Background bg) {
+__global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams p, const float* prims, Background bg, int band_rows) {
   __shared__ float lds_prims[MAX_NPRIM * PRIM_FLOATS];
   __shared__ int bbox[MAX_NPRIM * 4];
   __shared__ uint32_t image[RECT_WALK_MAX_PIXELS];  // packed colours, written out coalesced at the end
   __shared__ int next_tile;                        // tiles are taken in turn by whichever wavefront is free
-  const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int npix = p.H * p.W;
+  // one workgroup per (env, band of rows): images above 4096 pixels are cut into bands of band_rows rows (a multiple of 8,
+  // band_rows * W <= 4096) that stage their 16 KB of colours each; a band is contiguous in the output
+  const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63;
+  const int band0 = blockIdx.y * band_rows, rows = min(band_rows, p.H - band0);
+  const int npix = rows * p.W, pix0 = band0 * p.W;
   {
     const float* pe = prims + (size_t)env * nprim * PRIM_FLOATS;
     for (int k = tid; k < nprim * PRIM_FLOATS; k += 256) lds_prims[k] = pe[k];
     if (tid == 0) next_tile = 0;
     if (FIXED)  // the env-independent image first; only tiles a primitive touches are revisited
-      for (int k = tid; k < npix; k += 256) image[k] = bg.rgb[k];
+      for (int k = tid; k < npix; k += 256) image[k] = bg.rgb[pix0 + k];
   }
   F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
   const float* right = p.cam.right;
@@ -828,7 +831,7 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
     if (lane == 0) tile = atomicAdd(&next_tile, 1);
     tile = __builtin_amdgcn_readfirstlane(tile);
     if (tile >= ntiles) break;
-    const int row0 = (tile / tiles_x) * 8, col0 = (tile % tiles_x) * 8;
+    const int row0 = band0 + (tile / tiles_x) * 8, col0 = (tile % tiles_x) * 8;
     const int row = row0 + (lane >> 3), col = col0 + (lane & 7);
     bool c = false;
     if (lane < nprim) c = bbox[4 * lane] <= row0 + 7 && bbox[4 * lane + 1] >= row0 && bbox[4 * lane + 2] <= col0 + 7 && bbox[4 * lane + 3] >= col0;
@@ -861,15 +864,15 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
       exact_test(pr, eye, d, s);
     }
     if (FIXED) {
-      if (s.t < t_floor) image[row * p.W + col] = pack_rgb(shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS));  // a primitive won the pixel
+      if (s.t < t_floor) image[(row - band0) * p.W + col] = pack_rgb(shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS));  // a primitive won the pixel
     } else {
       F3 cc = f3(0, 0, 0);
       if (s.t < INFINITY) cc = shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS);
-      image[row * p.W + col] = pack_rgb(cc);
+      image[(row - band0) * p.W + col] = pack_rgb(cc);
     }
   }
   __syncthreads();
-  uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + (size_t)env * npix * 3);
+  uint32_t* o32 = reinterpret_cast<uint32_t*>(p.out + ((size_t)env * p.H * p.W + pix0) * 3);  // pix0 * 3 bytes: a multiple of 4 (W % 8 == 0)
   for (int q = tid; q < (npix >> 2); q += 256) {
     const uint32_t a = image[4 * q], b = image[4 * q + 1], c = image[4 * q + 2], d = image[4 * q + 3];
     o32[3 * q + 0] = a | (b << 24);

@@ -422,11 +422,14 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
   dim3 grid((unsigned)((height * width + 255) / 256), (unsigned)p.N);
   const int tiles = ((height + 7) / 8) * ((width + 7) / 8);  // robot scenes: one wavefront per 8x8 tile
   dim3 tile_grid((unsigned)((tiles + 3) / 4), (unsigned)p.N);
-  // robot scenes up to 64x64 pixels: the rectangle walk (one workgroup per env image, per-primitive pixel rectangles,
-  // colours staged in 16 KB of LDS); the fixed scene cameras add the table of env-independent rays and floor colours,
-  // computed once per size. Larger images keep the 8x8-tile walk. Ladder: profiles/r02_g_render_ladder.txt.
-  const bool rect_walk = height * width <= rend::RECT_WALK_MAX_PIXELS && height % 8 == 0 && width % 8 == 0 &&
-                      h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
+  // robot scenes: the rectangle walk (per-primitive pixel rectangles, colours staged in 16 KB of LDS) with one workgroup per
+  // env image, or per band of rows when the image has more than 4096 pixels; the fixed scene cameras add the table of
+  // env-independent rays and floor colours, computed once per size. Sizes that are not multiples of 8 (and kernel_variant 1)
+  // keep the 8x8-tile walk. Ladder: profiles/r02_g_render_ladder.txt.
+  int band_rows = height;
+  if (height * width > rend::RECT_WALK_MAX_PIXELS) band_rows = (rend::RECT_WALK_MAX_PIXELS / width) & ~7;
+  const bool rect_walk = height % 8 == 0 && width % 8 == 0 && band_rows >= 8 && h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
+  const unsigned nbands = rect_walk ? (unsigned)((height + band_rows - 1) / band_rows) : 1u;
   if (rect_walk && !wrist && (h->bg_H != height || h->bg_W != width)) {  // the scene camera of a handle never moves: keyed by size only
     if (h->bg_ray) (void)hipFree(h->bg_ray);
     if (h->bg_rgb) (void)hipFree(h->bg_rgb);
@@ -439,8 +442,9 @@ int mjs_render(mjs_handle* h, int32_t camera, int32_t height, int32_t width, uin
     h->bg_H = height; h->bg_W = width;
   }
   auto robot_scene = [&]() {
-    if (rect_walk && p.env_cams) rend::robot_scene_rect_walk_kernel<false><<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{nullptr, nullptr});
-    else if (rect_walk) rend::robot_scene_rect_walk_kernel<true><<<(unsigned)p.N, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb});
+    const dim3 rw_grid((unsigned)p.N, nbands);
+    if (rect_walk && p.env_cams) rend::robot_scene_rect_walk_kernel<false><<<rw_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{nullptr, nullptr}, band_rows);
+    else if (rect_walk) rend::robot_scene_rect_walk_kernel<true><<<rw_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims, rend::Background{h->bg_ray, h->bg_rgb}, band_rows);
     else rend::robot_scene_kernel<<<tile_grid, 256, 0, (hipStream_t)stream>>>(p, h->prims);
   };
   const bool fresh = h->prims_valid && h->prims_stream == stream;  // same state, same stream: the list is still good

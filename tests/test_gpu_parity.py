@@ -1292,7 +1292,7 @@ def test_planar_push_camera_matches_oracle(oracle_mod, shape):
 
 @pytest.mark.parametrize("task", ["robot_reach", "robot_push_button", "robot_planar_push"])
 def test_scene_camera_kernels_agree_byte_for_byte(task):
-    """The rectangle-walk render kernels (default for images up to 64x64: per-primitive pixel rectangles, the scene cameras'
+    """The rectangle-walk render kernels (default for image sizes that are multiples of 8: per-primitive pixel rectangles, the scene cameras'
     env-independent ray / floor table) only reorganise WHICH exact ray tests run; their images must equal the 8x8-tile walk's (kernel_variant 1) byte for byte."""
     import mujoco_sim_amd as m
 
@@ -1304,7 +1304,7 @@ def test_scene_camera_kernels_agree_byte_for_byte(task):
     rng = np.random.RandomState(5)
     cams = (0, 1) if task == "robot_push_button" else (0,)  # 1 = the wrist camera (per-env pose, the gripper next to the lens)
     for rnd in range(4):  # arms in varied poses: the culling rules see primitives near, behind and across the camera plane
-        for hh, ww in ((32, 32), (64, 64), (48, 64), (40, 24)):  # square and non-square, within the rectangle walk's 4096-pixel limit
+        for hh, ww in ((32, 32), (64, 64), (48, 64), (40, 24), (96, 96), (72, 128)):  # square and non-square; one workgroup per image, and bands of rows above 4096 pixels (96x96 = the registered visual env's size)
             for cam in cams:
                 ia, ib = a.render(hh, ww, camera=cam).cpu().numpy(), b.render(hh, ww, camera=cam).cpu().numpy()
                 assert np.array_equal(ia, ib), (task, rnd, cam, hh, ww, int((ia != ib).sum()))

@@ -20,7 +20,7 @@ for task in ("robot_push_button", "robot_reach", "robot_planar_push"):
     lo, hi = np.asarray(a.action_low, dtype=np.float64), np.asarray(a.action_high, dtype=np.float64)
     for rnd in range(12):
         for cam in cams:
-            for hh, ww in ((64, 64), (32, 48)):
+            for hh, ww in ((64, 64), (32, 48), (96, 96)):
                 ia, ib = a.render(hh, ww, camera=cam), b.render(hh, ww, camera=cam)
                 nd = int((ia != ib).sum().item())
                 tot += nd
