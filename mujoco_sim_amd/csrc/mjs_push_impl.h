@@ -206,19 +206,37 @@ MJS_DEV V3 support(const Geom& g, V3 dir) {
     const int nvx = MJS_HULL_NV[g.cat];
     const double sc = g.s.x;
     const double lsx = loc.x * sc, lsy = loc.y * sc, lsz = loc.z * sc;
-    const int first = COOP ? (int)(threadIdx.x & (LPE - 1)) : 0, stride = COOP ? LPE : 1;
     double best = -1e300;
-    for (int i = first; i < nvx; i += stride) {
-      const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
-      best = pr > best ? pr : best;
-    }
-    if constexpr (COOP) best = group_max(best);
     int idx = 1 << 20;
-    for (int i = first; i < nvx; i += stride) {
-      const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
-      if (pr >= best - MPR_EPS_TIE) { idx = i; break; }
+    if constexpr (COOP) {
+      // the lane's share of the vertices (sub, sub + LPE, ...) is scanned once: the projections stay in registers for the tie
+      // pass (the table is padded to MJS_HULL_MAXV rows: reads past nvx are in bounds and masked)
+      constexpr int MAXJ = (MJS_HULL_MAXV + LPE - 1) / LPE;
+      const int sub = (int)(threadIdx.x & (LPE - 1));
+      double prj[MAXJ];
+#pragma unroll
+      for (int j = 0; j < MAXJ; j++) {
+        const int i = sub + j * LPE;
+        const int ic = i < MJS_HULL_MAXV ? i : MJS_HULL_MAXV - 1;
+        const double pr = lsx * hull_c(g.cat, ic, 0) + lsy * hull_c(g.cat, ic, 1) + lsz * hull_c(g.cat, ic, 2);
+        prj[j] = i < nvx ? pr : -1e300;
+        best = prj[j] > best ? prj[j] : best;
+      }
+      best = group_max(best);
+#pragma unroll
+      for (int j = MAXJ - 1; j >= 0; j--)  // descending: the lowest index of this lane within the tie band survives
+        if (prj[j] >= best - MPR_EPS_TIE) idx = sub + j * LPE;
+      idx = group_min(idx);
+    } else {
+      for (int i = 0; i < nvx; i++) {
+        const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
+        best = pr > best ? pr : best;
+      }
+      for (int i = 0; i < nvx; i++) {
+        const double pr = lsx * hull_c(g.cat, i, 0) + lsy * hull_c(g.cat, i, 1) + lsz * hull_c(g.cat, i, 2);
+        if (pr >= best - MPR_EPS_TIE) { idx = i; break; }
+      }
     }
-    if constexpr (COOP) idx = group_min(idx);
     res = v3(hull_c(g.cat, idx, 0) * sc, hull_c(g.cat, idx, 1) * sc, hull_c(g.cat, idx, 2) * sc);
   } else if (g.box) {
     res = v3(loc.x >= -MPR_EPS_DIR ? g.s.x : -g.s.x, loc.y >= -MPR_EPS_DIR ? g.s.y : -g.s.y, loc.z >= -MPR_EPS_DIR ? g.s.z : -g.s.z);
