@@ -1632,68 +1632,57 @@ MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& 
           }
         }
       }
-      if constexpr (NB > 2) {
-      // one loop over the pairs (a single inlined copy of the MPR); slot k decodes to its two geoms, which are read from LDS
-#pragma unroll 1
-      for (int k = 0; k < NCVX; k++) {
-        int ia, ib;
-        pair_geoms(k, ia, ib);
-        if (ib - 2 >= nb) continue;  // ia < ib: both blocks exist
-        const Geom g1 = get_geom(dl.g[grp][ia]), g2 = get_geom(dl.g[grp][ib]);
-        const PairHit h = convex_pair_group(g1, g2);
-        if ((lane_ & (LPE - 1)) == 0) {
-          double* o = dl.out[grp][k];
-          o[0] = h.hit ? 1.0 : 0.0; o[1] = h.dist; o[2] = h.pos.x; o[3] = h.pos.y; o[4] = h.pos.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
-        }
-      }
-      }
     }
-    if constexpr (NB <= 2) {
-      // 2-slot instance: the pairs of ALL the wavefront's envs that pass the bounding-sphere test form one list and the env
-      // groups take them in turn, whichever env they belong to: an env with a block on the arm needs a full MPR run for
-      // up to 5 pairs in every substep while the other three groups had nothing to do (the launch is as slow as that
-      // wavefront). Lane (env, pair) does the sphere test; every group runs the same MPR code on its own item.
-      constexpr int NIT = NB <= 2 ? EPW * NCVX : 0;  // (not a template: the discarded branch of the 5-slot instance is still checked)
-      static_assert(NIT <= 64, "one lane per (env, pair)");
-      bool want = false;
-      if (lane_ < NIT) {
-        const int e = lane_ / NCVX, k = lane_ % NCVX;
-        int ia, ib;
-        pair_geoms(k, ia, ib);
-        if (dl.live[e] && ib - 2 < nb) {
-          const Geom g1 = get_geom(dl.g[e][ia]), g2 = get_geom(dl.g[e][ib]);
-          const V3 diff = sub_nc(g2.c, g1.c);
-          const double bound = rbound(g1) + rbound(g2);
-          want = !(dot_nc(diff, diff) > bound * bound);
-          if (!want) {
-            double* o = dl.out[e][k];
-            o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0; o[6] = 0.0; o[7] = 1.0;
-          }
-        }
-      }
-      const unsigned long long todo = __ballot(want);
-      const int nitems = __popcll(todo);
+    {
+      // The pairs of ALL the wavefront's envs that pass the bounding-sphere test form lists of up to 64 (one lane per (env,
+      // pair) does the sphere test, a ballot is the list) and the env groups take the listed pairs in turn, whichever env
+      // they belong to: an env with a block on the arm, or with blocks leaning on each other, needs a full MPR run for
+      // several pairs in every substep while the groups of the other envs had nothing to do (the launch is as slow as that
+      // wavefront). Every group runs the same MPR code on its own item.
+      constexpr int NIT = EPW * NCVX, GROUPS = 64 / LPE;
 #pragma unroll 1
-      for (int r = 0; r * EPW < nitems; r++) {  // wave-uniform
-        const int target = r * EPW + grp;
-        int item = -1;
-        {
-          unsigned long long m = todo;
-          for (int c = 0; m; c++) {
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            if (c == target) { item = bit; break; }
-          }
-        }
-        if (item >= 0) {  // group-uniform
-          const int e = item / NCVX, k = item % NCVX;
+      for (int base = 0; base < NIT; base += 64) {
+        const int item_ = base + lane_;
+        bool want = false;
+        if (item_ < NIT) {
+          const int e = item_ / NCVX, k = item_ % NCVX;
           int ia, ib;
           pair_geoms(k, ia, ib);
-          const Geom g1 = get_geom(dl.g[e][ia]), g2 = get_geom(dl.g[e][ib]);
-          const PairHit h = convex_pair_group(g1, g2);
-          if ((lane_ & (LPE - 1)) == 0) {
-            double* o = dl.out[e][k];
-            o[0] = h.hit ? 1.0 : 0.0; o[1] = h.dist; o[2] = h.pos.x; o[3] = h.pos.y; o[4] = h.pos.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
+          if (dl.live[e] && ib - 2 < nb) {
+            const Geom g1 = get_geom(dl.g[e][ia]), g2 = get_geom(dl.g[e][ib]);
+            const V3 diff = sub_nc(g2.c, g1.c);
+            const double bound = rbound(g1) + rbound(g2);
+            want = !(dot_nc(diff, diff) > bound * bound);
+            if (!want) {
+              double* o = dl.out[e][k];
+              o[0] = 0.0; o[1] = 0.0; o[2] = 0.0; o[3] = 0.0; o[4] = 0.0; o[5] = 0.0; o[6] = 0.0; o[7] = 1.0;
+            }
+          }
+        }
+        const unsigned long long todo = __ballot(want);
+        const int nitems = __popcll(todo);
+#pragma unroll 1
+        for (int r = 0; r * GROUPS < nitems; r++) {  // wave-uniform
+          const int target = r * GROUPS + grp;
+          int item = -1;
+          {
+            unsigned long long m = todo;
+            for (int c = 0; m; c++) {
+              const int bit = __ffsll((long long)m) - 1;
+              m &= m - 1;
+              if (c == target) { item = base + bit; break; }
+            }
+          }
+          if (item >= 0) {  // group-uniform
+            const int e = item / NCVX, k = item % NCVX;
+            int ia, ib;
+            pair_geoms(k, ia, ib);
+            const Geom g1 = get_geom(dl.g[e][ia]), g2 = get_geom(dl.g[e][ib]);
+            const PairHit h = convex_pair_group(g1, g2);
+            if ((lane_ & (LPE - 1)) == 0) {
+              double* o = dl.out[e][k];
+              o[0] = h.hit ? 1.0 : 0.0; o[1] = h.dist; o[2] = h.pos.x; o[3] = h.pos.y; o[4] = h.pos.z; o[5] = h.n.x; o[6] = h.n.y; o[7] = h.n.z;
+            }
           }
         }
       }
