@@ -1569,9 +1569,10 @@ MJS_DEV void sincos_small(double x, double* s, double* c) {
 // dynamics, constraint solve, implicitfast for the servo'd arm / plain Euler for the blocks, position integration.
 // `live` = this lane really steps its env; lanes that do not still take part in the cooperative solve of their
 // neighbours (all 64 lanes of the workgroup must call this function together).
-// Substep phase 1 (its own function in the 2-slot instance: the group-parallel MPR is the most register-hungry code of the substep and nothing of
-// it is needed afterwards): kinematics, collision detection by the env groups, the coupled sub-system. Results go to the
-// env's LDS slot.
+// Substep phase 1: kinematics, collision detection by the env groups, the coupled sub-system. In the 2-slot instance it
+// is its own non-inlined function (detect_phase: the group-parallel MPR is the most register-hungry code of the substep and
+// nothing of it is needed afterwards) that hands its results over through the env's LDS slot; the 5-slot instance, which has
+// no LDS left for them, calls it in line and keeps them in registers.
 MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& cvx, bool& arm_in, bool* blk_in) {
   EnvLds& env = env_lds();
   World& s = env.w;
