@@ -431,6 +431,7 @@ struct FloorSlots {
   bool on[4];       // slot k = k-th corner at or below the floor in mjc_PlaneBox order (active when dist < 0)
   double dist[4];
   V3 r[4];          // contact point - body origin
+  int n;            // slots found (detected contacts, dist <= 0): what mj_collision counts
 };
 #pragma clang fp contract(off)
 MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
@@ -453,6 +454,7 @@ MJS_DEV FloorSlots floor_slots(const Geom& g, V3 origin) {
       if (hit && rank == k) { fs.on[k] = dist < 0.0; fs.dist[k] = dist; fs.r[k] = r; }
     rank += hit ? 1 : 0;
   }
+  fs.n = rank;
   return fs;
 }
 // the same slots computed by all lanes of an env group together (identical arguments, identical result in every lane): the
@@ -466,6 +468,7 @@ MJS_DEV FloorSlots floor_slots_group(const Geom& g, V3 origin) {
   for (int k = 0; k < 4; k++) { fs.on[k] = false; fs.dist[k] = 0; fs.r[k] = v3(0, 0, 0); }
   const int ncand = floor_candidates(g), sub = (int)(threadIdx.x & (LPE - 1));
   constexpr int NONE = 1 << 20;
+  fs.n = 0;
   unsigned long long mine = 0;  // bit j: this lane's j-th candidate (index sub + j * LPE) is at or below the floor
   for (int j = 0, i = sub; i < ncand; j++, i += LPE) {
     const V3 lc = floor_candidate(g, i);
@@ -485,6 +488,7 @@ MJS_DEV FloorSlots floor_slots_group(const Geom& g, V3 origin) {
     const double dist = corner.z;
     fs.on[k] = dist < 0.0; fs.dist[k] = dist;
     fs.r[k] = v3(corner.x - origin.x, corner.y - origin.y, (corner.z - dist * 0.5) - origin.z);
+    fs.n = k + 1;
   }
   return fs;
 }
@@ -865,7 +869,7 @@ struct EnvLds {
   double Rb[SPLIT_DETECT ? NB : 1][9];      // block rotations (columns cx, cy, cz)
   double fl[SPLIT_DETECT ? NB : 1][4][5];   // floor slots: on, dist, r[3]
   double cv[SPLIT_DETECT ? NCVX : 1][8];    // convex pairs: hit, dist, pos[3], n[3]
-  int arm_in, blk_in[NB];
+  int arm_in, blk_in[NB], fln[NB];  // fln: floor contacts detected per block
   double Marm[SPLIT_DETECT ? 21 : 1], qacc[SPLIT_DETECT ? NV : 1];  // arm mass matrix (packed), qfrc_smooth -> qacc of the substep
 };
 MJS_DEV FloorSlots env_fs(const EnvLds& e, int b) {
@@ -875,6 +879,7 @@ MJS_DEV FloorSlots env_fs(const EnvLds& e, int b) {
     const double* o = e.fl[b][k];
     f.on[k] = o[0] != 0.0; f.dist[k] = o[1]; f.r[k] = v3(o[2], o[3], o[4]);
   }
+  f.n = e.fln[b];
   return f;
 }
 MJS_DEV ConvexHits env_cvx(const EnvLds& e) {
@@ -914,6 +919,7 @@ struct DetLds {
   double org[EPW][NB][3];          // block body origins
   double out[EPW][NCVX][8];        // hit, dist, pos[3], n[3]
   double fl[EPW][NB][4][5];        // floor slots: on, dist, r[3]
+  int fln[EPW][NB];                // floor slots found per block
   int live[EPW];
 };
 static_assert(sizeof(DetLds) <= sizeof(CoopLds), "the exchange area aliases the cooperative workspace");
@@ -1631,6 +1637,7 @@ MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& 
             double* o = dl.fl[grp][b][k];
             o[0] = f.on[k] ? 1.0 : 0.0; o[1] = f.dist[k]; o[2] = f.r[k].x; o[3] = f.r[k].y; o[4] = f.r[k].z;
           }
+          dl.fln[grp][b] = f.n;
         }
       }
     }
@@ -1703,6 +1710,7 @@ MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& 
         const double* o = dl.fl[lane_][b][k];
         fs[b].on[k] = o[0] != 0.0; fs[b].dist[k] = o[1]; fs[b].r[k] = v3(o[2], o[3], o[4]);
       }
+      fs[b].n = dl.fln[lane_][b];
     }
     auto take = [&](int slot) {
       const double* o = dl.out[lane_][slot];
@@ -1761,6 +1769,7 @@ __device__ __noinline__ void detect_phase(int nb, bool live) {
         o[0] = fs[b].on[k] ? 1.0 : 0.0; o[1] = fs[b].dist[k]; o[2] = fs[b].r[k].x; o[3] = fs[b].r[k].y; o[4] = fs[b].r[k].z;
       }
       env.blk_in[b] = blk_in[b] ? 1 : 0;
+      env.fln[b] = fs[b].n;
     }
 #pragma unroll
     for (int k = 0; k < NCVX; k++) {
@@ -1770,6 +1779,35 @@ __device__ __noinline__ void detect_phase(int nb, bool live) {
     env.arm_in = arm_in ? 1 : 0;
   }
   }
+}
+
+// mj_collision's ncon of the env's CURRENT state (the state after the last substep of a control step), counted from one more
+// run of the group-parallel detection phase. The serial count_contacts below walks the hulls on one lane per env (full MPR
+// runs with 96-vertex scans for an env that is pushing a block: 9 % of the launch); all 64 lanes must call this one.
+__device__ __noinline__ int count_contacts_group(int nb, bool live) {
+  detect_phase(nb, live);
+  int n = 0;
+  if constexpr (SPLIT_DETECT) {
+    if (live) {
+      const EnvLds& env = env_lds();
+      rr::Chain ch;
+      rr::fk_cs(env.cs, env.sn, ch);
+      n = rr::count_floor_contacts(ch);
+      const Geom eg = eef_geom(ch);
+      const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+      if (!(eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x > 0.0)) n += 1;  // mjc_PlaneCylinder's first test (detect_contacts)
+#pragma unroll
+      for (int b = 0; b < NB; b++)
+        if (b < nb) n += env.fln[b] + (env.cv[b][0] != 0.0 ? 1 : 0) + (env.cv[NB + b][0] != 0.0 ? 1 : 0);
+#pragma unroll
+      for (int a = 0; a < NB; a++) {
+#pragma unroll
+        for (int b = a + 1; b < NB; b++)
+          if (b < nb) n += env.cv[pair_slot(a, b)][0] != 0.0 ? 1 : 0;
+      }
+    }
+  }
+  return n;
 }
 
 // The substep is inlined into its two call sites (the control-step loop and the same-step auto-reset's settle loop): as a
@@ -2124,9 +2162,12 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     s = env.w;
     for (int j = 0; j < NJ; j++) { cs[j] = env.cs[j]; sn[j] = env.sn[j]; }
     info = env.info;
+    // ncon of the state just reached (mj_step1 of the last substep): by the env groups where the detection results live in LDS
+    int ncon_now = 0;
+    if constexpr (SPLIT_DETECT) ncon_now = count_contacts_group(nb, valid && (pass == 0 ? (resetting || stepping) : again));
     if (pass == 1) {
       if (again) {
-        const int ncon2 = count_contacts(s, cs, sn, nb);
+        const int ncon2 = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
         if (valid) {
           store_world(p, i, s);
           p.flags[i] = 0;
@@ -2144,7 +2185,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
 #endif
     bad = info.bad;
     if (resetting) {
-      const int ncon = count_contacts(s, cs, sn, nb);
+      const int ncon = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
       if (valid) {
         store_world(p, i, s);
         p.flags[i] = 0;
@@ -2171,7 +2212,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
       terminate = success || s.episode_step >= (double)p.max_episode_steps;
       if (bad) { reward = 0; discount = 0; terminate = true; }
       if (s.time >= p.time_limit) terminate = true;
-      const int ncon = count_contacts(s, cs, sn, nb);
+      const int ncon = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
       const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
                         (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
       const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
