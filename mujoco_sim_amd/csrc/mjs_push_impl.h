@@ -1782,29 +1782,52 @@ __device__ __noinline__ void detect_phase(int nb, bool live) {
 }
 
 // mj_collision's ncon of the env's CURRENT state (the state after the last substep of a control step), counted from one more
-// run of the group-parallel detection phase. The serial count_contacts below walks the hulls on one lane per env (full MPR
-// runs with 96-vertex scans for an env that is pushing a block: 9 % of the launch); all 64 lanes must call this one.
+// run of the group-parallel detection phase. The serial count_contacts below (still used by the reset's rejection sampling)
+// walks the hulls on one lane per env (full MPR runs with 96-vertex scans for an env that is pushing a block: 9 % of the
+// launch); all 64 lanes must call this one.
 __device__ __noinline__ int count_contacts_group(int nb, bool live) {
-  detect_phase(nb, live);
   int n = 0;
+  // floor contacts per block and convex-pair hits of the current state
+  int fln[NB];
+  bool hit[NCVX];
   if constexpr (SPLIT_DETECT) {
-    if (live) {
-      const EnvLds& env = env_lds();
-      rr::Chain ch;
-      rr::fk_cs(env.cs, env.sn, ch);
-      n = rr::count_floor_contacts(ch);
-      const Geom eg = eef_geom(ch);
-      const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
-      if (!(eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x > 0.0)) n += 1;  // mjc_PlaneCylinder's first test (detect_contacts)
+    detect_phase(nb, live);  // results in the env's LDS slot
+    const EnvLds& env = env_lds();
 #pragma unroll
-      for (int b = 0; b < NB; b++)
-        if (b < nb) n += env.fln[b] + (env.cv[b][0] != 0.0 ? 1 : 0) + (env.cv[NB + b][0] != 0.0 ? 1 : 0);
+    for (int b = 0; b < NB; b++) fln[b] = live ? env.fln[b] : 0;
 #pragma unroll
-      for (int a = 0; a < NB; a++) {
+    for (int k = 0; k < NCVX; k++) hit[k] = live && env.cv[k][0] != 0.0;
+  } else {  // the 5-slot instance keeps the detection results in registers: its own copy of the phase
+    bool arm_in = false, blk_in[NB];
+    ConvexHits cvx;
+    FloorSlots fs[NB];
+    M3 Rb[NB];
 #pragma unroll
-        for (int b = a + 1; b < NB; b++)
-          if (b < nb) n += env.cv[pair_slot(a, b)][0] != 0.0 ? 1 : 0;
-      }
+    for (int b = 0; b < NB; b++) { blk_in[b] = false; fs[b].n = 0; }
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) cvx.hit[k] = false;
+    detect_body(nb, live, Rb, fs, cvx, arm_in, blk_in);
+#pragma unroll
+    for (int b = 0; b < NB; b++) fln[b] = live ? fs[b].n : 0;
+#pragma unroll
+    for (int k = 0; k < NCVX; k++) hit[k] = live && cvx.hit[k];
+  }
+  if (live) {
+    const EnvLds& env = env_lds();
+    rr::Chain ch;
+    rr::fk_cs(env.cs, env.sn, ch);
+    n = rr::count_floor_contacts(ch);
+    const Geom eg = eef_geom(ch);
+    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
+    if (!(eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x > 0.0)) n += 1;  // mjc_PlaneCylinder's first test (detect_contacts)
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+      if (b < nb) n += fln[b] + (hit[b] ? 1 : 0) + (hit[NB + b] ? 1 : 0);
+#pragma unroll
+    for (int a = 0; a < NB; a++) {
+#pragma unroll
+      for (int b = a + 1; b < NB; b++)
+        if (b < nb) n += hit[pair_slot(a, b)] ? 1 : 0;
     }
   }
   return n;
@@ -2163,11 +2186,10 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     for (int j = 0; j < NJ; j++) { cs[j] = env.cs[j]; sn[j] = env.sn[j]; }
     info = env.info;
     // ncon of the state just reached (mj_step1 of the last substep): by the env groups where the detection results live in LDS
-    int ncon_now = 0;
-    if constexpr (SPLIT_DETECT) ncon_now = count_contacts_group(nb, valid && (pass == 0 ? (resetting || stepping) : again));
+    const int ncon_now = count_contacts_group(nb, valid && (pass == 0 ? (resetting || stepping) : again));
     if (pass == 1) {
       if (again) {
-        const int ncon2 = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
+        const int ncon2 = ncon_now;
         if (valid) {
           store_world(p, i, s);
           p.flags[i] = 0;
@@ -2185,7 +2207,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
 #endif
     bad = info.bad;
     if (resetting) {
-      const int ncon = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
+      const int ncon = ncon_now;
       if (valid) {
         store_world(p, i, s);
         p.flags[i] = 0;
@@ -2212,7 +2234,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
       terminate = success || s.episode_step >= (double)p.max_episode_steps;
       if (bad) { reward = 0; discount = 0; terminate = true; }
       if (s.time >= p.time_limit) terminate = true;
-      const int ncon = SPLIT_DETECT ? ncon_now : count_contacts(s, cs, sn, nb);
+      const int ncon = ncon_now;
       const int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (info.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
                         (info.unsupported ? MJS_FAULT_UNSUPPORTED_CONTACT : 0);
       const bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
