@@ -163,8 +163,12 @@ struct ContactRows {
 };
 // By-value interface (the arguments travel in registers): through pointers every use of M, q, v was a FLAT load from the
 // caller's scratch frame that could not be kept in a register across the stage's own scratch stores.
-struct StageIn { double q[NJ], v[NJ], cs[NJ], sn[NJ], sw[3], grip_th, M[21] /* lower triangle of M + armature */, qs[NJ]; };
-struct StageOut { double qs[NJ], touch; bool overflow; };
+struct StageIn {
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], sw[3], grip_th, M[21] /* lower triangle of M + armature */, qs[NJ];
+  double warm[NJ];  // qacc_warmstart: the previous substep's solution, when that substep had rows too
+  bool has_warm;
+};
+struct StageOut { double qs[NJ], qacc[NJ], touch; bool overflow; };
 __device__ __noinline__ StageOut constraint_stage(StageIn in) {
   double q[NJ], v[NJ], cs[NJ], sn[NJ], qs[NJ], Mf[NJ][NJ], touch;
 #pragma unroll
@@ -339,6 +343,22 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
   };
   refresh();
   double cost = update();
+  // mj_fwdConstraint's warm start: begin at qacc_warmstart when its cost is lower than qacc_smooth's (a contact that lasts
+  // starts the Newton iteration at the previous substep's solution and usually needs a single iteration)
+  if (__any(in.has_warm)) {
+#pragma unroll
+    for (int i = 0; i < NJ; i++) a[i] = in.has_warm ? in.warm[i] : a_s[i];
+    refresh();
+    const double cost_w = update();
+    const bool keep = in.has_warm && cost_w < cost;
+    if (__any(!keep)) {  // some lane goes back to qacc_smooth (the evaluation state belongs to the chosen start)
+#pragma unroll
+      for (int i = 0; i < NJ; i++) a[i] = keep ? a[i] : a_s[i];
+      refresh();
+      cost = update();
+    } else
+      cost = cost_w;
+  }
   const double scale = 1 / (UR5E_BP_MEANINERTIA * NJ);
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
@@ -457,7 +477,7 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
   }
   StageOut out;
 #pragma unroll
-  for (int j = 0; j < NJ; j++) out.qs[j] = qs[j];
+  for (int j = 0; j < NJ; j++) { out.qs[j] = qs[j]; out.qacc[j] = a[j]; }
   out.touch = touch;
   out.overflow = overflow;
   return out;
@@ -466,7 +486,8 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
 // One Physics.step() of a lane: smooth dynamics (generated, Button-Push payload variant), constraint
 // stage when `maybe_rows`, implicitfast solve. Returns the integrator's acceleration.
 MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, double grip_th,
-                            bool maybe_rows, double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow) {
+                            bool maybe_rows, double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow,
+                            double* warm, bool& has_warm) {
   double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
   ur5e_bp_M_gen(cs, sn, M);
   ur5e_bp_bias_gen(cs, sn, v, bias);
@@ -502,13 +523,17 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
       }
       in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
       in.grip_th = grip_th;
+#pragma unroll
+      for (int i = 0; i < NJ; i++) in.warm[i] = warm[i];
+      in.has_warm = has_warm;
       const StageOut out = constraint_stage(in);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) rhs[i] = out.qs[i];
+      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; warm[i] = out.qacc[i]; }
       touch = out.touch;
       slot_overflow = slot_overflow || out.overflow;
       rows_active = true;
     }
+    has_warm = rows;  // the next substep may start from this solution only if this one had rows
   }
   rr::factor_system(A, clamped, Dinv);
   rr::udu_solve(A, Dinv, rhs);
@@ -603,8 +628,9 @@ __device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_fla
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(o.st.q[j], &sn[j], &cs[j]);
   V3 sw = v3(o.st.target[0], o.st.target[1], o.st.target[2]);
-  bool overflow_ = false;
-  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, 0.0, true, qacc, touch, ncp, rows, overflow_);
+  bool overflow_ = false, has_warm_ = false;
+  double warm_[NJ] = {0, 0, 0, 0, 0, 0};
+  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, 0.0, true, qacc, touch, ncp, rows, overflow_, warm_, has_warm_);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   switch_update(touch, f);                      // with _is_active = False
   o.flags = f;
@@ -646,7 +672,8 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
   const bool maybe_rows = in.maybe_rows;
   Grip grip{in.grip_th, in.grip_vel};
   uint8_t flags = in.flags;
-  bool bad = false, rows_active = false, slot_overflow = false;
+  bool bad = false, rows_active = false, slot_overflow = false, has_warm = false;
+  double warm[NJ] = {0, 0, 0, 0, 0, 0};
   int ncon_proxy = 0;
 #pragma unroll 1
   for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
@@ -654,7 +681,7 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
     double ctrl[NJ], qacc[NJ], touch;
 #pragma unroll
     for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    physics_forces(q, v, ctrl, cs, sn, sw, grip.th, maybe_rows, qacc, touch, ncon_proxy, rows_active, slot_overflow);
+    physics_forces(q, v, ctrl, cs, sn, sw, grip.th, maybe_rows, qacc, touch, ncon_proxy, rows_active, slot_overflow, warm, has_warm);
     grip_integrate(grip, in.grip_ctrl);
     double acc2 = 0, dq2 = 0;
 #pragma unroll
