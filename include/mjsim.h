@@ -52,7 +52,7 @@ enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1, MJS_VARIANT_TWO_ROL
 enum {
   MJS_FAULT_BAD_STATE = 1,            /* NaN / huge qpos, qvel or qacc: dm_control's PhysicsError path (episode ends, reward 0, discount 0) */
   MJS_FAULT_IK_FAILED = 2,            /* servoL found no IK solution (the reference raises ValueError): the env holds its joints */
-  MJS_FAULT_LIMIT_COLDSTART = 4,      /* constraint rows were active (informational: solved cold-started) */
+  MJS_FAULT_LIMIT_COLDSTART = 4,      /* constraint rows were active (informational; the solver starts at qacc_smooth, Button-Push also at the previous substep's solution) */
   MJS_FAULT_UNSUPPORTED_CONTACT = 8,  /* a contact this build detects and counts but does not solve (arm link on the floor) */
   MJS_FAULT_FASTPATH_VIOLATED = 16    /* the row-free fast path's a-posteriori check failed (a joint left its range, or the gripper stand-in
                                          touches something, at the end of a step taken without constraint rows): this env's step is unreliable */
