@@ -88,15 +88,19 @@ class LeRobotDatasetRecorder:
         self._frames = []
 
     # ------------------------------------------------------------------ batched path (HipVectorEnv)
-    def record_batch(self, obs, actions, reward, success, last, seeds=None):
+    def record_batch(self, obs, actions, reward, success, last, seeds=None, active=None):
         """obs: dict of [N, ...] (observation BEFORE the action, as in the reference loop), actions [N, A], reward [N],
-        success [N] bool, last [N] bool (episode ended with this step). Finished episodes are written out."""
+        success [N] bool, last [N] bool (episode ended with this step). Finished episodes are written out. ``active`` [N]
+        bool (optional): envs whose step is recorded (a collector that stops an env after its episode passes the rest)."""
         actions, reward, success, last = (_to_numpy(x) for x in (actions, reward, success, last))
+        active = None if active is None else _to_numpy(active).astype(bool)
         obs = {k: _to_numpy(v) for k, v in obs.items()}
         n = len(reward)
         if self._batch_frames is None:
             self._batch_frames = [[] for _ in range(n)]
         for i in range(n):
+            if active is not None and not active[i]:
+                continue
             fr = self._frame({k: v[i] for k, v in obs.items()}, actions[i], reward[i], success[i], seed=0 if seeds is None else int(seeds[i]),
                              t=len(self._batch_frames[i]))
             self._batch_frames[i].append(fr)

@@ -1503,3 +1503,57 @@ def test_pointmass_demonstration_policy():
         *_, term, trunc, _ = env.step(policy(None))
         ended, n = term or trunc, n + 1
     assert ended
+
+
+def test_lerobot_recorder_on_device_episodes(tmp_path):
+    """scripts/demonstration_collection.py:170-240 in batch form: the scripted Button-Push policy drives a visual HipVectorEnv,
+    every env's first episode is recorded with the reference collector's conventions and read back with pyarrow: one parquet
+    per episode, frames = control steps, the stored observations are the ones BEFORE each action, next.success marks the
+    frame on which the env reported success, images are the rendered uint8 frames."""
+    import json
+
+    import pyarrow.parquet as pq
+
+    import mujoco_sim_amd as m
+    from mujoco_sim_amd.recording import LeRobotDatasetRecorder
+
+    N, R = 8, 16
+    task = m.RobotPushButtonTask(observation_type="visual_observations", action_type="absolute_eef_action", image_resolution=R)
+    venv = m.HipVectorEnv("robot_push_button", N, seed=3, autoreset="disabled", action_type="absolute_eef_action", observation_type="visual_observations",
+                          image_resolution=R)
+    rec = LeRobotDatasetRecorder(venv, tmp_path / "ds", "test/button_push_demo", fps=10, task="push the button")
+    assert "observation.images.Camera_rgb_image" in rec.features and "observation.images.ur5e_Camera_rgb_image" in rec.features
+    obs, _ = venv.reset()
+    first_images = obs["Camera/rgb_image"].cpu().numpy().reshape(N, -1).copy()
+    done = torch.zeros(N, dtype=torch.bool, device="cuda")
+    lengths, solved = np.zeros(N, int), np.zeros(N, bool)
+    for t in range(100):
+        a = task.demonstration_actions(venv)
+        prev = {k: v.clone() for k, v in obs.items()}
+        obs, reward, terminated, truncated, info = venv.step(a)
+        live = ~done
+        last = (terminated | truncated) & live
+        rec.record_batch(prev, a, reward, info["is_success"].bool(), last, seeds=[3 + i for i in range(N)], active=live)
+        lengths += live.cpu().numpy()
+        solved |= (live & info["is_success"].bool()).cpu().numpy()
+        done |= last
+        if bool(done.all()):
+            break
+    rec.finish_recording()
+    assert bool(done.all()) and rec.n_recorded_episodes == N
+    meta = json.loads((tmp_path / "ds" / "meta" / "info.json").read_text())
+    assert meta["total_episodes"] == N and meta["total_frames"] == int(lengths.sum()) and meta["fps"] == 10
+    eps = [json.loads(line) for line in (tmp_path / "ds" / "meta" / "episodes.jsonl").read_text().splitlines()]
+    assert sorted(e["length"] for e in eps) == sorted(lengths.tolist())
+    n_success = 0
+    for e in eps:
+        tab = pq.read_table(tmp_path / "ds" / "data" / "chunk-000" / f"episode_{e['episode_index']:06d}.parquet").to_pandas()
+        assert len(tab) == e["length"] and list(tab["frame_index"]) == list(range(len(tab)))
+        succ = np.array([bool(x[0]) for x in tab["next.success"]])
+        assert succ[:-1].sum() == 0  # success ends the episode: only the last frame can carry it
+        n_success += int(succ[-1])
+        img0 = np.asarray(tab["observation.images.Camera_rgb_image"][0], dtype=np.uint8).ravel()
+        assert img0.std() > 5 and any(np.array_equal(img0, f) for f in first_images)  # frame 0 = that env's reset image
+        assert np.asarray(tab["action"][0]).shape == (4,)
+    assert n_success == int(solved.sum()) and n_success >= N // 2  # the scripted policy solves most episodes
+    venv.close()
