@@ -250,7 +250,10 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   hipError_t e = dev_.err;
   if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) {
     // > 64 KB of dynamic LDS per workgroup is an opt-in (gfx950 has 160 KB per CU): cooperative workspaces + hull tables
-    static_assert(pp5::LDS_BYTES <= 160 * 1024 && pp::LDS_BYTES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
+#ifndef MJS_STAMPS  // the diagnostic build's phase counters live in the env slots: its 5-slot instance does not fit and is not used
+    static_assert(pp5::LDS_BYTES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
+#endif
+    static_assert(pp::LDS_BYTES <= 160 * 1024, "cooperative workspace exceeds the CU's LDS");
     if (h->cfg.n_objects > MJS_PP_FAST_OBJECTS) {
       e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp5::LDS_BYTES);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&pp5::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pp5::LDS_BYTES);
