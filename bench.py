@@ -282,13 +282,13 @@ def main():
         achieved = bytes_per_launch / (kernel_ms * 1e-3) / 1e9
         line = {
             "metric": {"robot_reach": "env-steps/sec at N_envs=4096, Robot-Reach", "point_mass_reach": "env-steps/sec, Pointmass-Reach",
-                       "robot_push_button": "env-steps/sec, Button-Push (state obs)",
+                       "robot_push_button": "env-steps/sec, Button-Push (" + (f"scene + wrist camera {args.visual}x{args.visual}" if cams else "state obs") + ")",
                        "robot_planar_push": f"env-steps/sec, Planar-Push, {args.n_objects} objects (state obs)"}[args.task],
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task}: {n_local} envs per GPU, {substeps} substeps/step, "
-                                   f"state obs, {'joint targets q_home +- U(0.2)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
+                                   f"{'state obs' if not cams else 'visual obs'}, {'joint targets q_home +- U(0.2) + gripper opening U(0, 0.085)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
                                    + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
