@@ -169,8 +169,13 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
   }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
-  else if (h->cfg.kernel_variant == MJS_VARIANT_TWO_ROLES) rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);  // round 1: two role-specialised waves per 64 envs
-  else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);  // an IK wave + two role-specialised dynamics waves per 64 envs
+  // Two shapes of the same step (results equal to rounding): an IK wave + two role-specialised dynamics waves per 64 envs
+  // is the faster one while every workgroup has a CU to itself (the launch is one workgroup's latency: -10 % at 4096 envs);
+  // past 16384 envs per GPU the chip is full and the third, mostly idle wave costs a SIMD: the two-role kernel of round 1
+  // then has twice the throughput (profiles/r02_j_batch_size_scaling.txt: 65536 envs 435 vs 822 M env-steps/s).
+  else if (h->cfg.kernel_variant == MJS_VARIANT_TWO_ROLES || (h->cfg.kernel_variant == MJS_VARIANT_DEFAULT && p.N > 16384))
+    rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
+  else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }
