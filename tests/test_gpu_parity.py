@@ -1557,3 +1557,22 @@ def test_lerobot_recorder_on_device_episodes(tmp_path):
         assert np.asarray(tab["action"][0]).shape == (4,)
     assert n_success == int(solved.sum()) and n_success >= N // 2  # the scripted policy solves most episodes
     venv.close()
+
+
+def test_robot_reach_large_batch_matches_oracle(oracle_mod):
+    """Above 16384 envs per GPU mjs_step launches the two-role Robot-Reach kernel instead of the three-wavefront one (the
+    chip is full: DESIGN.md section 4). Same parity with the oracle on that path."""
+    import mujoco_sim_amd as m
+
+    N, T = 16384 + 192, 4
+    venv = m.HipVectorEnv("robot_reach", N, seed=11)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, N, 11, nthreads=8)
+    acts = _actions("robot_reach", T, N)
+    venv.reset()
+    o = ob.reset()
+    np.testing.assert_allclose(_gpu_result(venv)["obs"], o["obs"], rtol=0, atol=ATOL)
+    for t in range(T):
+        venv.step(torch.from_numpy(acts[t]))
+        o = ob.step(acts[t])
+        _compare(t, _gpu_result(venv), o)
+    venv.close()
