@@ -65,4 +65,4 @@ __device__ inline double rng_uniform(const DevRng& r, int i, RngCursor& c, doubl
   const double span = hi - lo, prod = span * u;
   return lo + prod;
 }
-#pragma clang fp contract(on)
+#pragma clang fp contract(fast)  // back to hipcc's default (-ffp-contract=fast): "on" would stop cross-statement fusion in everything included later

@@ -401,7 +401,7 @@ MJS_DEV int floor_box(const Geom& g, int bb, Contact* out) {
   }
   return cnt;
 }
-#pragma clang fp contract(on)
+#pragma clang fp contract(fast)  // back to hipcc's default (-ffp-contract=fast): "on" would stop cross-statement fusion in everything included later
 
 MJS_DEV Geom eef_geom(const rr::Chain& ch) {  // CylinderEEF: axis = flange z = wrist_3 y, centre at flange z = 0.051
   Geom g;
@@ -492,7 +492,7 @@ MJS_DEV FloorSlots floor_slots_group(const Geom& g, V3 origin) {
   }
   return fs;
 }
-#pragma clang fp contract(on)
+#pragma clang fp contract(fast)  // back to hipcc's default (-ffp-contract=fast): "on" would stop cross-statement fusion in everything included later
 // convex pairs of the scene in MuJoCo's pair order: wrist proxy - block b (NB slots), EEF - block b (NB), block a - block b
 // (a < b, row-major)
 constexpr int NCVX = 2 * NB + (NB * (NB - 1)) / 2;
@@ -529,7 +529,7 @@ MJS_DEV PairHit convex_pair_group(const Geom& g1, const Geom& g2) {
   h.hit = true; h.dist = -depth; h.pos = pp_; h.n = nn;
   return h;
 }
-#pragma clang fp contract(on)
+#pragma clang fp contract(fast)  // back to hipcc's default (-ffp-contract=fast): "on" would stop cross-statement fusion in everything included later
 
 // all contacts of the scene in MuJoCo's pair order (geom ids: floor, arm capsules, EEF cylinder, blocks): floor-block i
 // (<= 4 each), EEF-block i, block-block. Arm capsules vs floor and EEF vs floor are only COUNTED (D-8): `extra`.
