@@ -486,6 +486,41 @@ def model_constants(M, links, body_com_local):
     return np.diag(Ainv), float(np.trace(A) / NJ), tran, rot
 
 
+def link_body_invweights(M, links):
+    """body_invweight0 (translation, rotation) of the arm's OWN link bodies at qpos0 = 0 (mj_setConst: Jacobian at the
+    body's own COM body_ipos; only the joints up to the body move it): index 0 = base (static: 0), b = 1..6 = link b.
+    Contact rows of a collision geom on link b use the translational value (diagApprox of mj_makeImpedance)."""
+    import numpy as np
+
+    env = {f"c[{j}]": 1.0 for j in range(NJ)}
+    env.update({f"s[{j}]": 0.0 for j in range(NJ)})
+    env.update({f"qd[{j}]": 0.0 for j in range(NJ)})
+    flat = evaluate([M[i][j] for i in range(NJ) for j in range(i + 1)], env)
+    A = np.zeros((NJ, NJ))
+    k = 0
+    for i in range(NJ):
+        for j in range(i + 1):
+            A[i, j] = A[j, i] = flat[k]
+            k += 1
+    A += np.eye(NJ) * spec_scalar("MJS_UR_ARMATURE")
+    Ainv = np.linalg.inv(A)
+    R, p = np.eye(3), np.zeros(3)
+    axes, anchors, out = [], [], [(0.0, 0.0)]
+    for b, L in enumerate(links, start=1):
+        p = p + R @ np.array(L["r"])
+        R = R @ np.array(L["C"], dtype=float)
+        axes.append(R @ np.array(L["axis"]))
+        anchors.append(p.copy())
+        P = p + R @ np.array(body_ipos[b])
+        Jt = np.zeros((3, NJ))
+        Jr = np.zeros((3, NJ))
+        for j in range(b):
+            Jt[:, j] = np.cross(axes[j], P - anchors[j])
+            Jr[:, j] = axes[j]
+        out.append((float(np.trace(Jt @ Ainv @ Jt.T) / 3), float(np.trace(Jr @ Ainv @ Jr.T) / 3)))
+    return out
+
+
 def emit_variant(prefix, links, uncomp, body_com_local, what):
     tau, M = build(links, uncomp)
     out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
@@ -495,6 +530,8 @@ def emit_variant(prefix, links, uncomp, body_com_local, what):
     nb, nm = sum(cb.values()), sum(cm.values())
     invw, meaninertia, tran, rot = model_constants(M, links, body_com_local)
     _, _, w3tran, w3rot = model_constants(M, links, body_ipos[NJ])  # the wrist_3 body itself, at its own COM
+    linkw = link_body_invweights(M, links)
+    assert abs(linkw[NJ][0] - w3tran) < 1e-12 and abs(linkw[NJ][1] - w3rot) < 1e-12
     up = prefix.upper()
     text = f"""
 // ---- variant "{prefix}": {what}
@@ -503,6 +540,7 @@ constexpr double {up}_DOF_INVWEIGHT0[6] = {{{", ".join(repr(float(x)) for x in i
 constexpr double {up}_MEANINERTIA = {meaninertia!r};
 constexpr double {up}_EEF_BODY_INVWEIGHT0[2] = {{{tran!r}, {rot!r}}};  // translation, rotation: contact rows of the EEF body
 constexpr double {up}_WRIST3_BODY_INVWEIGHT0[2] = {{{w3tran!r}, {w3rot!r}}};  // contact rows of geoms on the wrist_3 body
+constexpr double {up}_LINK_BODY_INVWEIGHT0[7] = {{{", ".join(repr(t) for t, _ in linkw)}}};  // translation, link bodies 0 (base) .. 6 (wrist_3): contact rows of the arm's collision geoms
 
 MJS_DEV void {prefix}_M_gen(const double* c, const double* s, double* M) {{  // {nm} ops before FMA fusion
 """ + "\n".join(lm) + f"""
