@@ -22,13 +22,16 @@
 extern "C" {
 #endif
 
-#define MJS_ABI_VERSION 1
+/* 2 (round 3): mjs_config starts with struct_size (validated by mjs_create: a caller built against another header is refused
+ * instead of being read past its end); Robot-Reach / Button-Push state blocks grew 6 rows (qacc_warmstart): checkpoints of abi 1
+ * do not fit mjs_set_state any more (mjs_state_dim reports the new widths). */
+#define MJS_ABI_VERSION 2
 
 /* tasks (environments/tasks/*.py) */
 enum {
   MJS_TASK_POINTMASS_REACH = 0, /* tasks/point_reach.py */
   MJS_TASK_ROBOT_REACH = 1,     /* tasks/robot_reach.py */
-  MJS_TASK_PLANAR_PUSH = 2,     /* tasks/robot_planar_push.py (intended semantics; box stand-in blocks, DESIGN D-9) */
+  MJS_TASK_PLANAR_PUSH = 2,     /* tasks/robot_planar_push.py (intended semantics; the reference's mesh blocks by default, DESIGN D-9) */
   MJS_TASK_BUTTON_PUSH = 3      /* tasks/robot_push_button.py */
 };
 /* Button-Push action spaces (robot_push_button.py:35-36,143-157): absolute joints + gripper (7-D, the
@@ -52,10 +55,13 @@ enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1, MJS_VARIANT_TWO_ROL
 enum {
   MJS_FAULT_BAD_STATE = 1,            /* NaN / huge qpos, qvel or qacc: dm_control's PhysicsError path (episode ends, reward 0, discount 0) */
   MJS_FAULT_IK_FAILED = 2,            /* servoL found no IK solution (the reference raises ValueError): the env holds its joints */
-  MJS_FAULT_LIMIT_COLDSTART = 4,      /* constraint rows were active (informational; the solver starts at qacc_smooth, Button-Push also at the previous substep's solution) */
-  MJS_FAULT_UNSUPPORTED_CONTACT = 8,  /* a contact this build detects and counts but does not solve (arm link on the floor) */
-  MJS_FAULT_FASTPATH_VIOLATED = 16    /* the row-free fast path's a-posteriori check failed (a joint left its range, or the gripper stand-in
-                                         touches something, at the end of a step taken without constraint rows): this env's step is unreliable */
+  MJS_FAULT_LIMIT_COLDSTART = 4,      /* constraint rows (joint limits / contacts) were active in some substep (informational; the solver is
+                                         warm-started like mj_fwdConstraint: qacc_warmstart = the previous Physics.step()'s solution) */
+  MJS_FAULT_UNSUPPORTED_CONTACT = 8,  /* a lane had more simultaneously ACTIVE contacts than the constraint stage holds (24 on the robot
+                                         scenes' robust path: arm links on the floor are solved since abi 2); the surplus made no rows */
+  MJS_FAULT_FASTPATH_VIOLATED = 16    /* the row-free fast path's a-posteriori check failed (a joint left its range, or an arm geom / the
+                                         gripper stand-in touches something, at the end of a step taken without constraint rows): this env's
+                                         step is unreliable */
 };
 
 enum {
@@ -70,6 +76,7 @@ enum {
 typedef struct mjs_handle mjs_handle;
 
 typedef struct {
+  uint32_t struct_size;         /* sizeof(mjs_config) of the caller's header: mjs_create refuses any other value */
   int32_t task;                 /* MJS_TASK_* */
   int32_t num_envs;             /* N on this GPU */
   int32_t device;               /* HIP device ordinal */
@@ -123,7 +130,9 @@ int mjs_obs_dim(int task);
 int mjs_action_dim(int task);
 /* action width for a task + MJS_ACTION_* pair (Button-Push: 7 or 4); equals mjs_action_dim otherwise */
 int mjs_action_dim_for(int task, int action_type);
-/* number of float64 per env in mjs_get_state / mjs_set_state */
+/* number of float64 per env in mjs_get_state / mjs_set_state: the task's state rows + 1 (the flag byte as a double, last row).
+ * Robot-Reach: q6, v6, time, target3, qacc_warmstart6; Button-Push: q6, v6, time, switch position3, gripper driver angle and
+ * velocity, qacc_warmstart6. mjs_set_state recomputes the flags that are functions of the configuration. */
 int mjs_state_dim(int task);
 /* the same two widths for a created handle: Planar-Push with n_objects 3..5 uses 5 block slots
  * (obs 5 + 2*5 = 15, state 1 + 17 + 13*5 = 83); the per-task queries above describe the 2-slot layout */

@@ -43,10 +43,15 @@ EXPORTED_SYMBOLS = [
 
 class MjsConfig(C.Structure):
     _fields_ = [
-        ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
+        ("struct_size", C.c_uint32), ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
         ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("button_disturbances", C.c_int32), ("n_objects", C.c_int32), ("max_episode_steps", C.c_int32), ("block_shape", C.c_int32),
     ]
+
+    def __init__(self, *args, **kw):  # struct_size = sizeof(mjs_config) of THIS binding: mjs_create refuses a mismatch (abi 2)
+        super().__init__(*args, **kw)
+        if "struct_size" not in kw:
+            self.struct_size = C.sizeof(MjsConfig)
 
 
 class MjsOutputs(C.Structure):

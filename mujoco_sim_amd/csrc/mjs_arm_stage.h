@@ -25,7 +25,7 @@
 
 namespace rr {
 
-constexpr int ST_MAXC = 16;   // active (penetrating) contacts a lane can carry; more -> MJS_FAULT_UNSUPPORTED_CONTACT
+constexpr int ST_MAXC = 24;   // active (penetrating) contacts a lane can carry (the arm alone has 22 candidates); more -> MJS_FAULT_UNSUPPORTED_CONTACT
 constexpr int ST_SLOT = 18;   // doubles per contact slot: pos3 nrm3 | invw->D, dist->kid, meta | B Jc v (3) | W (3) | Jc search (3)
 constexpr int WS_ROWS = ST_MAXC * ST_SLOT;
 struct Ws {
@@ -60,7 +60,7 @@ MJS_DEV void col_geom_pose(const Chain& c, int g, V3& gp, V3& axis) {
 MJS_DEV double min_floor_clearance(const Chain& c) {
   double m = INFINITY;
 #pragma unroll
-  for (int g = 1; g < MJS_UR_NCOLGEOM; g++) {  // geom 0 (shoulder, 3 mm above the floor at its lowest) turns about the vertical: it never touches
+  for (int g = 2; g < MJS_UR_NCOLGEOM; g++) {  // geoms 0 and 1 never touch the floor, whatever the joints do (see the assertions below)
     const int b = MJS_UR_COL_BODY[g];
     const M3 R = c.R[b];
     const double gz = c.p[b].z + MJS_UR_COL_POS[g][0] * R.cx.z + MJS_UR_COL_POS[g][1] * R.cy.z + MJS_UR_COL_POS[g][2] * R.cz.z;
@@ -69,8 +69,15 @@ MJS_DEV double min_floor_clearance(const Chain& c) {
   }
   return m;
 }
-static_assert(MJS_UR_COL_BODY[0] == 1 && MJS_UR_COL_TYPE[0] == 3 && MJS_UR_BODY_POS[1][2] + MJS_UR_COL_POS[0][2] - MJS_UR_COL_SIZE[0][1] - MJS_UR_COL_SIZE[0][0] > 0,
+// geom 0: capsule on the shoulder link along its vertical joint axis: lowest point 3 mm above the floor, fixed.
+// geom 1: capsule on the upper arm along the shoulder-lift axis (local y, horizontal in every configuration: the only joint
+// before it turns about the vertical), centred on that axis at the shoulder's height: lowest point 0.163 - 0.06 m, fixed.
+static_assert(MJS_UR_COL_BODY[0] == 1 && MJS_UR_COL_TYPE[0] == 3 && MJS_UR_COL_QUAT[0][1] == 0.0 && MJS_UR_COL_POS[0][0] == 0.0 && MJS_UR_COL_POS[0][1] == 0.0 &&
+                  MJS_UR_BODY_POS[1][2] + MJS_UR_COL_POS[0][2] - MJS_UR_COL_SIZE[0][1] - MJS_UR_COL_SIZE[0][0] > 0,
               "the shoulder capsule is assumed to clear the floor in every configuration");
+static_assert(MJS_UR_COL_BODY[1] == 2 && MJS_UR_COL_TYPE[1] == 3 && MJS_UR_COL_QUAT[1][1] != 0.0 && MJS_UR_COL_POS[1][0] == 0.0 && MJS_UR_COL_POS[1][2] == 0.0 &&
+                  MJS_UR_BODY_POS[2][0] == 0.0 && MJS_UR_BODY_POS[2][2] == 0.0 && MJS_UR_BODY_POS[1][2] - MJS_UR_COL_SIZE[1][0] > 0,
+              "the upper arm's shoulder-side capsule is assumed to lie on the (horizontal) shoulder-lift axis at the shoulder's height");
 
 // every DETECTED arm-floor contact (dist <= 0, what mj_collision lists) in MuJoCo's pair order: emit(body, pos, dist).
 // Same arithmetic as count_floor_contacts (mjc_PlaneCapsule: one contact per end sphere; mjc_PlaneCylinder: up to 4).

@@ -18,23 +18,17 @@
 #pragma once
 #include "mjs_kernel_common.h"
 #include "mjs_reach.h"
+#include "mjs_push.h"  // the convex-pair machinery (MPR) for the one convex pair of this scene: wrist cylinder - switch box
 
 namespace bp {
 
 using rr::NJ;
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16, STATE_DIM = 18;  // S_GRIP: driver angle, velocity of the reduced 2F-85
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16, HOT_STATE_DIM = 18;  // S_GRIP: driver angle, velocity of the reduced 2F-85
+constexpr int S_WARM = 18, STATE_DIM = 24;  // rows 18-23: qacc_warmstart, robust path only (see rr::S_WARM)
 constexpr int OBS_DIM = 13, ACT_DIM_JOINT = 7, ACT_DIM_EEF = 4;
 enum { FLAG_SWITCH_ACTIVE = 4, FLAG_SWITCH_PRESSED = 8 };
 
-// mju_makeFrame: two tangents for a unit normal
-MJS_DEV void make_frame(V3 n, V3& t1, V3& t2) {
-  V3 y = (n.y > -0.5 && n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
-  double dp = dot(n, y);
-  y = madd(y, -dp, n);
-  double len = sqrt(dot(y, y));
-  t1 = (1.0 / len) * y;
-  t2 = cross(n, t1);
-}
+using rr::make_frame;
 
 constexpr int NCS = 6;  // contact slots: finger tip t (0: +y, 1: -y of the gripper frame) x (floor, switch box, button cylinder) = 3 t + k
 struct ContactSet {
@@ -142,6 +136,33 @@ MJS_DEV void detect_contacts(const rr::Chain& ch, double th, V3 sw, ContactSet& 
   cs.n = 0;
   detect_tip(madd(mid, -off, ch.R[6].cz), sw, cs, 0);
   detect_tip(madd(mid, off, ch.R[6].cz), sw, cs, 3);
+}
+
+// The arm's last collision geom is a CYLINDER (MJS_UR_COL_* index 9, on wrist_3) and the switch's base a BOX: the one
+// convex-convex pair MuJoCo's collision table evaluates between the arm and the switch besides the finger tips (the capsule
+// pairs are not evaluated). Own MPR, shared with the Planar-Push kernel (one contact: normal cylinder -> box,
+// depth = portal distance), behind the same bounding-sphere filter as the oracle's collide_convex. With joint actions the
+// tool is not top-down and the wrist can reach the switch while the finger tips are 0.19 m away.
+struct WristBox {
+  bool hit;
+  double dist;
+  V3 pos, nrm;
+};
+MJS_DEV WristBox detect_wrist_box(const rr::Chain& ch, V3 sw) {
+  const pp::Geom cyl = pp::wrist3_proxy_geom(ch);
+  pp::Geom box;
+  box.c = v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF);
+  box.R = M3{v3(1, 0, 0), v3(0, 1, 0), v3(0, 0, 1)};
+  box.s = v3(MJS_SW_BOX_HALF, MJS_SW_BOX_HALF, MJS_SW_BOX_HALF);
+  box.box = true;
+  box.cat = -1;
+  pp::Contact c;
+  WristBox w;
+  w.hit = pp::collide_convex(cyl, box, 1, 0, 0.0, c);
+  w.dist = w.hit ? c.dist : 0.0;
+  w.pos = w.hit ? c.pos : v3(0, 0, 0);
+  w.nrm = w.hit ? c.n : v3(0, 0, 1);
+  return w;
 }
 
 // Constraint stage of one physics step for a lane that has rows: joint limits + finger-tip sphere contacts.
@@ -350,7 +371,7 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
     for (int i = 0; i < NJ; i++) a[i] = in.has_warm ? in.warm[i] : a_s[i];
     refresh();
     const double cost_w = update();
-    const bool keep = in.has_warm && cost_w < cost;
+    const bool keep = in.has_warm && !(cost < cost_w);  // ties keep the warm start, as the oracle's trial loop does
     if (__any(!keep)) {  // some lane goes back to qacc_smooth (the evaluation state belongs to the chosen start)
 #pragma unroll
       for (int i = 0; i < NJ; i++) a[i] = keep ? a[i] : a_s[i];
@@ -483,11 +504,51 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
   return out;
 }
 
-// One Physics.step() of a lane: smooth dynamics (generated, Button-Push payload variant), constraint
-// stage when `maybe_rows`, implicitfast solve. Returns the integrator's acceleration.
+// The scene as the general constraint stage (mjs_arm_stage.h) sees it: the arm's own geoms against the floor come from the
+// stage itself; this adds the two finger-tip spheres' contacts (body = the gripper lump on wrist_3: all six joints move it)
+// in MuJoCo's pair order (geom ids: floor, arm, tip +y, tip -y, switch box, button): floor - tip 0, floor - tip 1,
+// wrist cylinder - box (detected by the caller: one MPR run per substep), tip 0 - box, tip 0 - button, tip 1 - box,
+// tip 1 - button; and the touch sensor's site test.
+struct SceneButton {
+  struct Extra { double sw[3], grip_th; bool wb_hit; double wb_dist, wb_pos[3], wb_nrm[3]; };
+  static constexpr double MEANINERTIA = UR5E_BP_MEANINERTIA;
+  MJS_DEV static double dof_invweight(int j) { return UR5E_BP_DOF_INVWEIGHT0[j]; }
+  MJS_DEV static double link_invweight(int b) { return UR5E_BP_LINK_BODY_INVWEIGHT0[b]; }
+  template <class E>
+  MJS_DEV static void extra_contacts(const rr::Chain& ch, Extra ex, E emit) {
+    ContactSet all;
+    detect_contacts(ch, ex.grip_th, v3(ex.sw[0], ex.sw[1], ex.sw[2]), all);
+    constexpr int order[NCS] = {0, 3, 1, 2, 4, 5};
+#pragma unroll
+    for (int o = 0; o < NCS; o++) {
+      const int k = order[o];
+      if (o == 2 && ex.wb_hit)
+        emit(NJ, v3(ex.wb_pos[0], ex.wb_pos[1], ex.wb_pos[2]), v3(ex.wb_nrm[0], ex.wb_nrm[1], ex.wb_nrm[2]), -1.0, ex.wb_dist, UR5E_BP_LINK_BODY_INVWEIGHT0[6], true);
+      if (all.hit[k]) emit(NJ, all.pos[k], all.nrm[k], all.sgn[k], all.dist[k], UR5E_BP_EEF_BODY_INVWEIGHT0[0], all.on_switch[k]);
+    }
+  }
+  MJS_DEV static bool in_touch_site(Extra ex, V3 pos) {
+    const double sr = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE, sh = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
+    const V3 loc = pos - v3(ex.sw[0], ex.sw[1], ex.sw[2] + MJS_SW_BUTTON_Z);
+    return !(loc.x * loc.x + loc.y * loc.y > sr * sr || fabs(loc.z) > sh);
+  }
+};
+
+// mj_fwdConstraint's warm start across Physics.step() calls: qacc_warmstart = the previous step's SOLVER acceleration, i.e.
+// the stage's result, or (M + armature)^-1 qfrc_smooth of a step without rows — kept as (pM, pqs) and evaluated lazily, only
+// when the next step turns out to have rows (rr::solo_control_step does the same).
+struct WarmState {
+  double warm[NJ], pM[21], pqs[NJ];
+  bool has_warm, lazy;
+};
+
+// One Physics.step() of a lane on the robust path: smooth dynamics (generated, Button-Push payload variant), detection of
+// every row this scene can have (joint ranges, the arm's geoms on the floor, the finger tips on floor / switch box / button),
+// the constraint stage for the lanes that have one — the static-slot stage above while only limits and tip contacts are
+// active in the wavefront, the general stage (rr::gen_stage: any number of arm-floor contacts) as soon as a lane has a link
+// in the floor —, then the implicitfast solve. Returns the integrator's acceleration.
 MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, double grip_th,
-                            bool maybe_rows, double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow,
-                            double* warm, bool& has_warm) {
+                            double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow, WarmState& w, rr::Ws ws) {
   double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
   ur5e_bp_M_gen(cs, sn, M);
   ur5e_bp_bias_gen(cs, sn, v, bias);
@@ -495,45 +556,62 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   for (int i = 0; i < NJ; i++) {
 #pragma unroll
     for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
+    M[i * (i + 1) / 2 + i] += MJS_UR_ARMATURE;
   }
   const int clamped = rr::actuator_forces(q, v, ctrl, fact);
 #pragma unroll
   for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
   touch = 0;
-  ncon_proxy = 0;
-  if (maybe_rows) {
-    // cheap in-line detection: any joint beyond its range, any active contact of a finger-tip sphere?
-    bool rows = false;
+  // cheap in-line detection: any joint beyond its range, an arm geom in the floor, an active contact of a finger-tip sphere?
+  bool rows = rr::joint_outside_range(q);
+  rr::Chain ch;
+  rr::fk_cs(cs, sn, ch);
+  const WristBox wb = detect_wrist_box(ch, sw);
+  const bool arm = !(rr::min_floor_clearance(ch) >= 0.0) || (wb.hit && wb.dist < 0.0);  // rows only the general stage knows
+  ContactSet con;
+  detect_contacts(ch, grip_th, sw, con);
+  ncon_proxy = con.n + (wb.hit ? 1 : 0);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) rows = rows || (q[j] < MJS_UR_JNT_RANGE[j][0]) || (q[j] > MJS_UR_JNT_RANGE[j][1]);
-    rr::Chain ch;
-    rr::fk_cs(cs, sn, ch);
-    ContactSet con;
-    detect_contacts(ch, grip_th, sw, con);
-    ncon_proxy = con.n;
+  for (int c = 0; c < NCS; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
+  rows = rows || arm;
+  if (rows) {  // rare: hand copies to an out-of-line constraint stage, nothing of the hot path lives in memory
+    if (w.lazy) { rr::smooth_acceleration(w.pM, w.pqs, w.warm); w.has_warm = true; w.lazy = false; }
+    if (__any(arm)) {
+      rr::GenStageIn gi;
 #pragma unroll
-    for (int c = 0; c < NCS; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
-    if (rows) {  // rare: hand copies to the out-of-line constraint stage, nothing of the hot path lives in memory
+      for (int i = 0; i < NJ; i++) { gi.q[i] = q[i]; gi.v[i] = v[i]; gi.cs[i] = cs[i]; gi.sn[i] = sn[i]; gi.qs[i] = rhs[i]; gi.warm[i] = w.warm[i]; }
+#pragma unroll
+      for (int k = 0; k < 21; k++) gi.M[k] = M[k];
+      gi.has_warm = w.has_warm;
+      const rr::GenStageOut go = rr::gen_stage<SceneButton>(
+          gi, SceneButton::Extra{{sw.x, sw.y, sw.z}, grip_th, wb.hit, wb.dist, {wb.pos.x, wb.pos.y, wb.pos.z}, {wb.nrm.x, wb.nrm.y, wb.nrm.z}}, ws);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) { rhs[i] = go.qs[i]; w.warm[i] = go.qacc[i]; }
+      touch = go.touch;
+      slot_overflow = slot_overflow || go.overflow;
+    } else {
       StageIn in;
 #pragma unroll
-      for (int i = 0; i < NJ; i++) {
-        in.q[i] = q[i]; in.v[i] = v[i]; in.cs[i] = cs[i]; in.sn[i] = sn[i]; in.qs[i] = rhs[i];
+      for (int i = 0; i < NJ; i++) { in.q[i] = q[i]; in.v[i] = v[i]; in.cs[i] = cs[i]; in.sn[i] = sn[i]; in.qs[i] = rhs[i]; in.warm[i] = w.warm[i]; }
 #pragma unroll
-        for (int j = 0; j <= i; j++) in.M[i * (i + 1) / 2 + j] = A[i][j] + (i == j ? MJS_UR_ARMATURE : 0.0);
-      }
+      for (int k = 0; k < 21; k++) in.M[k] = M[k];
       in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
       in.grip_th = grip_th;
-#pragma unroll
-      for (int i = 0; i < NJ; i++) in.warm[i] = warm[i];
-      in.has_warm = has_warm;
+      in.has_warm = w.has_warm;
       const StageOut out = constraint_stage(in);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; warm[i] = out.qacc[i]; }
+      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; w.warm[i] = out.qacc[i]; }
       touch = out.touch;
       slot_overflow = slot_overflow || out.overflow;
-      rows_active = true;
     }
-    has_warm = rows;  // the next substep may start from this solution only if this one had rows
+    w.has_warm = true;
+    rows_active = true;
+  } else {
+#pragma unroll
+    for (int k = 0; k < 21; k++) w.pM[k] = M[k];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) w.pqs[j] = rhs[j];
+    w.lazy = true;
   }
   rr::factor_system(A, clamped, Dinv);
   rr::udu_solve(A, Dinv, rhs);
@@ -579,7 +657,17 @@ MJS_DEV bool rows_possible(const double* q, const double* v, const rr::Chain& ch
     const V3 d = c - v3(sw.x, sw.y, sw.z + 0.035);
     close = close || c.z < 0.03 + travel || dot(d, d) < reach * reach;
   }
-  return near || close;
+  // the wrist cylinder against the switch box (bounding spheres 0.045 + 0.044 m): the cylinder sits 0.19 m up the tool axis
+  // from the finger tips and is carried round them by the arm's rotation
+  {
+    const V3 wc = madd(ch.p[6], MJS_UR_COL_POS[MJS_UR_NCOLGEOM - 1][1], ch.R[6].cy);
+    const V3 d = wc - v3(sw.x, sw.y, sw.z + MJS_SW_BOX_HALF);
+    const double wreach = 0.09 + 12.0 * h * h + h * sqrt(dot(vel, vel)) + 0.2 * spin * h;
+    close = close || dot(d, d) < wreach * wreach;
+  }
+  // the arm's own collision geoms and the floor: the configuration must be clear by rr::CLEAR_MARGIN now (what the arm may do
+  // during the step is bounded per control step by the kernel: servo target clear as well, short joint-space travel)
+  return near || close || !(rr::min_floor_clearance(ch) >= rr::CLEAR_MARGIN);
 }
 
 // Switch._update_activation (switch.py:51-60)
@@ -608,7 +696,7 @@ struct ResetOut {
   uint8_t flags;
   int ncon;
 };  // the gripper of a fresh episode: driver angle 0 (open), at rest (mj_resetData)
-__device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_flags) {
+__device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_flags, rr::Ws ws) {
   ResetOut o;
   RngCursor c = rng_open(rng, i);
   double rp[3], q[NJ], zeros[NJ] = {0, 0, 0, 0, 0, 0};
@@ -628,12 +716,17 @@ __device__ __noinline__ ResetOut episode_init(DevRng rng, int i, uint8_t old_fla
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(o.st.q[j], &sn[j], &cs[j]);
   V3 sw = v3(o.st.target[0], o.st.target[1], o.st.target[2]);
-  bool overflow_ = false, has_warm_ = false;
-  double warm_[NJ] = {0, 0, 0, 0, 0, 0};
-  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, 0.0, true, qacc, touch, ncp, rows, overflow_, warm_, has_warm_);
+  bool overflow_ = false;
+  WarmState w_;  // mj_resetData: qacc_warmstart = 0
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { w_.warm[j] = 0; w_.pqs[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 21; k++) w_.pM[k] = 0;
+  w_.has_warm = true; w_.lazy = false;
+  physics_forces(o.st.q, o.st.v, o.st.q, cs, sn, sw, 0.0, qacc, touch, ncp, rows, overflow_, w_, ws);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   switch_update(touch, f);                      // with _is_active = False
-  o.flags = f;
+  o.flags = (uint8_t)(f | FLAG_WARM_VALID);     // mj_forward does not advance qacc_warmstart: the zeros of mj_resetData start the first step
   rr::Chain ch;
   rr::fk_cs(cs, sn, ch);
   o.ncon = rr::count_floor_contacts(ch) + ncp;
@@ -653,27 +746,32 @@ __device__ __noinline__ uint8_t disturb(DevRng rng, int i, uint8_t flags) {
 struct SoloIn {
   double q[NJ], v[NJ], q0[NJ], q1[NJ], cs[NJ], sn[NJ], time, t0, t1, sw[3];
   uint8_t flags;
-  bool maybe_rows;
   int first_substep;  // the substeps before it were taken on the row-free path
   double grip_th, grip_vel, grip_ctrl;
+  double warm[NJ];  // the state's qacc_warmstart rows (first_substep == 0 only)
+  bool has_warm;
 };
 struct SoloOut {
-  double q[NJ], v[NJ], cs[NJ], sn[NJ], time, grip_th, grip_vel;
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], time, grip_th, grip_vel, warm[NJ];
   uint8_t flags;
   bool bad, rows_active, slot_overflow;
 };
-__device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
+__device__ __noinline__ SoloOut solo_control_step(SoloIn in, rr::Ws ws) {
   double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) { q[j] = in.q[j]; v[j] = in.v[j]; cs[j] = in.cs[j]; sn[j] = in.sn[j]; q0[j] = in.q0[j]; q1[j] = in.q1[j]; }
   double time = in.time;
   const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
   const V3 sw = v3(in.sw[0], in.sw[1], in.sw[2]);
-  const bool maybe_rows = in.maybe_rows;
   Grip grip{in.grip_th, in.grip_vel};
   uint8_t flags = in.flags;
-  bool bad = false, rows_active = false, slot_overflow = false, has_warm = false;
-  double warm[NJ] = {0, 0, 0, 0, 0, 0};
+  bool bad = false, rows_active = false, slot_overflow = false;
+  WarmState w;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { w.warm[j] = in.warm[j]; w.pqs[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 21; k++) w.pM[k] = 0;
+  w.has_warm = in.has_warm; w.lazy = false;
   int ncon_proxy = 0;
 #pragma unroll 1
   for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
@@ -681,7 +779,7 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
     double ctrl[NJ], qacc[NJ], touch;
 #pragma unroll
     for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    physics_forces(q, v, ctrl, cs, sn, sw, grip.th, maybe_rows, qacc, touch, ncon_proxy, rows_active, slot_overflow, warm, has_warm);
+    physics_forces(q, v, ctrl, cs, sn, sw, grip.th, qacc, touch, ncon_proxy, rows_active, slot_overflow, w, ws);
     grip_integrate(grip, in.grip_ctrl);
     double acc2 = 0, dq2 = 0;
 #pragma unroll
@@ -701,9 +799,10 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
     time += MJS_RR_PHYSICS_DT;
     switch_update(touch, flags);  // Switch.after_substep (switch.py:71-72)
   }
+  if (w.lazy) rr::smooth_acceleration(w.pM, w.pqs, w.warm);  // the next control step's warm start
   SoloOut o;
 #pragma unroll
-  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; }
+  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; o.warm[j] = w.warm[j]; }
   o.time = time;
   o.grip_th = grip.th; o.grip_vel = grip.vel;
   o.flags = flags;
@@ -725,15 +824,18 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   __shared__ double xch[ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
+  if (ROLES == 2) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it (see rr::kernel3)
+  const rr::Ws ws{p.ws, p.N, i};
   double obs[OBS_DIM];
   rr::Chain c;
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
     if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    ResetOut r = episode_init(p.rng, i, flags);
+    ResetOut r = episode_init(p.rng, i, flags, ws);
     rr::store_state(p, i, r.st);
     p.state[(size_t)S_GRIP * p.N + i] = 0.0;  // mj_resetData: gripper open, at rest
     p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
+    rr::store_warm(p, i, S_WARM, nullptr);
     p.flags[i] = r.flags;
     rr::fk(r.st.q, c);
     make_obs(r.st, c, r.flags, obs);
@@ -765,16 +867,35 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const double grip_ctrl = grip_ctrl_of_opening(p.actions[(size_t)i * adim + (adim - 1)]);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
   bool bad = false, rows_active = false, slot_overflow = false;
-  double cs[NJ], sn[NJ];
+  double cs[NJ], sn[NJ], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
   rr::fk_cs(cs, sn, c);
   // Which path? Both roles evaluate the same predicates on the same data, so the decisions agree without an exchange.
-  const bool guarded = __any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
-  int solo_from = (ROLES == 1) ? 0 : MJS_RR_NSUB;                                    // first substep of the robust path
+  // The arm's own geoms and the floor (the registered action space is +-3.14 rad on every joint, robot_push_button.py:193-203):
+  // the row-free path needs the configuration now AND the servo target clear of the floor by rr::CLEAR_MARGIN, and a
+  // joint-space travel (velocity included) short enough that the arm's points cannot dip from the chord between the two to the
+  // floor: reach (<= 1 m) * travel^2 / 8 <= clearance - 2 cm. Otherwise the whole control step takes the robust path.
+  bool link_unsafe;
+  {
+    double c1[NJ], s1[NJ], t2 = 0;
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      sincos(q1[j], &s1[j], &c1[j]);
+      const double d = fabs(q1[j] - q0[j]) + 0.05 * fabs(st.v[j]);
+      t2 = fma(d, d, t2);
+    }
+    rr::Chain ch1;
+    rr::fk_cs(c1, s1, ch1);
+    const double clr = fmin(rr::min_floor_clearance(c), rr::min_floor_clearance(ch1));
+    link_unsafe = !(clr >= rr::CLEAR_MARGIN) || !(t2 <= 8.0 * (clr - 0.02));
+  }
+  const bool links_solo = __any(link_unsafe);
+  const bool guarded = links_solo || __any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
+  int solo_from = (ROLES == 1 || links_solo) ? 0 : MJS_RR_NSUB;                      // first substep of the robust path
   if constexpr (ROLES == 2) {
 #pragma unroll 1
-    for (int seg = 0; seg < MJS_RR_NSUB / SEGMENT_SUBSTEPS; seg++) {
+    for (int seg = 0; seg < MJS_RR_NSUB / SEGMENT_SUBSTEPS && !links_solo; seg++) {
       if (guarded) {  // wave-uniform: the steady state never enters
         if (seg > 0) rr::fk_cs(cs, sn, c);
         if (__any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, SEGMENT_SUBSTEPS * MJS_RR_PHYSICS_DT))) {
@@ -854,12 +975,16 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     in.time = st.time; in.t0 = t0; in.t1 = t1;
     in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
     in.flags = flags;
-    in.maybe_rows = true;  // the whole wavefront runs the robust path from here: detect contacts for every lane of it
-    in.first_substep = solo_from;
+    in.first_substep = solo_from;  // the whole wavefront runs the robust path from here: every substep detects rows for every lane of it
     in.grip_th = grip.th; in.grip_vel = grip.vel; in.grip_ctrl = grip_ctrl;
-    SoloOut o = solo_control_step(in);
+    // the state's qacc_warmstart belongs to the start of the control step; after row-free substeps the robust path starts
+    // without one (its first substep has no rows by the guard's margin; later ones continue from it)
+    in.has_warm = solo_from == 0 && (flags & FLAG_WARM_VALID);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
+    for (int j = 0; j < NJ; j++) in.warm[j] = in.has_warm ? p.state[(size_t)(S_WARM + j) * p.N + i] : 0.0;
+    SoloOut o = solo_control_step(in, ws);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; warm_out[j] = o.warm[j]; }
     st.time = o.time;
     grip.th = o.grip_th; grip.vel = o.grip_vel;
     flags = o.flags;
@@ -883,21 +1008,22 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   if (bad) { reward = 0; discount = 0; terminate = true; }
   if (st.time >= p.time_limit) terminate = true;
   // ncon after the step (mj_step1 of the last substep): arm-vs-floor + finger-tip sphere contacts
-  int ncon = rr::count_floor_contacts(c);
-  const bool arm_touches_floor = ncon > 0;  // detected and counted, not solved: reported below
+  int ncon = rr::floor_contacts_from_clearance(c, rr::min_floor_clearance(c));
+  const bool arm_touches_floor = ncon > 0;
   int ncon_proxy;
   {
     ContactSet con;
     detect_contacts(c, grip.th, sw, con);
-    ncon_proxy = con.n;
-    ncon += con.n;
+    ncon_proxy = con.n + (detect_wrist_box(c, sw).hit ? 1 : 0);
+    ncon += ncon_proxy;
   }
-  const bool violated = !solo && (ncon_proxy > 0 || rr::joint_outside_range(st.q));  // a-posteriori check of the row-free path (solo: every lane detects)
+  const bool violated = !solo && (ncon_proxy > 0 || arm_touches_floor || rr::joint_outside_range(st.q));  // a-posteriori check of the row-free path (solo: every lane detects)
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-              ((arm_touches_floor || slot_overflow) ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
+              (slot_overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0));
+  uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0) | (solo ? FLAG_WARM_VALID : 0));
   rr::store_state(p, i, st);
+  if (solo) rr::store_warm(p, i, S_WARM, warm_out);
   p.state[(size_t)S_GRIP * p.N + i] = grip.th;
   p.state[(size_t)(S_GRIP + 1) * p.N + i] = grip.vel;
   p.flags[i] = newflags;
@@ -907,10 +1033,11 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
 #pragma unroll
       for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
     }
-    ResetOut r = episode_init(p.rng, i, newflags);
+    ResetOut r = episode_init(p.rng, i, newflags, ws);
     rr::store_state(p, i, r.st);
     p.state[(size_t)S_GRIP * p.N + i] = 0.0;
     p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
+    rr::store_warm(p, i, S_WARM, nullptr);
     p.flags[i] = r.flags;
     rr::fk(r.st.q, c);
     make_obs(r.st, c, r.flags, obs);

@@ -10,7 +10,10 @@
 #include "mjs_dev_rng.h"
 
 // per-env flag byte
-enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2 };
+// (4, 8: Button-Push switch bits.) FLAG_WARM_VALID: the state's qacc_warmstart rows hold the solver acceleration of the last
+// Physics.step() (written by the robust path and by resets; a row-free step leaves them stale and clears the bit).
+// FLAG_CLEAR (Robot-Reach): every arm collision geom was >= rr::CLEAR_MARGIN above the floor in the step's final configuration.
+enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2, FLAG_WARM_VALID = 16, FLAG_CLEAR = 32 };
 
 struct KernelParams {
   int N;
@@ -25,6 +28,7 @@ struct KernelParams {
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]
+  double* ws;       // [rr::WS_ROWS][N] contact workspace of the robot scenes' general constraint stage (mjs_arm_stage.h)
   DevRng rng;
   const double* actions;      // [N, A] (step) or nullptr (reset)
   const uint8_t* reset_mask;  // reset kernel only; nullptr = all

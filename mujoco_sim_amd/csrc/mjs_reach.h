@@ -30,7 +30,10 @@
 
 namespace rr {
 
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, STATE_DIM = 16;
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, HOT_STATE_DIM = 16;
+// rows 16-21: qacc_warmstart (mjData state: the solver acceleration of the last Physics.step()). Only the robust path reads or
+// writes them (flag FLAG_WARM_VALID says whether they belong to the current state); the row-free fast path never touches them.
+constexpr int S_WARM = 16, STATE_DIM = 22;
 constexpr int OBS_DIM = 12, ACT_DIM = 3, NJ = 6;
 constexpr double PI = 3.14159265358979323846;
 
@@ -799,14 +802,40 @@ MJS_DEV int count_floor_contacts(const Chain& c) {
   return n;
 }
 
+}  // namespace rr
+#include "mjs_arm_stage.h"
+namespace rr {
+
+struct SceneReach {  // Robot-Reach: UR5e + lumped gripper payload, no collision geom beyond the arm's own
+  struct Extra {};
+  static constexpr double MEANINERTIA = UR5E_MEANINERTIA;
+  MJS_DEV static double dof_invweight(int j) { return UR5E_DOF_INVWEIGHT0[j]; }
+  MJS_DEV static double link_invweight(int b) { return UR5E_LINK_BODY_INVWEIGHT0[b]; }
+  template <class E>
+  MJS_DEV static void extra_contacts(const Chain&, Extra, E) {}
+  MJS_DEV static bool in_touch_site(Extra, V3) { return false; }
+};
+
 // ---- the fast path's guard ---------------------------------------------------------------------------------------
-// The role-specialised fast path builds no constraint rows. A PRIORI it is only taken when no joint can reach its
-// range during the control step: margin = 0.6 rad (what the force-clamped servos add within 0.1 s from rest) plus the
-// distance the joint covers at its CURRENT velocity, |v| * 0.1 s (mjs_set_state can inject any velocity). A POSTERIORI
-// the final joint positions are re-checked; a violation (never observed; the bound is not a proof) is REPORTED as
-// MJS_FAULT_FASTPATH_VIOLATED for that env and step, so a wrong result is never published silently. (Redoing the step
-// on the robust path from inside the kernel was built and measured: the extra call after the hot loop costs 4.6 us per
-// launch in spills, profiles/r02_e_guard_ab.txt.)
+// The role-specialised fast path builds no constraint rows, so it may only run a control step during which no row can
+// become active. Rows of this scene: joint limits, and contacts of the arm's collision geoms with the floor.
+//   joints  A PRIORI: no joint can reach its range during the control step: margin = 0.6 rad (what the force-clamped
+//           servos add within 0.1 s from rest) plus the distance the joint covers at its CURRENT velocity, |v| * 0.1 s
+//           (mjs_set_state can inject any velocity).
+//   floor   A PRIORI, from three facts: (1) the step STARTS with every collision geom at least CLEAR_MARGIN above the floor
+//           (flag FLAG_CLEAR, computed from the final configuration of the previous step / reset / mjs_set_state: free, the
+//           step's epilogue has the kinematics anyway); (2) the servo TARGET is a top-down TCP pose inside the task's own
+//           action box (robot_reach.py:187-201), whose IK solutions keep the wrist geoms >= 0.15 m and the elbow far
+//           above the floor; (3) the joint-space TRAVEL towards it is short: sum_j (|q1_j - q0_j| + 0.05 s |v_j|)^2 <=
+//           TRAVEL2_MAX (the over-damped servos move every joint monotonically from q0 towards q1; between two
+//           top-down poses of the action box the wrist stays > 0.1 m up; uniform in-box targets reach 1.1 at most, p99 0.6).
+//           (2) is known at kernel entry (the action), (3) after the IK: a workgroup that fails (3) leaves the fast
+//           path after substep 0, which needs no IK result and, by (1), has no rows.
+// A POSTERIORI the final state is re-checked: a joint beyond its range or a geom on the floor after a row-free step
+// (never observed; the bounds are not proofs) is REPORTED as MJS_FAULT_FASTPATH_VIOLATED for that env and step, so a wrong
+// result is never published silently. Everything else — any action, any injected state — takes the robust path, which
+// detects limits and contacts in every substep and solves them (mjs_arm_stage.h).
+constexpr double CLEAR_MARGIN = 0.10, TRAVEL2_MAX = 2.5;
 MJS_DEV bool joint_near_range(const double* q, const double* v) {
   bool near = false;
 #pragma unroll
@@ -821,6 +850,33 @@ MJS_DEV bool joint_outside_range(const double* q) {
 #pragma unroll
   for (int j = 0; j < NJ; j++) out = out || (q[j] < MJS_UR_JNT_RANGE[j][0]) || (q[j] > MJS_UR_JNT_RANGE[j][1]);
   return out;
+}
+MJS_DEV bool action_in_box(const double* act) {
+  bool in = true;
+#pragma unroll
+  for (int k = 0; k < 3; k++) in = in && act[k] >= MJS_RR_SPACE_LO[k] && act[k] <= MJS_RR_SPACE_HI[k];
+  return in;
+}
+MJS_DEV bool travel_is_long(const double* q_start, const double* q_target, const double* v) {
+  double t2 = 0;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const double d = fabs(q_target[j] - q_start[j]) + 0.05 * fabs(v[j]);
+    t2 = fma(d, d, t2);
+  }
+  return !(t2 <= TRAVEL2_MAX);
+}
+// FLAG_CLEAR of a configuration (mjs_set_state recomputes it: the caller may have edited the joints)
+MJS_DEV bool config_is_clear(const double* q) {
+  Chain c;
+  fk(q, c);
+  return min_floor_clearance(c) >= CLEAR_MARGIN;
+}
+// ncon of a configuration: the exact count only where the cheap bound says a geom may touch (rare)
+MJS_DEV int floor_contacts_from_clearance(const Chain& c, double minclr) {
+  int ncon = 0;
+  if (__any(!(minclr > 0.0))) ncon = count_floor_contacts(c);
+  return (minclr > 0.0) ? 0 : ncon;
 }
 
 // ---------------------------------------------------------------------------- kernel
@@ -847,6 +903,11 @@ MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
 #pragma unroll
   for (int k = 0; k < 3; k++) s[(S_TARGET + k) * N] = st.target[k];
 }
+// qacc_warmstart rows (first_row = the task's S_WARM): mj_resetData zeroes them
+MJS_DEV void store_warm(const KernelParams& p, int i, int first_row, const double* w) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++) p.state[(size_t)(first_row + j) * p.N + i] = w ? w[j] : 0.0;
+}
 
 // initialize_episode (robot_reach.py:143-150): robot xyz -> IK from qpos0 = 0 -> set joints;
 // then target xyz. Returns the per-episode ik_failed flag (always clear after a reset).
@@ -868,6 +929,32 @@ __device__ __noinline__ State episode_init(DevRng rng, int i) {
   st.time = 0;
   return st;
 }
+// everything a reset publishes: state, zeroed warm start, flags (fresh mjData: qacc_warmstart = 0 is the valid warm start of
+// the first step), FIRST outputs. Returns nothing live.
+MJS_DEV void publish_reset(const KernelParams& p, int i, const State& st, bool write_first) {
+  Chain c;
+  double obs[OBS_DIM];
+  store_state(p, i, st);
+  store_warm(p, i, S_WARM, nullptr);
+  fk(st.q, c);
+  const double minclr = min_floor_clearance(c);
+  p.flags[i] = (uint8_t)(FLAG_WARM_VALID | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0));
+  V3 tcp = tcp_position(c);
+  obs[0] = tcp.x; obs[1] = tcp.y; obs[2] = tcp.z;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) obs[3 + j] = st.q[j];
+#pragma unroll
+  for (int k = 0; k < 3; k++) obs[9 + k] = st.target[k];
+  const int ncon = floor_contacts_from_clearance(c, minclr);
+  if (write_first) write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, ncon);
+  else {  // same-step auto-reset: only the observation and ncon are replaced (the LAST step's reward / flags stay)
+    if (p.out.obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    if (p.out.ncon) p.out.ncon[i] = ncon;
+  }
+}
 
 MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
   V3 tcp = tcp_position(c);
@@ -878,38 +965,97 @@ MJS_DEV void make_obs(const State& st, const Chain& c, double* obs) {
   for (int k = 0; k < 3; k++) obs[9 + k] = st.target[k];
 }
 
-// The 20 substeps of one control step on ONE wavefront, joint-limit rows included (robust path: used
-// by kernel_variant = single wave, and by the default kernel for workgroups in which some joint is
-// within reach of its range). noinline + by value: keeps this rarely-taken code (and the limit
-// solver's call frame) out of the role-specialised hot loop.
+// The substeps first_substep .. 19 of one control step on ONE wavefront with every constraint row of the scene available
+// (robust path: kernel_variant = single wave, and the default kernels for workgroups whose guard fails). Every substep
+// checks the joint ranges and the arm's floor clearance; lanes with an active row go through the general constraint stage
+// (mjs_arm_stage.h), warm-started exactly as mj_fwdConstraint does: qacc_warmstart = the previous Physics.step()'s solver
+// acceleration — the stage's own result, or M^-1 qfrc_smooth of a row-free substep (evaluated lazily, only when the next
+// substep turns out to have rows), or the persisted rows of the state at the control step's first substep.
+// noinline + by value: keeps this rarely-taken code (and the stage's call frame) out of the role-specialised hot loop.
 struct SoloIn {
   double q[NJ], v[NJ], q0[NJ], q1[NJ], cs[NJ], sn[NJ], time, t0, t1;
+  double warm[NJ];
+  bool has_warm;
+  int first_substep;  // the substeps before it were taken on the row-free path
 };
 struct SoloOut {
-  double q[NJ], v[NJ], cs[NJ], sn[NJ], time;
-  bool bad, limit_rows_active;
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], time, warm[NJ];
+  bool bad, rows_active, overflow;
 };
-__device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
-  // work on register copies; the in/out structs live in the call frame
-  double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ];
+// qacc_smooth = (M + armature)^-1 qfrc_smooth: what the solver returns for a step without rows
+MJS_DEV void smooth_acceleration(const double* Marm /*21*/, const double* qs, double* out) {
+  double L[NJ][NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; j++) { q[j] = in.q[j]; v[j] = in.v[j]; cs[j] = in.cs[j]; sn[j] = in.sn[j]; q0[j] = in.q0[j]; q1[j] = in.q1[j]; }
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) L[i][j] = Marm[i * (i + 1) / 2 + j];
+    out[i] = qs[i];
+  }
+  chol6(L);
+  chol6_solve(L, out);
+}
+__device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
+  // work on register copies; the in/out structs live in the call frame
+  double q[NJ], v[NJ], cs[NJ], sn[NJ], q0[NJ], q1[NJ], warm[NJ], pM[21], pqs[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { q[j] = in.q[j]; v[j] = in.v[j]; cs[j] = in.cs[j]; sn[j] = in.sn[j]; q0[j] = in.q0[j]; q1[j] = in.q1[j]; warm[j] = in.warm[j]; pqs[j] = 0; }
+#pragma unroll
+  for (int k = 0; k < 21; k++) pM[k] = 0;
   double time = in.time;
   const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
-  bool bad = false, limit_rows_active = false;
+  bool bad = false, rows_active = false, overflow = false;
+  bool has_warm = in.has_warm, lazy = false;  // lazy: the warm start is M^-1 qfrc_smooth of (pM, pqs), not yet evaluated
 #pragma unroll 1
-  for (int s = 0; s < MJS_RR_NSUB; s++) {
+  for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
     // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
     double t = fmin(fmax(time, t0), t1);
-    double ctrl[NJ], qacc[NJ];
+    double ctrl[NJ], M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-    dynamics(q, v, ctrl, cs, sn, qacc, limit_rows_active);
+    ur5e_dynamics_gen(cs, sn, v, M, bias);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
+      M[i * (i + 1) / 2 + i] += MJS_UR_ARMATURE;
+    }
+    const int clamped = actuator_forces(q, v, ctrl, fact);
+#pragma unroll
+    for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];  // qfrc_smooth = passive - bias + actuator
+    bool rows = joint_outside_range(q);
+    {
+      Chain ch;
+      fk_cs(cs, sn, ch);
+      rows = rows || !(min_floor_clearance(ch) >= 0.0);
+    }
+    if (rows) {  // rare: a joint beyond its range or a collision geom in the floor
+      if (lazy) { smooth_acceleration(pM, pqs, warm); has_warm = true; lazy = false; }
+      GenStageIn gi;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { gi.q[j] = q[j]; gi.v[j] = v[j]; gi.cs[j] = cs[j]; gi.sn[j] = sn[j]; gi.qs[j] = rhs[j]; gi.warm[j] = warm[j]; }
+#pragma unroll
+      for (int k = 0; k < 21; k++) gi.M[k] = M[k];
+      gi.has_warm = has_warm;
+      const GenStageOut go = gen_stage<SceneReach>(gi, SceneReach::Extra{}, ws);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { rhs[j] = go.qs[j]; warm[j] = go.qacc[j]; }
+      has_warm = true;
+      rows_active = true;
+      overflow = overflow || go.overflow;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 21; k++) pM[k] = M[k];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) pqs[j] = rhs[j];
+      lazy = true;
+    }
+    factor_system(A, clamped, Dinv);
+    udu_solve(A, Dinv, rhs);
     double acc2 = 0, dq2 = 0;
 #pragma unroll
     for (int j = 0; j < NJ; j++) {
-      acc2 = fma(qacc[j], qacc[j], acc2);
-      v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+      acc2 = fma(rhs[j], rhs[j], acc2);
+      v[j] += MJS_RR_PHYSICS_DT * rhs[j];
       double dq = MJS_RR_PHYSICS_DT * v[j];
       q[j] += dq;
       dq2 = fma(dq, dq, dq2);
@@ -922,13 +1068,107 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in) {
     }
     time += MJS_RR_PHYSICS_DT;
   }
+  if (lazy) smooth_acceleration(pM, pqs, warm);  // the next control step's warm start
   SoloOut o;
 #pragma unroll
-  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; }
+  for (int j = 0; j < NJ; j++) { o.q[j] = q[j]; o.v[j] = v[j]; o.cs[j] = cs[j]; o.sn[j] = sn[j]; o.warm[j] = warm[j]; }
   o.time = time;
   o.bad = bad;
-  o.limit_rows_active = limit_rows_active;
+  o.rows_active = rows_active;
+  o.overflow = overflow;
   return o;
+}
+// hands the lane's state to solo_control_step and takes the result back (the persisted warm start is read here: only the
+// robust path touches those rows)
+#define MJS_RR_RUN_SOLO(FIRST_SUBSTEP, USE_PERSISTED_WARM)                                                                     \
+  do {                                                                                                                          \
+    SoloIn in_;                                                                                                                 \
+    _Pragma("unroll") for (int j = 0; j < NJ; j++) {                                                                            \
+      in_.q[j] = st.q[j]; in_.v[j] = st.v[j]; in_.q0[j] = q0[j]; in_.q1[j] = q1[j]; in_.cs[j] = cs[j]; in_.sn[j] = sn[j];        \
+      in_.warm[j] = (USE_PERSISTED_WARM) ? p.state[(size_t)(S_WARM + j) * p.N + i] : 0.0;                                       \
+    }                                                                                                                           \
+    in_.time = st.time; in_.t0 = t0; in_.t1 = t1;                                                                               \
+    in_.has_warm = (USE_PERSISTED_WARM) && (flags & FLAG_WARM_VALID);                                                           \
+    in_.first_substep = (FIRST_SUBSTEP);                                                                                        \
+    SoloOut o_ = solo_control_step(in_, Ws{p.ws, p.N, i});                                                                      \
+    _Pragma("unroll") for (int j = 0; j < NJ; j++) { st.q[j] = o_.q[j]; st.v[j] = o_.v[j]; cs[j] = o_.cs[j]; sn[j] = o_.sn[j]; warm_out[j] = o_.warm[j]; } \
+    st.time = o_.time;                                                                                                          \
+    bad = bad || o_.bad;                                                                                                        \
+    rows_active = o_.rows_active; overflow = o_.overflow;                                                                       \
+  } while (0)
+
+// What every variant of the step does once the 20 substeps are done (role 0 / the only wavefront): observables, reward,
+// termination, the a-posteriori checks, fault word, flags, state and output stores, same-step auto-reset.
+struct StepEnd {
+  bool solo, bad, rows_active, overflow;
+};
+MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, const double* cs, const double* sn, uint8_t flags, const double* warm_out, StepEnd e,
+                         double* obs_tile) {
+  double obs[OBS_DIM];
+  Chain c;
+  bool bad = e.bad;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);  // mj_checkPos / mj_checkVel
+  MJS_STAMP(p, 2);
+  // observables, reward, termination (cos/sin carried from the last substep, <= 1e-15 from exact)
+  fk_cs(cs, sn, c);
+  make_obs(st, c, obs);
+  double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
+  double dist = sqrt(dx * dx + dy * dy + dz * dz);
+  bool success = dist < MJS_RR_GOAL_THRESHOLD;
+  double reward = (p.reward_type == MJS_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist;
+  double discount = 1.0;
+  bool terminate = false;
+  if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
+  if (bad) { reward = 0; discount = 0; terminate = true; }
+  if (st.time >= p.time_limit) terminate = true;
+  MJS_STAMP(p, 3);
+  // ncon of the final configuration (mj_step1 of the last substep) and the next step's FLAG_CLEAR, both from the cheap
+  // clearance bound; the exact count runs only when some lane of the wavefront may touch
+  const double minclr = min_floor_clearance(c);
+  const int ncon = floor_contacts_from_clearance(c, minclr);
+  MJS_STAMP(p, 4);
+  // fault word: the robust path solves every row of this scene (bit 8 only when a lane has more active contacts than the
+  // stage's workspace holds); the row-free path's a-posteriori check is bit 16
+  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (e.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
+              (e.overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!e.solo && (ncon > 0 || joint_outside_range(st.q))) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
+  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
+  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0) | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0) | (e.solo ? FLAG_WARM_VALID : 0));
+  // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
+  // has to stay live across that call
+  store_state(p, i, st);
+  if (e.solo) store_warm(p, i, S_WARM, warm_out);
+  p.flags[i] = newflags;
+  // observations [N, 12] row-major: a lane-per-env store is a 96-B-strided scatter (2.5x write
+  // amplification measured with WRITE_SIZE); transpose the wave's 64x12 block through LDS and write
+  // it as 12 fully coalesced 512-B stores instead. Only this wavefront touches obs_tile.
+  {
+    KernelParams pn = p;
+    pn.out.obs = nullptr;
+    write_outputs<OBS_DIM>(pn, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+    if (p.out.obs) {
+      if (__ballot(1) == ~0ull) {  // whole wavefront alive: cooperative block store
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) obs_tile[lane * OBS_DIM + k] = obs[k];
+        __builtin_amdgcn_wave_barrier();
+        double* dst = p.out.obs + (size_t)blockIdx.x * 64 * OBS_DIM;
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
+      } else {  // some lanes left earlier (auto-reset path, tail of the batch): each lane writes its own row
+#pragma unroll
+        for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
+      }
+    }
+  }
+  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
+    if (p.out.terminal_obs) {
+#pragma unroll
+      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
+    }
+    State fresh = episode_init(p.rng, i);
+    publish_reset(p, i, fresh, false);
+  }
+  MJS_STAMP(p, 5);
 }
 
 // ROLES == 1: one wavefront steps 64 envs. ROLES == 2 (default for stepping): two wavefronts of
@@ -949,23 +1189,18 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   __shared__ double obs_tile[IS_RESET ? 1 : OBS_DIM * 64];  // wave-private transpose buffer for coalesced obs stores
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
-  double obs[OBS_DIM];
-  Chain c;
+  if (ROLES == 2) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it (see kernel3)
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
     if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    State st = episode_init(p.rng, i);
-    store_state(p, i, st);
-    p.flags[i] = 0;
-    fk(st.q, c);
-    make_obs(st, c, obs);
-    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, count_floor_contacts(c));
+    State fresh = episode_init(p.rng, i);
+    publish_reset(p, i, fresh, true);
     return;
   }
   MJS_STAMP(p, 0);
   State st = load_state(p, i);
   // before_step: servoL (robot_reach.py:169 -> robot.py:218-259); evaluated by both roles (same result)
-  double q0[NJ], q1[NJ], act[3];
+  double q0[NJ], q1[NJ], act[3], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
 #pragma unroll
@@ -978,28 +1213,16 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 1);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
-  bool bad = false, limit_rows_active = false;
+  bool bad = false, rows_active = false, overflow = false;
   double cs[NJ], sn[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-  // Joint-limit rows can only become active if a joint gets within reach of its range during this
-  // control step (0.6 rad of travel is far beyond what the clamped servos produce in 0.1 s). Then the
-  // whole workgroup takes the robust single-wavefront path, which checks the limits every substep;
-  // both roles evaluate the same predicate on the same data, so the decision is consistent.
-  const bool near_limit = joint_near_range(st.q, st.v);
-  const bool solo = (ROLES == 1) || __any(near_limit);
+  // The guard (see above): both roles evaluate the same predicates on the same data, so the decision is consistent.
+  const bool unsafe = joint_near_range(st.q, st.v) || !(flags & FLAG_CLEAR) || !action_in_box(act) || travel_is_long(q0, q1, st.v);
+  const bool solo = (ROLES == 1) || __any(unsafe);
   if (solo) {
     if (role != 0) return;
-    SoloIn in;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
-    in.time = st.time; in.t0 = t0; in.t1 = t1;
-    SoloOut o = solo_control_step(in);
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
-    st.time = o.time;
-    bad = o.bad;
-    limit_rows_active = o.limit_rows_active;
+    MJS_RR_RUN_SOLO(0, true);
   } else if constexpr (ROLES == 2) {
 #pragma unroll 1
     for (int s = 0; s < MJS_RR_NSUB; s++) {
@@ -1074,72 +1297,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     }
   }
   if (role != 0) return;
-#pragma unroll
-  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);  // mj_checkPos / mj_checkVel
-  MJS_STAMP(p, 2);
-  // observables, reward, termination (cos/sin carried from the last substep, <= 1e-15 from exact)
-  fk_cs(cs, sn, c);
-  make_obs(st, c, obs);
-  double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
-  double dist = sqrt(dx * dx + dy * dy + dz * dz);
-  bool success = dist < MJS_RR_GOAL_THRESHOLD;
-  double reward = (p.reward_type == MJS_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist;
-  double discount = 1.0;
-  bool terminate = false;
-  if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
-  if (bad) { reward = 0; discount = 0; terminate = true; }
-  if (st.time >= p.time_limit) terminate = true;
-  MJS_STAMP(p, 3);
-  int ncon = count_floor_contacts(c);
-  MJS_STAMP(p, 4);
-  // arm-vs-floor contacts are detected and counted but not solved, and the row-free path assumed that no
-  // joint leaves its range: both are reported, never silent
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-              (ncon > 0 ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!solo && joint_outside_range(st.q)) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
-  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
-  // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
-  // has to stay live across that call
-  store_state(p, i, st);
-  p.flags[i] = newflags;
-  // observations [N, 12] row-major: a lane-per-env store is a 96-B-strided scatter (2.5x write
-  // amplification measured with WRITE_SIZE); transpose the wave's 64x12 block through LDS and write
-  // it as 12 fully coalesced 512-B stores instead. Only this wavefront touches obs_tile.
-  {
-    KernelParams pn = p;
-    pn.out.obs = nullptr;
-    write_outputs<OBS_DIM>(pn, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
-    if (p.out.obs) {
-      if (__ballot(1) == ~0ull) {  // whole wavefront alive: cooperative block store
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) obs_tile[lane * OBS_DIM + k] = obs[k];
-        __builtin_amdgcn_wave_barrier();
-        double* dst = p.out.obs + (size_t)blockIdx.x * 64 * OBS_DIM;
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
-      } else {  // some lanes left earlier (auto-reset path, tail of the batch): each lane writes its own row
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-      }
-    }
-  }
-  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
-    if (p.out.terminal_obs) {
-#pragma unroll
-      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
-    }
-    State fresh = episode_init(p.rng, i);
-    store_state(p, i, fresh);
-    p.flags[i] = 0;
-    fk(fresh.q, c);
-    make_obs(fresh, c, obs);
-    if (p.out.obs) {
-#pragma unroll
-      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-    }
-    if (p.out.ncon) p.out.ncon[i] = count_floor_contacts(c);
-  }
-  MJS_STAMP(p, 5);
+  finish_step(p, i, lane, st, cs, sn, flags, warm_out, StepEnd{solo, bad, rows_active, overflow}, obs_tile);
 }
 
 
@@ -1148,8 +1306,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
 //   wave 2      the analytic IK of servoL (the whole closest-of-8 search), published through LDS; then it exits.
 //   waves 0, 1  meanwhile run substep 0 on their own, redundantly and without a barrier: its servo set-point is q0
 //               itself (fraction 0/20 of the trajectory), so it does not need the IK result. Then one barrier, and
-//               substeps 1..19 as the two role-specialised wavefronts of kernel<false, 2>; at the end role 1 counts
-//               the floor contacts while role 0 writes the outputs.
+//               substeps 1..19 as the two role-specialised wavefronts of kernel<false, 2>.
 // Why not more wavefronts or lanes per env — measured on gfx950 (tools/microbench/ub.hip, profiles/r02_a_microbench.txt):
 // one LDS exchange + barrier between two wavefronts costs 150 cycles + ~20 per double, a cross-lane move of a double
 // (2 x v_mov_b32_dpp) ~11 cycles = two FP64 issue slots, a wavefront with 16 active lanes issues FP64 no faster than a
@@ -1188,32 +1345,31 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   __shared__ double ikx[7][64];     // q1[6], found
   __shared__ double obs_tile[OBS_DIM * 64];
   if (i >= p.N) return;
+  // Every wavefront takes the same branch below from its OWN read of flags[i]; wave 0 rewrites flags[i] (reset path: at once;
+  // step path: in the epilogue). The barrier orders every wavefront's read before any such write (a wavefront
+  // scheduled late could otherwise see the flag already cleared and step the freshly reset lane).
   uint8_t flags = p.flags[i];
-  double obs[OBS_DIM];
-  Chain c;
+  __syncthreads();
   if ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP) {
     if (wave != 0) return;
-    State st = episode_init(p.rng, i);
-    store_state(p, i, st);
-    p.flags[i] = 0;
-    fk(st.q, c);
-    make_obs(st, c, obs);
-    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, count_floor_contacts(c));
+    State fresh = episode_init(p.rng, i);
+    publish_reset(p, i, fresh, true);
     return;
   }
   MJS_STAMP(p, 0);
   State st = load_state(p, i);
-  double q0[NJ], q1[NJ], act[3];
+  double q0[NJ], q1[NJ], act[3], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
 #pragma unroll
   for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
 #pragma unroll
   for (int j = 0; j < NJ; j++) q0[j] = st.q[j];
-  // same wave-uniform guard as kernel<false, 2>: a joint within reach of its range sends the whole workgroup to the
-  // robust single-wavefront path (every wavefront evaluates it on the same data)
-  const bool solo = __any(joint_near_range(st.q, st.v));
+  // the part of the guard that is known at kernel entry (same data in every wavefront): a joint within reach of its range,
+  // a start configuration that is not known to be clear of the floor, or a servo target outside the task's action box send
+  // the whole workgroup to the robust single-wavefront path
+  bool solo = __any(joint_near_range(st.q, st.v) || !(flags & FLAG_CLEAR) || !action_in_box(act));
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
-  bool bad = false, limit_rows_active = false;
+  bool bad = false, rows_active = false, overflow = false;
   double cs[NJ], sn[NJ];
   if (solo) {
     if (wave != 0) return;
@@ -1225,16 +1381,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
     }
 #pragma unroll
     for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-    SoloIn in;
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { in.q[j] = st.q[j]; in.v[j] = st.v[j]; in.q0[j] = q0[j]; in.q1[j] = q1[j]; in.cs[j] = cs[j]; in.sn[j] = sn[j]; }
-    in.time = st.time; in.t0 = t0; in.t1 = t1;
-    SoloOut o = solo_control_step(in);
-#pragma unroll
-    for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; }
-    st.time = o.time;
-    bad = o.bad;
-    limit_rows_active = o.limit_rows_active;
+    MJS_RR_RUN_SOLO(0, true);
   } else {
     if (wave == 2) {
       // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
@@ -1246,8 +1393,9 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
       return;
     }
     const int role = wave;
+    double v_start[NJ];
 #pragma unroll
-    for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    for (int j = 0; j < NJ; j++) { sincos(st.q[j], &sn[j], &cs[j]); v_start[j] = st.v[j]; }
     {
       // substep 0, whole on this wavefront (both of them, same bits): ctrl = q0 (joint_trajectory.py:41-47 at t = t0)
       double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ], ctrl[NJ];
@@ -1288,145 +1436,83 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
 #pragma unroll
     for (int j = 0; j < NJ; j++) q1[j] = ikx[j][lane];
     if (ikx[6][lane] == 0.0) flags |= FLAG_IK_FAILED;  // reference raises ValueError; batched: flag + hold position (D-4)
+    // the rest of the guard needs the servo target: a long joint-space travel leaves the fast path here (substep 0 had no
+    // rows: the start configuration was clear and no joint near its range). Both dynamics wavefronts hold the same numbers.
+    if (__any(travel_is_long(q0, q1, v_start))) {
+      if (role != 0) return;
+      solo = true;
+      MJS_RR_RUN_SOLO(1, false);  // no warm start across the hand-over: the first robust substep has no rows (guard), later ones start from it
+    } else {
 #pragma unroll 1
-    for (int s = 1; s < MJS_RR_NSUB; s++) {
-      double qacc[NJ];
-      if (role == 1) {
-        double t = fmin(fmax(st.time, t0), t1);
-        double ctrl[NJ], bias[NJ], fact[NJ];
+      for (int s = 1; s < MJS_RR_NSUB; s++) {
+        double qacc[NJ];
+        if (role == 1) {
+          double t = fmin(fmax(st.time, t0), t1);
+          double ctrl[NJ], bias[NJ], fact[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-        actuator_forces(st.q, st.v, ctrl, fact);
-        ur5e_bias_gen(cs, sn, st.v, bias);
+          for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+          actuator_forces(st.q, st.v, ctrl, fact);
+          ur5e_bias_gen(cs, sn, st.v, bias);
 #pragma unroll
-        for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
-        __syncthreads();  // qfrc_smooth published
-        __syncthreads();  // qacc published
+          for (int j = 0; j < NJ; j++) xch[j][lane] = fact[j] - bias[j];  // qfrc_smooth = -bias + actuator
+          __syncthreads();  // qfrc_smooth published
+          __syncthreads();  // qacc published
 #pragma unroll
-        for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
-      } else {
-        if (s == 10) MJS_STAMP(p, 8);
-        double t = fmin(fmax(st.time, t0), t1);
-        double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
+          for (int j = 0; j < NJ; j++) qacc[j] = xch[6 + j][lane];
+        } else {
+          if (s == 10) MJS_STAMP(p, 8);
+          double t = fmin(fmax(st.time, t0), t1);
+          double ctrl[NJ], fdummy[NJ], M[21], A[NJ][NJ], W[NJ][NJ], Dinv[NJ], rhs[NJ];
 #pragma unroll
-        for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
-        int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
-        ur5e_M_gen(cs, sn, M);
+          for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
+          int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
+          ur5e_M_gen(cs, sn, M);
 #pragma unroll
-        for (int r = 0; r < NJ; r++) {
+          for (int r = 0; r < NJ; r++) {
 #pragma unroll
-          for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+            for (int j = 0; j <= r; j++) A[r][j] = M[r * (r + 1) / 2 + j];
+          }
+          factor_system(A, clamped, Dinv);
+          invert_unit_upper(A, W);
+#pragma unroll
+          for (int r = 0; r < NJ; r++) {
+            asm volatile("" : "+v"(Dinv[r]));
+#pragma unroll
+            for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+          }
+          if (s == 10) MJS_STAMP(p, 9);
+          __syncthreads();  // qfrc_smooth published
+          if (s == 10) MJS_STAMP(p, 10);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
+          apply_inverse(W, Dinv, rhs, qacc);
+#pragma unroll
+          for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
+          __syncthreads();  // qacc published
+          if (s == 10) MJS_STAMP(p, 11);
         }
-        factor_system(A, clamped, Dinv);
-        invert_unit_upper(A, W);
+        double acc2 = 0, dq2 = 0;
 #pragma unroll
-        for (int r = 0; r < NJ; r++) {
-          asm volatile("" : "+v"(Dinv[r]));
-#pragma unroll
-          for (int j = 0; j < r; j++) asm volatile("" : "+v"(W[r][j]));
+        for (int j = 0; j < NJ; j++) {
+          acc2 = fma(qacc[j], qacc[j], acc2);
+          st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
+          double dq = MJS_RR_PHYSICS_DT * st.v[j];
+          st.q[j] += dq;
+          dq2 = fma(dq, dq, dq2);
+          rotate_small(cs[j], sn[j], dq);
         }
-        if (s == 10) MJS_STAMP(p, 9);
-        __syncthreads();  // qfrc_smooth published
-        if (s == 10) MJS_STAMP(p, 10);
+        bad = bad || !(acc2 <= 1e20);
+        if (!(dq2 <= 0.01)) {
 #pragma unroll
-        for (int j = 0; j < NJ; j++) rhs[j] = xch[j][lane];
-        apply_inverse(W, Dinv, rhs, qacc);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) xch[6 + j][lane] = qacc[j];
-        __syncthreads();  // qacc published
-        if (s == 10) MJS_STAMP(p, 11);
+          for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+        }
+        st.time += MJS_RR_PHYSICS_DT;
+        if (role == 0 && s == 10) MJS_STAMP(p, 12);
       }
-      double acc2 = 0, dq2 = 0;
-#pragma unroll
-      for (int j = 0; j < NJ; j++) {
-        acc2 = fma(qacc[j], qacc[j], acc2);
-        st.v[j] += MJS_RR_PHYSICS_DT * qacc[j];
-        double dq = MJS_RR_PHYSICS_DT * st.v[j];
-        st.q[j] += dq;
-        dq2 = fma(dq, dq, dq2);
-        rotate_small(cs[j], sn[j], dq);
-      }
-      bad = bad || !(acc2 <= 1e20);
-      if (!(dq2 <= 0.01)) {
-#pragma unroll
-        for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-      }
-      st.time += MJS_RR_PHYSICS_DT;
-      if (role == 0 && s == 10) MJS_STAMP(p, 12);
-    }
-    if (role == 1) {
-      // role 1's last job: the floor-contact count of the final configuration (role 0 is writing the outputs meanwhile).
-      // Not with a same-step reset: there role 0 may overwrite ncon with the post-reset count, and two wavefronts' stores
-      // to one address are unordered.
-      if (p.out.ncon && p.autoreset != MJS_AUTORESET_SAME_STEP) {
-        fk_cs(cs, sn, c);
-        p.out.ncon[i] = count_floor_contacts(c);
-      }
-      return;
+      if (role == 1) return;  // (the floor-contact count it used to take here is a by-product of role 0's clearance bound now)
     }
   }
-#pragma unroll
-  for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);  // mj_checkPos / mj_checkVel
-  MJS_STAMP(p, 2);
-  fk_cs(cs, sn, c);
-  make_obs(st, c, obs);
-  double dx = obs[0] - st.target[0], dy = obs[1] - st.target[1], dz = obs[2] - st.target[2];
-  double dist = sqrt(dx * dx + dy * dy + dz * dz);
-  bool success = dist < MJS_RR_GOAL_THRESHOLD;
-  double reward = (p.reward_type == MJS_REW_SPARSE) ? (success ? 1.0 : 0.0) : -dist;
-  double discount = 1.0;
-  bool terminate = false;
-  if (p.terminate_on_success && success) { terminate = true; discount = 0.0; }
-  if (bad) { reward = 0; discount = 0; terminate = true; }
-  if (st.time >= p.time_limit) terminate = true;
-  MJS_STAMP(p, 3);
-  const bool ncon_here = solo || p.autoreset == MJS_AUTORESET_SAME_STEP;  // otherwise role 1 writes it
-  int ncon = ncon_here ? count_floor_contacts(c) : 0;
-  MJS_STAMP(p, 4);
-  // arm-vs-floor contacts are detected and counted but not solved, and the row-free path assumed that no
-  // joint leaves its range: both are reported, never silent
-  int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (limit_rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
-              (ncon > 0 ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!solo && joint_outside_range(st.q)) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
-  bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0));
-  store_state(p, i, st);
-  p.flags[i] = newflags;
-  {
-    KernelParams pn = p;
-    pn.out.obs = nullptr;
-    if (!ncon_here) pn.out.ncon = nullptr;
-    write_outputs<OBS_DIM>(pn, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
-    if (p.out.obs) {
-      if (__ballot(1) == ~0ull) {  // whole wavefront alive: cooperative block store (only this wavefront touches obs_tile)
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) obs_tile[lane * OBS_DIM + k] = obs[k];
-        __builtin_amdgcn_wave_barrier();
-        double* dst = p.out.obs + (size_t)blockIdx.x * 64 * OBS_DIM;
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) dst[k * 64 + lane] = obs_tile[k * 64 + lane];
-      } else {
-#pragma unroll
-        for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-      }
-    }
-  }
-  if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
-    if (p.out.terminal_obs) {
-#pragma unroll
-      for (int k = 0; k < OBS_DIM; k++) p.out.terminal_obs[(size_t)i * OBS_DIM + k] = obs[k];
-    }
-    State fresh = episode_init(p.rng, i);
-    store_state(p, i, fresh);
-    p.flags[i] = 0;
-    fk(fresh.q, c);
-    make_obs(fresh, c, obs);
-    if (p.out.obs) {
-#pragma unroll
-      for (int k = 0; k < OBS_DIM; k++) p.out.obs[(size_t)i * OBS_DIM + k] = obs[k];
-    }
-    if (p.out.ncon) p.out.ncon[i] = count_floor_contacts(c);
-  }
-  MJS_STAMP(p, 5);
+  finish_step(p, i, lane, st, cs, sn, flags, warm_out, StepEnd{solo, bad, rows_active, overflow}, obs_tile);
 }
 
 

@@ -32,6 +32,7 @@ struct mjs_handle {
   uint32_t* bg_rgb = nullptr;
   int bg_H = 0, bg_W = 0;
   float* cams;                 // [N][12] wrist-camera poses (Button-Push)
+  double* ws = nullptr;        // [rr::WS_ROWS][N] contact workspace of the general constraint stage (Robot-Reach, Button-Push)
   std::string err;
 };
 
@@ -101,11 +102,17 @@ __global__ void get_state_kernel(const double* state, const uint8_t* flags, doub
   for (int k = 0; k < S; k++) out[(size_t)k * N + i] = state[(size_t)k * N + i];
   out[(size_t)S * N + i] = (double)flags[i];
 }
-__global__ void set_state_kernel(double* state, uint8_t* flags, const double* in, int N, int S) {
+__global__ void set_state_kernel(double* state, uint8_t* flags, const double* in, int N, int S, int task) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   for (int k = 0; k < S; k++) state[(size_t)k * N + i] = in[(size_t)k * N + i];
-  flags[i] = (uint8_t)in[(size_t)S * N + i];
+  uint8_t f = (uint8_t)in[(size_t)S * N + i];
+  if (task == MJS_TASK_ROBOT_REACH) {  // FLAG_CLEAR is a function of the joints, which the caller may have edited
+    double q[rr::NJ];
+    for (int j = 0; j < rr::NJ; j++) q[j] = in[(size_t)(rr::S_Q + j) * N + i];
+    f = (uint8_t)((f & ~FLAG_CLEAR) | (rr::config_is_clear(q) ? FLAG_CLEAR : 0));
+  }
+  flags[i] = f;
 }
 
 __global__ void debug_ik_kernel(const double* T, const double* guess, double* q, uint8_t* ok, int n) {
@@ -146,6 +153,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
+  p.ws = h->ws;
   p.rng = DevRng{h->rng_mt, h->rng_pos, h->cfg.num_envs};
   p.actions = actions;
   p.reset_mask = mask;
@@ -187,7 +195,9 @@ extern "C" {
 #ifndef MJS_SOURCE_HASH
 #define MJS_SOURCE_HASH "unhashed"  // the in-tree build (mujoco_sim_amd/_native.py) passes -DMJS_SOURCE_HASH=<sha256 of csrc/ + include/>
 #endif
-const char* mjs_version(void) { return "mjsim-hip 0.2 (gfx950, abi 1) src=" MJS_SOURCE_HASH; }
+#define MJS_STR2(x) #x
+#define MJS_STR(x) MJS_STR2(x)
+const char* mjs_version(void) { return "mjsim-hip 0.3 (gfx950, abi " MJS_STR(MJS_ABI_VERSION) ") src=" MJS_SOURCE_HASH; }
 
 int mjs_obs_dim(int task) {
   return task == MJS_TASK_POINTMASS_REACH ? pm::OBS_DIM : task == MJS_TASK_ROBOT_REACH ? rr::OBS_DIM : task == MJS_TASK_BUTTON_PUSH ? bp::OBS_DIM : task == MJS_TASK_PLANAR_PUSH ? pp::OBS_DIM : -1;
@@ -212,11 +222,11 @@ int mjs_algorithmic_bytes_per_env_step(int task) {
   if (task == MJS_TASK_POINTMASS_REACH)
     return 8 * pm::STATE_DIM /*R*/ + 8 * (pm::STATE_DIM - 2) /*W: target unchanged*/ + 2 + 8 * pm::ACT_DIM + 8 * pm::OBS_DIM + out_fixed;
   if (task == MJS_TASK_ROBOT_REACH)
-    return 8 * rr::STATE_DIM /*R*/ + 8 * (rr::STATE_DIM - 3) /*W: target unchanged*/ + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;
+    return 8 * rr::HOT_STATE_DIM /*R*/ + 8 * (rr::HOT_STATE_DIM - 3) /*W: target unchanged*/ + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;  // the qacc_warmstart rows are only touched by the robust path
   if (task == MJS_TASK_PLANAR_PUSH)  // everything but the target is rewritten
     return 8 * pp::STATE_DIM /*R*/ + 8 * (pp::STATE_DIM - 3) /*W*/ + 2 + 8 * pp::ACT_DIM + 8 * pp::OBS_DIM + out_fixed;
   if (task == MJS_TASK_BUTTON_PUSH)
-    return 8 * bp::STATE_DIM /*R*/ + 8 * (bp::STATE_DIM - 3) /*W: switch pose unchanged*/ + 2 + 8 * bp::ACT_DIM_JOINT + 8 * bp::OBS_DIM + out_fixed;
+    return 8 * bp::HOT_STATE_DIM /*R*/ + 8 * (bp::HOT_STATE_DIM - 3) /*W: switch pose unchanged*/ + 2 + 8 * bp::ACT_DIM_JOINT + 8 * bp::OBS_DIM + out_fixed;
   return -1;
 }
 
@@ -225,6 +235,8 @@ const char* mjs_last_error(const mjs_handle* h) { return h ? h->err.c_str() : g_
 int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (!cfg || !out) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: null argument");
   *out = nullptr;
+  if (cfg->struct_size != sizeof(mjs_config))
+    return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: mjs_config.struct_size does not match this library's header (abi " MJS_STR(MJS_ABI_VERSION) "): the caller was built against another include/mjsim.h");
   if (cfg->task != MJS_TASK_POINTMASS_REACH && cfg->task != MJS_TASK_ROBOT_REACH && cfg->task != MJS_TASK_BUTTON_PUSH && cfg->task != MJS_TASK_PLANAR_PUSH)
     return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: unknown task id");
   if (mjs_action_dim_for(cfg->task, cfg->action_type) < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad action_type");
@@ -277,6 +289,8 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::PP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
+  if (e == hipSuccess && (cfg->task == MJS_TASK_ROBOT_REACH || cfg->task == MJS_TASK_BUTTON_PUSH))  // 2.3 KB per env, touched by the robust path only
+    e = hipMalloc(&h->ws, sizeof(double) * rr::WS_ROWS * N);
 #ifdef MJS_STAMPS
   if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * N);  // one slot block per workgroup, at most N workgroups
   if (e == hipSuccess) e = hipMemset(h->stamps, 0, sizeof(unsigned long long) * 16 * N);
@@ -342,6 +356,7 @@ void mjs_destroy(mjs_handle* h) {
   if (h->bg_ray) (void)hipFree(h->bg_ray);
   if (h->bg_rgb) (void)hipFree(h->bg_rgb);
   if (h->cams) (void)hipFree(h->cams);
+  if (h->ws) (void)hipFree(h->ws);
   delete h;
 }
 
@@ -518,7 +533,7 @@ int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
   DeviceGuard dev_(h->cfg.device);
   HIP_TRY(h, dev_.err);
   h->prims_valid = false;
-  set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim);
+  set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim, h->cfg.task);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }

@@ -205,6 +205,7 @@ void om_render_robot(const om_env* e, int H, int W, uint8_t* out);
 void om_render_camera(const om_env* e, int camera, int H, int W, uint8_t* out);
 void om_debug_button_dynamics(const double* q, const double* v, double* M_out, double* bias_out, double* invw_out);
 void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
+void om_debug_link_invweights(int task, double* out7);
 int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time);
 int om_debug_arm_floor_seen(om_env* e);
 void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale);

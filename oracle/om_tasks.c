@@ -695,6 +695,16 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
   for (int i = 0; i < 6; i++) invw_out[3 + i] = m.dof_invweight0[i];
 }
 
+/* debug hook for tests: body_invweight0 (translation) of the UR5e's own bodies (base, links 1..6) in the model of `task`
+ * (what mj_makeImpedance uses as diagApprox for a contact of one of the arm's collision geoms with the static floor) */
+void om_debug_link_invweights(int task, double* out7) {
+  static __thread om_model m;
+  if (task == OM_TASK_BUTTON_PUSH) build_button(&m);
+  else if (task == OM_TASK_PLANAR_PUSH) build_push(&m, 2);
+  else build_robot(&m, 1);
+  for (int k = 0; k < 7; k++) out7[k] = m.body_invweight0[1 + k][0];
+}
+
 /* debug hook for tests: give block `i` of a Planar-Push env the mesh `cat` at `scale` (as initialize_episode_mjcf would) */
 void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale) {
   e->block_cat[i] = cat; e->block_color[i] = color; e->block_scale[i] = scale;

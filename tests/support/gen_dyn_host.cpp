@@ -23,4 +23,9 @@ void gen_constants(int variant, double* out) {
   out[7] = variant == 0 ? UR5E_EEF_BODY_INVWEIGHT0[0] : UR5E_BP_EEF_BODY_INVWEIGHT0[0];
   out[8] = variant == 0 ? UR5E_EEF_BODY_INVWEIGHT0[1] : UR5E_BP_EEF_BODY_INVWEIGHT0[1];
 }
+// body_invweight0 (translation) of the arm's own link bodies 0..6, emitted for the arm-floor contact rows: variant 0 Reach,
+// 1 Button-Push, 2 Planar-Push
+void gen_link_invweights(int variant, double* out7) {
+  for (int b = 0; b < 7; b++) out7[b] = variant == 0 ? UR5E_LINK_BODY_INVWEIGHT0[b] : variant == 1 ? UR5E_BP_LINK_BODY_INVWEIGHT0[b] : UR5E_PP_LINK_BODY_INVWEIGHT0[b];
+}
 }

@@ -55,6 +55,8 @@ def test_static_queries(native):
     # algorithmic bytes per env-step, recomputed from the SoA layout
     assert L.mjs_algorithmic_bytes_per_env_step(0) == 8 * 13 + 8 * 11 + 2 + 16 + 32 + 25
     assert L.mjs_algorithmic_bytes_per_env_step(1) == 8 * 16 + 8 * 13 + 2 + 24 + 96 + 25
+    # state blocks (rows + the flag row): Robot-Reach q6 v6 time target3 qacc_warmstart6; Button-Push q6 v6 time switch3 gripper2 qacc_warmstart6
+    assert (L.mjs_state_dim(1), L.mjs_state_dim(3)) == (23, 25)
 
 
 def test_create_rejects_bad_arguments(native):
@@ -71,6 +73,10 @@ def test_create_rejects_bad_arguments(native):
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"n_objects" in L.mjs_last_error(None)
     cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=7)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"autoreset" in L.mjs_last_error(None)
+    # abi 2: a caller built against another header (different mjs_config) is refused before any field is read
+    cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=0, struct_size=C.sizeof(native.MjsConfig) - 4)
+    assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"struct_size" in L.mjs_last_error(None)
+    assert b"abi 2" in L.mjs_version()
 
 
 def test_no_cpu_fallback_without_gpu(native):

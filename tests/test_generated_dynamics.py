@@ -45,3 +45,16 @@ def test_generated_dynamics_match_generic_engine(oracle_mod, gen_lib, variant):
         np.testing.assert_allclose(g[7:9], consts[0:2], rtol=1e-12)   # EEF body invweight0
         np.testing.assert_allclose(g[6], consts[2], rtol=1e-12)       # meaninertia
         np.testing.assert_allclose(g[0:6], consts[3:9], rtol=1e-12)   # dof_invweight0
+
+
+@pytest.mark.parametrize("variant,task", [(0, 1), (1, 3), (2, 2)])
+def test_generated_link_body_invweights_match_generic_engine(oracle_mod, gen_lib, variant, task):
+    """The arm-floor contact rows (mjs_arm_stage.h) take their diagApprox from <V>_LINK_BODY_INVWEIGHT0: the generator's
+    values against the oracle's mj_setConst on the full model of each scene (base and shoulder link: 0 / mjMINVAL, their
+    COMs sit on the first joint's axis at qpos0)."""
+    L = oracle_mod.lib()
+    g, o = np.zeros(7), np.zeros(7)
+    gen_lib.gen_link_invweights(variant, g.ctypes.data_as(C.c_void_p))
+    L.om_debug_link_invweights(task, o.ctypes.data_as(C.c_void_p))
+    np.testing.assert_allclose(np.maximum(g, 1e-15)[2:], o[2:], rtol=1e-10)
+    assert (o[:2] <= 1e-12).all() and (g[:2] <= 1e-12).all(), (o, g)
