@@ -93,9 +93,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
         return LIB_PATH
     LIB_PATH.parent.mkdir(parents=True, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # max-ilp: the kernels run one wavefront per SIMD, so schedule for ILP, not occupancy (+2% measured)
+    # max-ilp: the kernels run one wavefront per SIMD, so schedule for ILP, not occupancy (+2% measured).
+    # enable-ipra=0: with inter-procedural register allocation the call to the (rare, register-hungry) robust path clobbers every
+    # AGPR in the step kernels' eyes, and their hot loops then spill to scratch instead of to AGPRs: Robot-Reach 39.7 -> 36.8 us,
+    # Button-Push 110.9 -> 93.9 us per launch (profiles/r03_c_ipra_ab.txt); Planar-Push / Pointmass unchanged.
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", f'-DMJS_SOURCE_HASH="{want}"',
+           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-enable-ipra=0", f'-DMJS_SOURCE_HASH="{want}"',
            "-o", str(LIB_PATH), str(_PKG / "csrc" / "mjsim.hip")]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:

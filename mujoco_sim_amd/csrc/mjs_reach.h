@@ -1078,25 +1078,6 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
   o.overflow = overflow;
   return o;
 }
-// hands the lane's state to solo_control_step and takes the result back (the persisted warm start is read here: only the
-// robust path touches those rows)
-#define MJS_RR_RUN_SOLO(FIRST_SUBSTEP, USE_PERSISTED_WARM)                                                                     \
-  do {                                                                                                                          \
-    SoloIn in_;                                                                                                                 \
-    _Pragma("unroll") for (int j = 0; j < NJ; j++) {                                                                            \
-      in_.q[j] = st.q[j]; in_.v[j] = st.v[j]; in_.q0[j] = q0[j]; in_.q1[j] = q1[j]; in_.cs[j] = cs[j]; in_.sn[j] = sn[j];        \
-      in_.warm[j] = (USE_PERSISTED_WARM) ? p.state[(size_t)(S_WARM + j) * p.N + i] : 0.0;                                       \
-    }                                                                                                                           \
-    in_.time = st.time; in_.t0 = t0; in_.t1 = t1;                                                                               \
-    in_.has_warm = (USE_PERSISTED_WARM) && (flags & FLAG_WARM_VALID);                                                           \
-    in_.first_substep = (FIRST_SUBSTEP);                                                                                        \
-    SoloOut o_ = solo_control_step(in_, Ws{p.ws, p.N, i});                                                                      \
-    _Pragma("unroll") for (int j = 0; j < NJ; j++) { st.q[j] = o_.q[j]; st.v[j] = o_.v[j]; cs[j] = o_.cs[j]; sn[j] = o_.sn[j]; warm_out[j] = o_.warm[j]; } \
-    st.time = o_.time;                                                                                                          \
-    bad = bad || o_.bad;                                                                                                        \
-    rows_active = o_.rows_active; overflow = o_.overflow;                                                                       \
-  } while (0)
-
 // What every variant of the step does once the 20 substeps are done (role 0 / the only wavefront): observables, reward,
 // termination, the a-posteriori checks, fault word, flags, state and output stores, same-step auto-reset.
 struct StepEnd {
@@ -1171,6 +1152,47 @@ MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, cons
   MJS_STAMP(p, 5);
 }
 
+// The robust path as a TAIL of the kernel: takes the lane's state by value, runs the remaining substeps on this one wavefront
+// (solo_control_step), and finishes the step itself (finish_step). The kernels call it and return, so the row-free fast path
+// keeps nothing live across a call: with the call in the middle of the kernel the register allocator spilt around it on the
+// fast path too (+3 us per launch at 4096 envs, profiles/r03_c_*). The persisted warm start (the state's qacc_warmstart rows)
+// is read here: only the robust path touches those rows.
+struct SoloTail {
+  State st;
+  double q0[NJ], q1[NJ], cs[NJ], sn[NJ], t0, t1;
+  uint8_t flags;
+  bool bad, use_persisted_warm;
+  int first_substep;
+};
+__device__ __noinline__ void solo_tail(KernelParams p, int i, int lane, SoloTail a, double* obs_tile) {
+  SoloIn in;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    in.q[j] = a.st.q[j]; in.v[j] = a.st.v[j]; in.q0[j] = a.q0[j]; in.q1[j] = a.q1[j]; in.cs[j] = a.cs[j]; in.sn[j] = a.sn[j];
+    in.warm[j] = a.use_persisted_warm ? p.state[(size_t)(S_WARM + j) * p.N + i] : 0.0;
+  }
+  in.time = a.st.time; in.t0 = a.t0; in.t1 = a.t1;
+  in.has_warm = a.use_persisted_warm && (a.flags & FLAG_WARM_VALID);
+  in.first_substep = a.first_substep;
+  const SoloOut o = solo_control_step(in, Ws{p.ws, p.N, i});
+  State st = a.st;
+  double cs[NJ], sn[NJ], warm_out[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { st.q[j] = o.q[j]; st.v[j] = o.v[j]; cs[j] = o.cs[j]; sn[j] = o.sn[j]; warm_out[j] = o.warm[j]; }
+  st.time = o.time;
+  finish_step(p, i, lane, st, cs, sn, a.flags, warm_out, StepEnd{true, a.bad || o.bad, o.rows_active, o.overflow}, obs_tile);
+}
+#define MJS_RR_SOLO_TAIL(FIRST_SUBSTEP, USE_PERSISTED_WARM)                                                                   \
+  do {                                                                                                                        \
+    SoloTail a_;                                                                                                              \
+    a_.st = st;                                                                                                               \
+    _Pragma("unroll") for (int j = 0; j < NJ; j++) { a_.q0[j] = q0[j]; a_.q1[j] = q1[j]; a_.cs[j] = cs[j]; a_.sn[j] = sn[j]; } \
+    a_.t0 = t0; a_.t1 = t1; a_.flags = flags; a_.bad = bad; a_.use_persisted_warm = (USE_PERSISTED_WARM);                    \
+    a_.first_substep = (FIRST_SUBSTEP);                                                                                       \
+    solo_tail(p, i, lane, a_, obs_tile);                                                                                      \
+    return;                                                                                                                   \
+  } while (0)
+
 // ROLES == 1: one wavefront steps 64 envs. ROLES == 2 (default for stepping): two wavefronts of
 // one workgroup, placed on different SIMDs of the CU, step the same 64 envs: role 0 builds M(q),
 // factorises the implicitfast matrix (U D U^T) and inverts U while role 1 evaluates the servo
@@ -1200,7 +1222,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 0);
   State st = load_state(p, i);
   // before_step: servoL (robot_reach.py:169 -> robot.py:218-259); evaluated by both roles (same result)
-  double q0[NJ], q1[NJ], act[3], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
+  double q0[NJ], q1[NJ], act[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
 #pragma unroll
@@ -1213,7 +1235,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   MJS_STAMP(p, 1);
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
-  bool bad = false, rows_active = false, overflow = false;
+  bool bad = false;
   double cs[NJ], sn[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
@@ -1222,7 +1244,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const bool solo = (ROLES == 1) || __any(unsafe);
   if (solo) {
     if (role != 0) return;
-    MJS_RR_RUN_SOLO(0, true);
+    MJS_RR_SOLO_TAIL(0, true);
   } else if constexpr (ROLES == 2) {
 #pragma unroll 1
     for (int s = 0; s < MJS_RR_NSUB; s++) {
@@ -1297,7 +1319,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     }
   }
   if (role != 0) return;
-  finish_step(p, i, lane, st, cs, sn, flags, warm_out, StepEnd{solo, bad, rows_active, overflow}, obs_tile);
+  finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false}, obs_tile);
 }
 
 
@@ -1358,7 +1380,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   }
   MJS_STAMP(p, 0);
   State st = load_state(p, i);
-  double q0[NJ], q1[NJ], act[3], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
+  double q0[NJ], q1[NJ], act[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) act[k] = p.actions[(size_t)i * ACT_DIM + k];
 #pragma unroll
@@ -1369,7 +1391,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   bool solo = __any(joint_near_range(st.q, st.v) || !(flags & FLAG_CLEAR) || !action_in_box(act));
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT;
   const double inv_span = 1.0 / (t1 - t0);
-  bool bad = false, rows_active = false, overflow = false;
+  bool bad = false;
   double cs[NJ], sn[NJ];
   if (solo) {
     if (wave != 0) return;
@@ -1381,7 +1403,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
     }
 #pragma unroll
     for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
-    MJS_RR_RUN_SOLO(0, true);
+    MJS_RR_SOLO_TAIL(0, true);
   } else {
     if (wave == 2) {
       // before_step: servoL (robot_reach.py:169 -> robot.py:218-259)
@@ -1440,8 +1462,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
     // rows: the start configuration was clear and no joint near its range). Both dynamics wavefronts hold the same numbers.
     if (__any(travel_is_long(q0, q1, v_start))) {
       if (role != 0) return;
-      solo = true;
-      MJS_RR_RUN_SOLO(1, false);  // no warm start across the hand-over: the first robust substep has no rows (guard), later ones start from it
+      MJS_RR_SOLO_TAIL(1, false);  // no warm start across the hand-over: the first robust substep has no rows (guard), later ones start from it
     } else {
 #pragma unroll 1
       for (int s = 1; s < MJS_RR_NSUB; s++) {
@@ -1512,7 +1533,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
       if (role == 1) return;  // (the floor-contact count it used to take here is a by-product of role 0's clearance bound now)
     }
   }
-  finish_step(p, i, lane, st, cs, sn, flags, warm_out, StepEnd{solo, bad, rows_active, overflow}, obs_tile);
+  finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false}, obs_tile);
 }
 
 

@@ -20,7 +20,8 @@ res = {n: [] for n, _, _ in arms}
 for r in range(rounds):
     for name, path, variant in arms:
         env = dict(os.environ, MJS_LIB=str(Path(path).resolve()))
-        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--steps", "1500", "--warmup", "100", "--no-cpu-baseline", "--variant", variant],
+        extra = os.environ.get("AB_ARGS", "--steps 1500 --warmup 100").split()  # e.g. AB_ARGS="--task robot_push_button --steps 500 --warmup 50"
+        out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *extra, "--no-cpu-baseline", "--variant", variant],
                              env=env, capture_output=True, text=True)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         d = json.loads(line)

@@ -34,7 +34,7 @@ def main():
     out = ROOT / "ab" / f"libmjsim_{name}.so"
     out.parent.mkdir(exist_ok=True)
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment", "-mllvm",
-           "-amdgpu-sched-strategy=max-ilp", f'-DMJS_SOURCE_HASH="ab-{name}"', *flags, "-o", str(out), str(tmp / "mujoco_sim_amd" / "csrc" / "mjsim.hip")]
+           "-amdgpu-sched-strategy=max-ilp", *([] if "--ipra" in flags else ["-mllvm", "-enable-ipra=0"]), f'-DMJS_SOURCE_HASH="ab-{name}"', *[f for f in flags if f != "--ipra"], "-o", str(out), str(tmp / "mujoco_sim_amd" / "csrc" / "mjsim.hip")]
     subprocess.run(cmd, check=True)
     shutil.rmtree(tmp)
     print(out)
