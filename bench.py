@@ -50,7 +50,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--task", default="robot_reach", choices=["robot_reach", "point_mass_reach", "robot_push_button", "robot_planar_push"])
-    ap.add_argument("--envs-per-gpu", type=int, default=4096)
+    ap.add_argument("--envs-per-gpu", type=int, default=4096, help="weak scaling: envs per GPU; strong scaling: envs of the WHOLE job (split over the ranks)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default): --envs-per-gpu envs on every GPU; strong: --envs-per-gpu envs in total, 1/N of them per rank "
+                         "(north_star's '4096 parallel Robot-Reach envs at 1/2/4/8 MI355X' read literally)")
     ap.add_argument("--n-objects", type=int, default=2, help="Planar-Push blocks: 2 = BASELINE config 4, 5 = the reference's dataclass default")
     ap.add_argument("--block-shape", default="mesh", choices=["mesh", "box"], help="Planar-Push blocks: the reference's meshes (default) or round 1's box stand-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -115,6 +118,82 @@ def cpu_baseline(task, n_envs, seconds, n_objects=2, block_shape="mesh"):
             "sample": f"{n_envs} envs x {steps} control steps ({dt:.1f} s), oracle/ C restatement, OpenMP over envs"}
 
 
+def mujoco_probe():
+    """Is a real MuJoCo importable on THIS box (SURVEY section 8c last row, BASELINE.md baseline A)? Asked with find_spec only:
+    nothing of the reference travels, and nothing is imported unless it is there. Round 3's answer on the GPU pool: absent
+    (profiles/r03_a_mujoco_probe.txt), so the CPU column is the oracle (kind "port") and the physics stay parity-unpinned."""
+    import importlib.util
+
+    found = {}
+    for mod in ("mujoco", "dm_control"):
+        try:
+            found[mod] = importlib.util.find_spec(mod) is not None
+        except Exception:  # noqa: BLE001
+            found[mod] = False
+    out = {"mujoco_on_box": found["mujoco"], "dm_control_on_box": found["dm_control"]}
+    if found["mujoco"]:
+        try:
+            import mujoco  # noqa: PLC0415
+
+            out["mujoco_version"] = getattr(mujoco, "__version__", "?")
+            out["mujoco_pointmass"] = mujoco_pointmass_baseline(mujoco)
+        except Exception as e:  # noqa: BLE001
+            out["mujoco_error"] = repr(e)[:200]
+    return out
+
+
+def mujoco_pointmass_baseline(mujoco, seconds=5.0):
+    """Baseline A on the build's OWN MJCF of the Pointmass scene (tests/golden/pointmass_scene.xml, authored from
+    walled_pointmass_arena.xml:11-20, pointmass.py:52-66, point_reach.py:79-93): raw mj_step rate of one MjData on one host
+    thread (dmc2gym.py:136's Physics.step without the Python around it). Only runs where `import mujoco` works."""
+    model = mujoco.MjModel.from_xml_path(str(ROOT / "tests" / "golden" / "pointmass_scene.xml"))
+    data = mujoco.MjData(model)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(1000):
+            mujoco.mj_step(model, data)
+        n += 1000
+    dt = time.perf_counter() - t0
+    return {"mj_steps_per_s": n / dt, "env_steps_per_s": n / dt / 5, "cores": 1, "sample": f"{n} mj_step calls, 1 MjData, 1 thread"}
+
+
+def single_env_figures(device, n_steps=2000):
+    """BASELINE config 1 in the reference's own style (environments/tasks/utils.py:6-17: n_steps iterations of
+    `reset if done else step(action_space.sample())`, resets included, seconds per iteration): Pointmass-Reach, ONE env,
+    through the single-env adapter. (a) the HIP path behind the reference's DMCEnvironmentAdapter surface (one kernel launch +
+    one device->host read-back per step: host-bound); (b) the oracle, one env, one host thread, called from Python."""
+    import mujoco_sim_amd as m
+    import oracle
+
+    env = m.make("mujoco_sim/point_mass_reach_state-v0", device=str(device))
+    env.seed(2025)
+    done, t0 = True, time.perf_counter()
+    for _ in range(n_steps):
+        if done:
+            env.reset()
+            done = False
+        else:
+            _, _, term, trunc, _ = env.step(env.action_space.sample())
+            done = term or trunc
+    hip = (time.perf_counter() - t0) / n_steps
+    env.close()
+    ob = oracle.OracleBatch(oracle.TASK_POINTMASS, 1, 2025, nthreads=1, autoreset=2)
+    rs = np.random.RandomState(2025)
+    done, t0 = True, time.perf_counter()
+    for _ in range(n_steps):
+        if done:
+            ob.reset()
+            done = False
+        else:
+            o = ob.step(rs.uniform(-0.05, 0.05, (1, 2)).astype(np.float32).astype(np.float64))
+            done = bool(o["step_type"][0] == 2)
+    cpu = (time.perf_counter() - t0) / n_steps
+    return {"workload": f"Pointmass-Reach, 1 env, {n_steps} iterations of reset-if-done-else-random-step (tasks/utils.py:6-17)",
+            "hip_adapter_s_per_step": hip, "hip_adapter_env_steps_per_s": 1.0 / hip,
+            "oracle_s_per_step": cpu, "oracle_env_steps_per_s": 1.0 / cpu,
+            "note": "HIP: one launch + read-back per step behind DMCEnvironmentAdapter (host-bound); oracle: the C restatement, 1 thread, via ctypes"}
+
+
 class _StubVectorEnv:
     """Launcher self-test stand-in (``--stub``, CPU, gloo): the same surface bench.py drives, NO physics and no GPU.
     Its only purpose is to let a GPU-less test exercise the rank fan-out, the barrier / max-over-ranks timing and the
@@ -150,6 +229,10 @@ def launch_ranks(args) -> int:
     import socket
     import subprocess
 
+    if not args.stub:  # compile once here (hipcc only, no GPU): N children would otherwise race N links to the same output path
+        from mujoco_sim_amd import _native
+
+        _native.build()
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -159,14 +242,32 @@ def launch_ranks(args) -> int:
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL needs it)
         procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    import threading
+
     out0, rc = "", 0
     deadline = time.time() + float(os.environ.get("MJS_BENCH_LAUNCH_TIMEOUT", "1500"))
-    try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.time()))
-        for p in procs:
-            p.wait(timeout=max(1.0, deadline - time.time()))
-    except subprocess.TimeoutExpired:
-        rc = 124
+    chunks: list[str] = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # drain rank 0's pipe while polling
+    reader.start()
+    # poll ALL children: the first rank that dies ends the job at once (its siblings would otherwise sit in the rendezvous
+    # until the timeout), each remaining child is stopped by its own handle
+    while True:
+        codes = [p.poll() for p in procs]
+        if all(c is not None for c in codes):
+            break
+        if any(c not in (None, 0) for c in codes):
+            break
+        if time.time() > deadline:
+            rc = 124
+            break
+        time.sleep(0.05)
+    for p in procs:
+        if p.poll() is None and (rc or any(c not in (None, 0) for c in codes)):
+            p.kill()
+    for p in procs:
+        p.wait()
+    reader.join(timeout=10)
+    out0 = "".join(chunks)
     for r, p in enumerate(procs):
         if p.poll() is None:  # a rank outlived a failed / timed-out sibling: stop exactly that child
             p.kill()
@@ -192,7 +293,12 @@ def main():
     rank, local_rank, world = D.init_process_group(backend="gloo" if args.stub else None)
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
-    n_local = args.envs_per_gpu
+    if args.scaling == "strong":  # the job's env count is fixed, every rank takes 1/N of it (global seeds as always)
+        if args.envs_per_gpu % world:
+            raise SystemExit(f"bench.py: --scaling strong needs --envs-per-gpu ({args.envs_per_gpu}) divisible by --gpus ({world})")
+        n_local = args.envs_per_gpu // world
+    else:
+        n_local = args.envs_per_gpu
     n_global = n_local * world
     if args.stub:
         device = torch.device("cpu")
@@ -285,12 +391,14 @@ def main():
                        "robot_push_button": "env-steps/sec, Button-Push (" + (f"scene + wrist camera {args.visual}x{args.visual}" if cams else "state obs") + ")",
                        "robot_planar_push": f"env-steps/sec, Planar-Push, {args.n_objects} objects (state obs)"}[args.task],
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task}: {n_local} envs per GPU, {substeps} substeps/step, "
                                    f"{'state obs' if not cams else 'visual obs'}, {'joint targets q_home +- U(0.2) + gripper opening U(0, 0.085)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
                                    + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
-                       "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step"},
+                       "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step",
+                       "scaling_mode": ("weak: envs_per_gpu fixed, envs_total grows with the GPU count" if args.scaling == "weak" else
+                                        "strong: envs_total fixed, envs_per_gpu = envs_total / n_gpus (a launch is latency-bound below ~16k envs per GPU: expect ~1x)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
@@ -318,6 +426,9 @@ def main():
                 pass
         if world == 1 and not args.no_cpu_baseline and not args.stub:
             line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects, args.block_shape)
+            line["cpu_baseline"].update(mujoco_probe())  # "mujoco_on_box": asked on every run, acted on only when true
+            if args.task == "robot_reach":
+                line["config1_single_env"] = single_env_figures(device)
         print(json.dumps(line))
     venv.close()
     if torch.distributed.is_initialized():

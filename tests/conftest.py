@@ -10,6 +10,7 @@ if str(ROOT) not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "mujoco: pins the oracle to a real MuJoCo; the physics part skips where the `mujoco` wheel is absent")
 
 
 @pytest.fixture(scope="session")

@@ -167,6 +167,32 @@ def test_bench_gpus2_launches_its_own_ranks():
         assert res.returncode != 0 and "rank" in res.stderr
 
 
+def test_bench_strong_scaling_mode_splits_a_fixed_env_count():
+    """`bench.py --scaling strong --gpus 2`: north_star's "4096 parallel Robot-Reach envs at 1/2/4/8 MI355X" read literally,
+    the job's env count stays 4096 and every rank steps 4096 / N of them (the reference's fan-out keeps the env count of the
+    job fixed too: scripts/sb3/reach_sac.py:93-96 builds num_envs sub-envs whatever the worker count). Stub ranks, gloo."""
+    import json
+    import subprocess
+    import sys
+    import time
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "4", "--warmup", "1", "--scaling", "strong"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2
+    assert line["config"]["envs_total"] == 4096 and line["config"]["envs_per_gpu"] == 2048
+    assert line["rollout_gather"]["bytes_per_rank"] == 64 * 2048 * 12 * 8
+    assert abs(line["value"] - 4 * 4096 / (line["ms_per_step"] * 4 * 1e-3)) < 1e-6 * line["value"]
+    # an env count the ranks cannot split evenly is refused by every rank, and the launcher reports it at once (it polls all
+    # of its children instead of waiting for rank 0's rendezvous to time out)
+    t0 = time.time()
+    res = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--stub", "--steps", "1", "--warmup", "0", "--scaling", "strong",
+                          "--envs-per-gpu", "4097"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and "divisible" in res.stderr and time.time() - t0 < 120
+
+
 def test_lerobot_recorder_schema_and_round_trip(tmp_path):
     """Recorder with the reference collector's conventions (scripts/demonstration_collection.py:39-167): feature names,
     '/' -> '_' key mapping, observation.images.* for image keys, observation.state = concatenated state keys; LeRobot
