@@ -23,8 +23,8 @@ extern "C" {
 #endif
 
 /* 2 (round 3): mjs_config starts with struct_size (validated by mjs_create: a caller built against another header is refused
- * instead of being read past its end); Robot-Reach / Button-Push state blocks grew 6 rows (qacc_warmstart): checkpoints of abi 1
- * do not fit mjs_set_state any more (mjs_state_dim reports the new widths). */
+ * instead of being read past its end); Robot-Reach / Button-Push state blocks grew 18 rows (qacc_warmstart, carried cos / sin):
+ * checkpoints of abi 1 do not fit mjs_set_state any more (mjs_state_dim reports the new widths). */
 #define MJS_ABI_VERSION 2
 
 /* tasks (environments/tasks/*.py) */
@@ -51,6 +51,11 @@ enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_D
  * the single-wavefront step kernels of Robot-Reach / Button-Push (default: two role-specialised wavefronts) and the
  * 8x8-tile camera kernel for every image (default: the rectangle walk for images up to 64x64) */
 enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1, MJS_VARIANT_TWO_ROLES = 2 /* Robot-Reach: round 1's two-wavefront kernel */ };
+/* Shard invariance (env i of a sharded job == env i of the whole job, global seeds via env_index_offset) is BITWISE as long as
+ * every handle of the comparison launches the same kernel. Robot-Reach with MJS_VARIANT_DEFAULT switches kernels at 16384 envs
+ * per handle (three-wavefront kernel up to there, the two-role kernel above: same results to rounding only), so shards of at
+ * most 16384 envs are bit-identical to each other and to any whole job of at most 16384; pin kernel_variant to compare across
+ * that size. All other tasks use one kernel at every size. */
 /* mjs_outputs.fault bits */
 enum {
   MJS_FAULT_BAD_STATE = 1,            /* NaN / huge qpos, qvel or qacc: dm_control's PhysicsError path (episode ends, reward 0, discount 0) */
@@ -131,8 +136,10 @@ int mjs_action_dim(int task);
 /* action width for a task + MJS_ACTION_* pair (Button-Push: 7 or 4); equals mjs_action_dim otherwise */
 int mjs_action_dim_for(int task, int action_type);
 /* number of float64 per env in mjs_get_state / mjs_set_state: the task's state rows + 1 (the flag byte as a double, last row).
- * Robot-Reach: q6, v6, time, target3, qacc_warmstart6; Button-Push: q6, v6, time, switch position3, gripper driver angle and
- * velocity, qacc_warmstart6. mjs_set_state recomputes the flags that are functions of the configuration. */
+ * Robot-Reach: q6, v6, time, target3, qacc_warmstart6, cos6, sin6; Button-Push: q6, v6, time, switch position3, gripper driver
+ * angle and velocity, qacc_warmstart6, cos6, sin6. cos / sin are the kernels' carried cache of the joint angles: mjs_set_state
+ * keeps rows that belong to the given q (a checkpoint resumes bit for bit) and rewrites them with exact values otherwise (a
+ * caller that edits q need not touch them); it also recomputes the flags that are functions of the configuration. */
 int mjs_state_dim(int task);
 /* the same two widths for a created handle: Planar-Push with n_objects 3..5 uses 5 block slots
  * (obs 5 + 2*5 = 15, state 1 + 17 + 13*5 = 83); the per-task queries above describe the 2-slot layout */

@@ -24,7 +24,9 @@ namespace bp {
 
 using rr::NJ;
 constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16, HOT_STATE_DIM = 18;  // S_GRIP: driver angle, velocity of the reduced 2F-85
-constexpr int S_WARM = 18, STATE_DIM = 24;  // rows 18-23: qacc_warmstart, robust path only (see rr::S_WARM)
+constexpr int S_WARM = 18;  // rows 18-23: qacc_warmstart, robust path only (see rr::S_WARM)
+constexpr int S_CS = 24, S_SN = 30, STATE_DIM = 36;  // rows 24-35: the carried cos / sin of the joint angles (see rr::S_CS)
+constexpr int HOT_ROWS_READ = 18 + 12, HOT_ROWS_WRITTEN = 15 + 12;
 constexpr int OBS_DIM = 13, ACT_DIM_JOINT = 7, ACT_DIM_EEF = 4;
 enum { FLAG_SWITCH_ACTIVE = 4, FLAG_SWITCH_PRESSED = 8 };
 
@@ -837,7 +839,13 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
     rr::store_warm(p, i, S_WARM, nullptr);
     p.flags[i] = r.flags;
-    rr::fk(r.st.q, c);
+    {
+      double cs[NJ], sn[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(r.st.q[j], &sn[j], &cs[j]);
+      rr::store_cs(p, i, S_CS, cs, sn);
+      rr::fk_cs(cs, sn, c);
+    }
     make_obs(r.st, c, r.flags, obs);
     write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, r.ncon);
     return;
@@ -868,8 +876,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const double t0 = st.time, t1 = st.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
   bool bad = false, rows_active = false, slot_overflow = false;
   double cs[NJ], sn[NJ], warm_out[NJ] = {0, 0, 0, 0, 0, 0};
-#pragma unroll
-  for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+  rr::load_cs(p, i, S_CS, cs, sn);
   rr::fk_cs(cs, sn, c);
   // Which path? Both roles evaluate the same predicates on the same data, so the decisions agree without an exchange.
   // The arm's own geoms and the floor (the registered action space is +-3.14 rad on every joint, robot_push_button.py:193-203):
@@ -1023,6 +1030,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0) | (solo ? FLAG_WARM_VALID : 0));
   rr::store_state(p, i, st);
+  rr::store_cs(p, i, S_CS, cs, sn);
   if (solo) rr::store_warm(p, i, S_WARM, warm_out);
   p.state[(size_t)S_GRIP * p.N + i] = grip.th;
   p.state[(size_t)(S_GRIP + 1) * p.N + i] = grip.vel;
@@ -1039,7 +1047,13 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
     rr::store_warm(p, i, S_WARM, nullptr);
     p.flags[i] = r.flags;
-    rr::fk(r.st.q, c);
+    {
+      double cs2[NJ], sn2[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) sincos(r.st.q[j], &sn2[j], &cs2[j]);
+      rr::store_cs(p, i, S_CS, cs2, sn2);
+      rr::fk_cs(cs2, sn2, c);
+    }
     make_obs(r.st, c, r.flags, obs);
     if (p.out.obs) {
 #pragma unroll

@@ -33,7 +33,13 @@ namespace rr {
 constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, HOT_STATE_DIM = 16;
 // rows 16-21: qacc_warmstart (mjData state: the solver acceleration of the last Physics.step()). Only the robust path reads or
 // writes them (flag FLAG_WARM_VALID says whether they belong to the current state); the row-free fast path never touches them.
-constexpr int S_WARM = 16, STATE_DIM = 22;
+constexpr int S_WARM = 16;
+// rows 22-33: cos / sin of the six joint angles as the substep loop carries them (angle-addition updates, rotate_small): the step
+// kernels start from them instead of six sincos calls on the critical path of the prologue (-2.4 k cycles of 9 k on the two
+// dynamics wavefronts, profiles/r03_d_*). A cache of q, not state of its own: resets and mjs_set_state (when the rows do not
+// belong to the given q) write exact values; the loaded pair is re-normalised, so rounding cannot accumulate in its length.
+constexpr int S_CS = 22, S_SN = 28, STATE_DIM = 34;
+constexpr int HOT_ROWS_READ = 16 + 12, HOT_ROWS_WRITTEN = 13 + 12;  // per env-step on the row-free path (target rows are only read)
 constexpr int OBS_DIM = 12, ACT_DIM = 3, NJ = 6;
 constexpr double PI = 3.14159265358979323846;
 
@@ -759,8 +765,186 @@ MJS_DEV Aff flange_pose_of_tcp(const double* pos, const double* quat_xyzw, doubl
   T.t[2] = pos[2] - T.r[8] * tcp_z;
   return T;
 }
+// ---- the same search for the ONE orientation every task commands: TOP_DOWN_QUATERNION = (1, 0, 0, 0) scalar-last
+// (robot_reach.py:30, type_aliases.py:6-10), i.e. R = diag(1, -1, -1). With that rotation the closed form collapses
+// (derivation: sympy on the DH chain, T14 = T01^-1 T06 (T45 T56)^-1):
+//   cos(theta5) = (tx s1 - ty c1 - d4) / d6 = 0 up to rounding  =>  theta5 = +-pi/2, sin(theta5) = +-1
+//   theta6 = atan2(-c1 / s5, s1 / s5) = theta1 -+ pi/2,  cos / sin(theta6) = (s1, -c1) * s5
+//   T14:  px = tx c1 + ty s1 - s5 d5,  py = tz + d6 - d1,  theta2 + theta3 + theta4 = s5 * pi/2
+// which removes two of the three acos, three of the five atan2, the 4x4 products and the divisions by sin(theta5) from the
+// candidate evaluation (the IK wavefront of kernel3 is the critical path of the step's prologue: the two dynamics wavefronts
+// wait for it). Same candidates, same visiting order, pruning and tie rule as ik_branch / the oracle's exhaustive loop; the
+// joint angles agree with the general formulas to a few ulp (atan2(-c1, s1) vs theta1 - pi/2). A target that is not top-down
+// to rounding (|cos theta5| >= 1e-8: never for this quaternion) is not handled here: the caller falls back to ik_closest.
+MJS_DEV bool ik_branch_top_down(double tx, double ty, double tz, const double* g, double psi, double phi, int s1, int s5p, int s3p, double& best, int& best_idx,
+                                double* q_out) {
+  const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
+  const double th1 = psi + (s1 ? -phi : phi) + 0.5 * PI;
+  double q0 = wrap_pi(th1);
+  const double p0 = joint_dist2(q0, g[0]);
+  if (p0 > best) return true;
+  double sn1, c1;
+  sincos(th1, &sn1, &c1);
+  bool ok5 = true;
+  const double c5 = clamp_unit((tx * sn1 - ty * c1 - d4) / d6, ok5);
+  if (!(fabs(c5) < 1e-8)) return false;  // not a top-down pose after all
+  const double ac5 = 0.5 * PI - c5;      // acos(x) = pi/2 - x - x^3/6 - ...: exact in double for |x| < 1e-8; sqrt(1 - x^2) = 1
+  const double py = tz + d6 - d1, c3den = 1.0 / (2 * a2 * a3);
+#pragma unroll 1
+  for (int b = 0; b < 2; b++) {
+    const int s5 = s5p ^ b;
+    const double sg5 = s5 ? -1.0 : 1.0;
+    double q4 = wrap_pi(sg5 * ac5);
+    const double p4 = joint_dist2(q4, g[4]);
+    if (p0 + p4 > best) continue;
+    double q5 = wrap_pi(th1 - sg5 * (0.5 * PI));
+    const double p5 = joint_dist2(q5, g[5]);
+    if (p0 + p4 + p5 > best) continue;
+    const double px = tx * c1 + ty * sn1 - sg5 * d5, r2 = px * px + py * py;
+    bool ok3 = true;
+    const double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) * c3den, ok3);
+    if (!ok3) continue;
+    const double ac3 = acos(c3), root3 = sqrt(fmax(0.0, 1.0 - c3 * c3));
+    const double base2 = atan2(py, px), at3 = atan2(a3 * root3, a2 + a3 * c3), th234 = sg5 * (0.5 * PI);
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const int s3 = s3p ^ c;
+      const double sg3 = s3 ? -1.0 : 1.0;
+      const double th3 = sg3 * ac3;
+      double q2 = wrap_pi(th3);
+      const double p2 = joint_dist2(q2, g[2]);
+      if (p0 + p4 + p5 + p2 > best) continue;
+      const double th2 = base2 - sg3 * at3;
+      const double th4 = th234 - th2 - th3;
+      double q1 = wrap_pi(th2), q3 = wrap_pi(th4);
+      if (!(isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3) && isfinite(q4) && isfinite(q5))) continue;
+      double dist = p0;  // same summation order as the exhaustive evaluation: joints 0..5
+      dist += joint_dist2(q1, g[1]);
+      dist += p2;
+      dist += joint_dist2(q3, g[3]);
+      dist += p4;
+      dist += p5;
+      const int idx = (s1 << 2) | (s5 << 1) | s3;
+      if (dist < best || (dist == best && idx < best_idx)) {
+        best = dist;
+        best_idx = idx;
+        q_out[0] = q0; q_out[1] = q1; q_out[2] = q2; q_out[3] = q3; q_out[4] = q4; q_out[5] = q5;
+      }
+    }
+  }
+  return true;
+}
+// returns 1 found, 0 no solution, -1 "not top-down to rounding" (the caller uses the general search)
+MJS_DEV int ik_closest_top_down_search(double tx, double ty, double tz, const double* g, double* q_out) {
+  const double d4 = MJS_UR_DH_D4;
+  const double rxy = sqrt(tx * tx + ty * ty);  // the wrist centre's xy is the flange's: R's z column is (0, 0, -1)
+  if (rxy < fabs(d4)) return 0;
+  const double psi = atan2(ty, tx), phi = acos(d4 / rxy);
+  double ta = wrap_pi(psi + phi + 0.5 * PI), tb = wrap_pi(psi - phi + 0.5 * PI);
+  const int s1p = joint_dist2(tb, g[0]) < joint_dist2(ta, g[0]) ? 1 : 0;
+  const int s5p = wrap_pi(g[4]) < 0 ? 1 : 0, s3p = wrap_pi(g[2]) < 0 ? 1 : 0;
+  double best = INFINITY;
+  int best_idx = 8;
+  bool top_down = true;
+#pragma unroll 1
+  for (int a = 0; a < 2; a++) top_down = ik_branch_top_down(tx, ty, tz, g, psi, phi, s1p ^ a, s5p, s3p, best, best_idx, q_out) && top_down;
+  return top_down ? (best_idx < 8 ? 1 : 0) : -1;
+}
+struct IkTd { double q[NJ]; int status; };
+__device__ __noinline__ IkTd ik_top_down_search_out_of_line(double tx, double ty, double tz, double g0, double g1, double g2, double g3, double g4, double g5) {
+  const double g[NJ] = {g0, g1, g2, g3, g4, g5};
+  IkTd o;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) o.q[j] = g[j];
+  o.status = ik_closest_top_down_search(tx, ty, tz, g, o.q);
+  return o;
+}
+// The common case in STRAIGHT-LINE code: the candidate on the guess's own branch (s1p, s5p, s3p) is evaluated in full, with
+// no loop and no divergence, and the other seven are excluded by LOWER BOUNDS of their joint distances that need no further
+// inverse trigonometry: theta1' (the other shoulder branch), theta5' = -theta5 and theta6' = theta1' -+ pi/2 are arithmetic,
+// and the other elbow branch of the same (theta1, theta5) is -theta3. A servo target near the current joints leaves every such
+// bound pi^2-ish above the winner. Whenever a bound does not exclude its candidates strictly (or the guess branch has no
+// solution) the lane asks for the full search (same winner: exact ties included, they go to the search); the caller runs it
+// out of line for the wavefronts that need it. Loops with per-candidate pruning cost more in exec-mask / scalar instructions
+// than in arithmetic: tools/ik_bench.py, profiles/r03_d_*.
+MJS_DEV int ik_closest_top_down(double tx, double ty, double tz, const double* g, double* q_out, bool& need_search) {
+  const double d1 = MJS_UR_DH_D1, a2 = MJS_UR_DH_A2, a3 = MJS_UR_DH_A3, d4 = MJS_UR_DH_D4, d5 = MJS_UR_DH_D5, d6 = MJS_UR_DH_D6;
+  need_search = false;
+  const double rxy = sqrt(tx * tx + ty * ty);
+  if (rxy < fabs(d4)) return 0;
+  const double psi = atan2(ty, tx), phi = acos(d4 / rxy);
+  double ta = wrap_pi(psi + phi + 0.5 * PI), tb = wrap_pi(psi - phi + 0.5 * PI);
+  const double pa = joint_dist2(ta, g[0]), pb = joint_dist2(tb, g[0]);
+  const int s1p = pb < pa ? 1 : 0;
+  const int s5p = wrap_pi(g[4]) < 0 ? 1 : 0, s3p = wrap_pi(g[2]) < 0 ? 1 : 0;
+  // ---- the guess's branch
+  const double th1 = psi + (s1p ? -phi : phi) + 0.5 * PI;
+  const double q0 = s1p ? tb : ta, p0 = s1p ? pb : pa, p0_other = s1p ? pa : pb;
+  // cos / sin(theta1) without a sincos call: theta1 = psi +- phi + pi/2 with (cos, sin) psi = (tx, ty) / rxy and
+  // (cos, sin) phi = (d4, sqrt(rxy^2 - d4^2)) / rxy; agrees with sincos(theta1) to 2 ulp (theta1 itself carries the atan2 / acos rounding)
+  const double inv_r = 1.0 / rxy, cps = tx * inv_r, sps = ty * inv_r, cph = d4 * inv_r;
+  const double sph = (s1p ? -1.0 : 1.0) * sqrt(fmax(0.0, 1.0 - cph * cph));
+  const double sn1 = cps * cph - sps * sph, c1 = -(sps * cph + cps * sph);  // sin(x + pi/2) = cos x, cos(x + pi/2) = -sin x, x = psi +- phi
+  bool ok5 = true;
+  const double c5 = clamp_unit((tx * sn1 - ty * c1 - d4) / d6, ok5);
+  if (!(fabs(c5) < 1e-8)) return -1;
+  const double ac5 = 0.5 * PI - c5, sg5 = s5p ? -1.0 : 1.0;
+  double q4 = wrap_pi(sg5 * ac5), q4_other = wrap_pi(-sg5 * ac5);
+  const double p4 = joint_dist2(q4, g[4]), p4_other = joint_dist2(q4_other, g[4]);
+  double q5 = wrap_pi(th1 - sg5 * (0.5 * PI));
+  const double p5 = joint_dist2(q5, g[5]);
+  const double px = tx * c1 + ty * sn1 - sg5 * d5, py = tz + d6 - d1, r2 = px * px + py * py;
+  bool ok3 = true;
+  const double c3 = clamp_unit((r2 - a2 * a2 - a3 * a3) / (2 * a2 * a3), ok3);
+  const double ac3 = acos(c3), root3 = sqrt(fmax(0.0, 1.0 - c3 * c3));
+  const double sg3 = s3p ? -1.0 : 1.0, th3 = sg3 * ac3;
+  double q2 = wrap_pi(th3), q2_other = wrap_pi(-th3);
+  const double p2 = joint_dist2(q2, g[2]), p2_other = joint_dist2(q2_other, g[2]);
+  // theta2 = atan2(py, px) - sg3 atan2(a3 sin|theta3|, a2 + a3 cos theta3): ONE atan2 of the rotated vector instead of the
+  // difference of two (same angle modulo 2 pi, which wrap_pi removes; the two agree to a few ulp)
+  const double A3 = a2 + a3 * c3, B3 = sg3 * (a3 * root3);
+  const double th2 = atan2(py * A3 - px * B3, px * A3 + py * B3), th4 = sg5 * (0.5 * PI) - th2 - th3;
+  double q1 = wrap_pi(th2), q3 = wrap_pi(th4);
+  double dist = p0;  // joints 0..5, the exhaustive evaluation's order
+  dist += joint_dist2(q1, g[1]);
+  dist += p2;
+  dist += joint_dist2(q3, g[3]);
+  dist += p4;
+  dist += p5;
+  const bool valid = ok3 && isfinite(q0) && isfinite(q1) && isfinite(q2) && isfinite(q3) && isfinite(q4) && isfinite(q5);
+  // ---- lower bounds of the other seven (a sum of some of a candidate's non-negative terms)
+  //   same theta1: other theta5 (both theta3): p0 + p4';  same theta1, theta5: other theta3: p0 + p4 + p5 + p2'
+  //   other theta1 (all four): p0'
+  const double lb = fmin(fmin(p0 + p4_other, p0 + p4 + p5 + p2_other), p0_other);
+  need_search = !valid || !(lb > dist);
+  q_out[0] = q0; q_out[1] = q1; q_out[2] = q2; q_out[3] = q3; q_out[4] = q4; q_out[5] = q5;
+  return 1;
+}
+__device__ __noinline__ bool ik_closest_general(Aff T, const double* g, double* q_out) { return ik_closest(T, g, q_out); }
+static_assert(MJS_TOP_DOWN_QUAT_XYZW[0] == 1.0 && MJS_TOP_DOWN_QUAT_XYZW[1] == 0.0 && MJS_TOP_DOWN_QUAT_XYZW[2] == 0.0 && MJS_TOP_DOWN_QUAT_XYZW[3] == 0.0,
+              "ik_closest_top_down is derived for R = diag(1, -1, -1)");
 MJS_DEV bool tcp_pose_to_joints_offset(const double* pos, double tcp_z, const double* q_guess, double* q_out) {
-  return ik_closest(flange_pose_of_tcp(pos, MJS_TOP_DOWN_QUAT_XYZW, tcp_z), q_guess, q_out);
+  // flange = TCP - R z tcp_z with R z = (0, 0, -1) (robot.py:138-151)
+  bool need_search;
+  int r = ik_closest_top_down(pos[0], pos[1], pos[2] + tcp_z, q_guess, q_out, need_search);
+  if (__any(r == 1 && need_search)) {  // rare: some lane's guess-branch candidate is not provably the closest
+    const IkTd o = ik_top_down_search_out_of_line(pos[0], pos[1], pos[2] + tcp_z, q_guess[0], q_guess[1], q_guess[2], q_guess[3], q_guess[4], q_guess[5]);
+    if (r == 1 && need_search) {
+      r = o.status;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) q_out[j] = o.q[j];
+    }
+  }
+  if (__any(r < 0)) {  // never for this quaternion; kept so that the entry point is total
+    double qg[NJ];
+    const bool f = ik_closest_general(flange_pose_of_tcp(pos, MJS_TOP_DOWN_QUAT_XYZW, tcp_z), q_guess, qg);
+    if (r < 0) {
+      r = f ? 1 : 0;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) q_out[j] = qg[j];
+    }
+  }
+  return r == 1;
 }
 
 // ----------------------------------------------------------------- contact detection
@@ -903,6 +1087,20 @@ MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
 #pragma unroll
   for (int k = 0; k < 3; k++) s[(S_TARGET + k) * N] = st.target[k];
 }
+// the carried cos / sin rows (first_row = the task's S_CS; the sines follow the six cosines)
+MJS_DEV void load_cs(const KernelParams& p, int i, int first_row, double* cs, double* sn) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++) {
+    const double c = p.state[(size_t)(first_row + j) * p.N + i], s_ = p.state[(size_t)(first_row + NJ + j) * p.N + i];
+    const double f = fma(-0.5, fma(c, c, s_ * s_), 1.5);  // one Newton step towards unit length: 1 / sqrt(n2) ~ 1.5 - n2 / 2
+    cs[j] = c * f;
+    sn[j] = s_ * f;
+  }
+}
+MJS_DEV void store_cs(const KernelParams& p, int i, int first_row, const double* cs, const double* sn) {
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { p.state[(size_t)(first_row + j) * p.N + i] = cs[j]; p.state[(size_t)(first_row + NJ + j) * p.N + i] = sn[j]; }
+}
 // qacc_warmstart rows (first_row = the task's S_WARM): mj_resetData zeroes them
 MJS_DEV void store_warm(const KernelParams& p, int i, int first_row, const double* w) {
 #pragma unroll
@@ -936,7 +1134,13 @@ MJS_DEV void publish_reset(const KernelParams& p, int i, const State& st, bool w
   double obs[OBS_DIM];
   store_state(p, i, st);
   store_warm(p, i, S_WARM, nullptr);
-  fk(st.q, c);
+  {
+    double cs[NJ], sn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    store_cs(p, i, S_CS, cs, sn);
+    fk_cs(cs, sn, c);
+  }
   const double minclr = min_floor_clearance(c);
   p.flags[i] = (uint8_t)(FLAG_WARM_VALID | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0));
   V3 tcp = tcp_position(c);
@@ -1118,6 +1322,7 @@ MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, cons
   // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
   // has to stay live across that call
   store_state(p, i, st);
+  store_cs(p, i, S_CS, cs, sn);
   if (e.solo) store_warm(p, i, S_WARM, warm_out);
   p.flags[i] = newflags;
   // observations [N, 12] row-major: a lane-per-env store is a 96-B-strided scatter (2.5x write
@@ -1237,8 +1442,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const double inv_span = 1.0 / (t1 - t0);
   bool bad = false;
   double cs[NJ], sn[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+  load_cs(p, i, S_CS, cs, sn);
   // The guard (see above): both roles evaluate the same predicates on the same data, so the decision is consistent.
   const bool unsafe = joint_near_range(st.q, st.v) || !(flags & FLAG_CLEAR) || !action_in_box(act) || travel_is_long(q0, q1, st.v);
   const bool solo = (ROLES == 1) || __any(unsafe);
@@ -1401,8 +1605,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) q1[j] = ik.q[j];
     }
-#pragma unroll
-    for (int j = 0; j < NJ; j++) sincos(st.q[j], &sn[j], &cs[j]);
+    load_cs(p, i, S_CS, cs, sn);
     MJS_RR_SOLO_TAIL(0, true);
   } else {
     if (wave == 2) {
@@ -1416,8 +1619,9 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
     }
     const int role = wave;
     double v_start[NJ];
+    load_cs(p, i, S_CS, cs, sn);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) { sincos(st.q[j], &sn[j], &cs[j]); v_start[j] = st.v[j]; }
+    for (int j = 0; j < NJ; j++) v_start[j] = st.v[j];
     {
       // substep 0, whole on this wavefront (both of them, same bits): ctrl = q0 (joint_trajectory.py:41-47 at t = t0)
       double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ], ctrl[NJ];

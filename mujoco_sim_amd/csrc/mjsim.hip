@@ -107,10 +107,23 @@ __global__ void set_state_kernel(double* state, uint8_t* flags, const double* in
   if (i >= N) return;
   for (int k = 0; k < S; k++) state[(size_t)k * N + i] = in[(size_t)k * N + i];
   uint8_t f = (uint8_t)in[(size_t)S * N + i];
-  if (task == MJS_TASK_ROBOT_REACH) {  // FLAG_CLEAR is a function of the joints, which the caller may have edited
+  if (task == MJS_TASK_ROBOT_REACH || task == MJS_TASK_BUTTON_PUSH) {
+    // the caller may have edited the joints: the carried cos / sin rows are kept when they belong to the given q (a checkpoint
+    // resumes bit for bit) and rewritten with exact values when they do not
+    const int first = task == MJS_TASK_ROBOT_REACH ? rr::S_CS : bp::S_CS;
     double q[rr::NJ];
-    for (int j = 0; j < rr::NJ; j++) q[j] = in[(size_t)(rr::S_Q + j) * N + i];
-    f = (uint8_t)((f & ~FLAG_CLEAR) | (rr::config_is_clear(q) ? FLAG_CLEAR : 0));
+    for (int j = 0; j < rr::NJ; j++) {
+      q[j] = in[(size_t)(rr::S_Q + j) * N + i];
+      double sn, cs;
+      sincos(q[j], &sn, &cs);
+      const double c_in = in[(size_t)(first + j) * N + i], s_in = in[(size_t)(first + rr::NJ + j) * N + i];
+      if (!(fabs(c_in - cs) < 1e-11 && fabs(s_in - sn) < 1e-11)) {
+        state[(size_t)(first + j) * N + i] = cs;
+        state[(size_t)(first + rr::NJ + j) * N + i] = sn;
+      }
+    }
+    if (task == MJS_TASK_ROBOT_REACH)  // FLAG_CLEAR is a function of the joints
+      f = (uint8_t)((f & ~FLAG_CLEAR) | (rr::config_is_clear(q) ? FLAG_CLEAR : 0));
   }
   flags[i] = f;
 }
@@ -222,11 +235,11 @@ int mjs_algorithmic_bytes_per_env_step(int task) {
   if (task == MJS_TASK_POINTMASS_REACH)
     return 8 * pm::STATE_DIM /*R*/ + 8 * (pm::STATE_DIM - 2) /*W: target unchanged*/ + 2 + 8 * pm::ACT_DIM + 8 * pm::OBS_DIM + out_fixed;
   if (task == MJS_TASK_ROBOT_REACH)
-    return 8 * rr::HOT_STATE_DIM /*R*/ + 8 * (rr::HOT_STATE_DIM - 3) /*W: target unchanged*/ + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;  // the qacc_warmstart rows are only touched by the robust path
+    return 8 * rr::HOT_ROWS_READ + 8 * rr::HOT_ROWS_WRITTEN + 2 + 8 * rr::ACT_DIM + 8 * rr::OBS_DIM + out_fixed;  // q v time target + carried cos / sin; the qacc_warmstart rows are only touched by the robust path
   if (task == MJS_TASK_PLANAR_PUSH)  // everything but the target is rewritten
     return 8 * pp::STATE_DIM /*R*/ + 8 * (pp::STATE_DIM - 3) /*W*/ + 2 + 8 * pp::ACT_DIM + 8 * pp::OBS_DIM + out_fixed;
   if (task == MJS_TASK_BUTTON_PUSH)
-    return 8 * bp::HOT_STATE_DIM /*R*/ + 8 * (bp::HOT_STATE_DIM - 3) /*W: switch pose unchanged*/ + 2 + 8 * bp::ACT_DIM_JOINT + 8 * bp::OBS_DIM + out_fixed;
+    return 8 * bp::HOT_ROWS_READ + 8 * bp::HOT_ROWS_WRITTEN + 2 + 8 * bp::ACT_DIM_JOINT + 8 * bp::OBS_DIM + out_fixed;
   return -1;
 }
 
@@ -342,7 +355,9 @@ void mjs_destroy(mjs_handle* h) {
       std::fprintf(stderr, "[MJS_STAMPS] slowest wavefront, inside its cooperative solves: rows %.0f | init (M^-1 f, J a, update) %.0f | gradient+Hessian %.0f | Cholesky+solves %.0f | M v, J v %.0f | line search %.0f | update+gradient norm %.0f | J^T f %.0f\n", worst[15], worst[8], worst[9], worst[10], worst[11], worst[12], worst[13], worst[14]);
       std::fprintf(stderr, "[MJS_STAMPS] SLOWEST workgroup: detect %.0f | arm dynamics %.0f | decoupled solves %.0f | cooperative coupled %.0f (publish %.0f) | integrate %.0f\n", worst[0], worst[1], worst[2], worst[3], worst[5], worst[4]);
     }
-    std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], d[1], d[2], d[3], d[4]);
+    double own = 0;  // Robot-Reach kernel3: stamp 6 = wave 0 has finished its own prologue (load, sincos, substep 0) and reaches the IK barrier
+    for (int w = 0; w < W; w++) own += (double)(host[16 * w + 6] - host[16 * w + 0]) / W;
+    std::fprintf(stderr, "[MJS_STAMPS] cycles: load+IK %.0f (of which wave 0's own load + sincos + substep 0: %.0f) | substeps %.0f | fk+obs %.0f | contacts %.0f | store %.0f\n", d[0], own, d[1], d[2], d[3], d[4]);
     std::fprintf(stderr, "[MJS_STAMPS] role-0 substep 10: CRBA+factor+invert %.0f | barrier %.0f | apply inverse+publish+barrier %.0f | integrate %.0f\n", e[0], e[1], e[2], e[3]);
     delete[] host;
     (void)hipFree(h->stamps);

@@ -54,9 +54,12 @@ def test_static_queries(native):
     assert L.mjs_obs_dim(99) == -1
     # algorithmic bytes per env-step, recomputed from the SoA layout
     assert L.mjs_algorithmic_bytes_per_env_step(0) == 8 * 13 + 8 * 11 + 2 + 16 + 32 + 25
-    assert L.mjs_algorithmic_bytes_per_env_step(1) == 8 * 16 + 8 * 13 + 2 + 24 + 96 + 25
-    # state blocks (rows + the flag row): Robot-Reach q6 v6 time target3 qacc_warmstart6; Button-Push q6 v6 time switch3 gripper2 qacc_warmstart6
-    assert (L.mjs_state_dim(1), L.mjs_state_dim(3)) == (23, 25)
+    # Robot-Reach: q6 v6 time target3 + the carried cos6 sin6 read, the same minus the target written (the qacc_warmstart rows are
+    # touched by the robust path only)
+    assert L.mjs_algorithmic_bytes_per_env_step(1) == 8 * (16 + 12) + 8 * (13 + 12) + 2 + 24 + 96 + 25
+    # state blocks (rows + the flag row): Robot-Reach q6 v6 time target3 qacc_warmstart6 cos6 sin6; Button-Push q6 v6 time switch3
+    # gripper2 qacc_warmstart6 cos6 sin6
+    assert (L.mjs_state_dim(1), L.mjs_state_dim(3)) == (35, 37)
 
 
 def test_create_rejects_bad_arguments(native):

@@ -914,15 +914,18 @@ def test_planar_push_controlled_scenarios(oracle_mod):
     assert q2[5, 6] - qp[5, 6] > 0.03 and q2[6, 13] - qp[6, 13] > 0.01  # the pushes really moved the blocks
 
 
-def test_planar_push_full_size_shard_invariance_and_determinism():
-    """BASELINE config 4 size (4096 envs per GPU): env i of one 4096-env handle is bit-identical to env i of two
-    2048-env handles with env_index_offset 0 / 2048 (wavefront placement, helper lanes, cooperative solves and quad
-    solves of OTHER envs must not leak into an env), and a second identical run repeats the first bit for bit."""
+@pytest.mark.parametrize("block_shape", ["mesh", "box"])
+def test_planar_push_full_size_shard_invariance_and_determinism(block_shape):
+    """BASELINE config 4 size (4096 envs per GPU) on config 4's OWN code path (the reference's mesh blocks: group-parallel
+    MPR, the convex-pair list shared by the four envs of a wavefront) and on the box stand-in: env i of one 4096-env handle
+    is bit-identical to env i of two 2048-env handles with env_index_offset 0 / 2048 (wavefront placement, helper lanes,
+    cooperative solves, quad solves and pair lists of OTHER envs must not leak into an env), and a second identical run
+    repeats the first bit for bit."""
     import mujoco_sim_amd as m
 
     N, T = 4096, 5
     def run(parts):
-        envs = [m.HipVectorEnv("robot_planar_push", N // parts, seed=99, env_index_offset=k * (N // parts), max_episode_steps=3, block_shape="box") for k in range(parts)]
+        envs = [m.HipVectorEnv("robot_planar_push", N // parts, seed=99, env_index_offset=k * (N // parts), max_episode_steps=3, block_shape=block_shape) for k in range(parts)]
         for e in envs:
             e.reset()
         outs = []
@@ -943,6 +946,30 @@ def test_planar_push_full_size_shard_invariance_and_determinism():
             assert np.array_equal(whole[t][key], halves[t][key]), ("shards", key, t)
     assert (whole[-1]["ncon"] > 8).any() and (np.concatenate([w["step_type"] for w in whole]) == 2).any()
     assert not (np.concatenate([w["fault"] for w in whole]) & 1).any()
+
+
+def test_robot_reach_shard_invariance_at_the_kernel_switch():
+    """include/mjsim.h: up to 16384 envs per handle mjs_step launches the three-wavefront Robot-Reach kernel, above it the
+    two-role kernel (same results to rounding, not to the bit). The supported bitwise rule: shards are bit-identical to the
+    whole job as long as every handle in the comparison runs the same kernel: 8192 + 8192 vs 16384 (all three-wavefront)
+    here; a 16384 + 16384 job vs one 32768-env handle may differ in the last bits (test_robot_reach_large_batch_matches_oracle
+    holds the large-batch kernel to the oracle instead)."""
+    import mujoco_sim_amd as m
+
+    N, T = 16384, 4
+    acts = torch.from_numpy(_actions("robot_reach", T, N, seed=5)).cuda()
+    whole = m.HipVectorEnv("robot_reach", N, seed=77)
+    whole.reset()
+    ref = whole.rollout(acts)
+    for k in range(2):
+        part = m.HipVectorEnv("robot_reach", N // 2, seed=77, env_index_offset=k * (N // 2))
+        part.reset()
+        out = part.rollout(acts[:, k * (N // 2):(k + 1) * (N // 2)].contiguous())
+        for key in ("obs", "reward", "step_type", "ncon", "fault"):
+            assert torch.equal(out[key], ref[key][:, k * (N // 2):(k + 1) * (N // 2)]), (key, k)
+        part.close()
+    assert int(ref["fault"].max()) == 0
+    whole.close()
 
 
 def test_planar_push_block_train_couples_all_bodies(oracle_mod):
@@ -1038,7 +1065,7 @@ def test_planar_push_parity_with_oracle(oracle_mod):
             assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
         n_last += int((o["step_type"] == 2).sum())
         n_pushed += int((o["ncon"] > 8).sum())
-    assert sens.mean() < 0.15, sens.mean()   # the ill-conditioned envs are a small minority
+    assert sens.mean() < 0.08, sens.mean()   # the ill-conditioned envs are a small minority (measured 0.03-0.04 in rounds 2 and 3)
     assert n_last >= 2 * N - 4               # two step-limit truncations per env: device-side resets were exercised
     assert n_pushed > 100                    # EEF-block / block-block contacts on top of the 8 floor corners
 
@@ -1169,7 +1196,7 @@ def test_planar_push_mesh_parity_with_oracle(oracle_mod):
         n_last += int((o["step_type"] == 2).sum())
         n_pushed += int((o["ncon"] > 8).sum())
     print("mesh blocks: ill-conditioned fraction per step, mean", np.mean(frac), "max", np.max(frac))
-    assert np.mean(frac) < 0.3, np.mean(frac)
+    assert np.mean(frac) < 0.08, np.mean(frac)  # measured 0.028-0.035
     assert n_last >= 2 * N - 4 and n_pushed > 50
 
 
