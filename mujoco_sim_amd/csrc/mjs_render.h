@@ -823,7 +823,21 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
     right = cm + 3; up = cm + 6; back = cm + 9;
   }
   __syncthreads();
-  if (tid < nprim) prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, right, up, back, bbox + 4 * tid);
+  if (tid < nprim) {
+    prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, right, up, back, bbox + 4 * tid);
+    // A capped cylinder that FOLLOWS a capsule on the same segment with the same radius (the UR5e's last two collision
+    // proxies, MJS_UR_COL_* 8 and 9) can never win a pixel: it lies inside the capsule, its side hits have the capsule's
+    // ray parameter to the bit (same expressions in hit_capsule / hit_cylinder) and lose the strict-< update to the lower
+    // index, its flat caps lie behind the capsule's round ones, and both share one bounding sphere. Its exact test only
+    // costs time - most of all in the wrist camera's image, where the pair sits 1-4 cm from the lens: empty rectangle.
+    if (tid > 0) {
+      const float* a = lds_prims + (tid - 1) * PRIM_FLOATS;
+      const float* b = lds_prims + tid * PRIM_FLOATS;
+      if ((int)a[0] == PRIM_CAPSULE && (int)b[0] == PRIM_CYLINDER && a[1] == b[1] && a[2] == b[2] && a[3] == b[3] && a[4] == b[4] && a[5] == b[5] && a[6] == b[6] &&
+          a[13] == b[13])
+        bbox[4 * tid + 1] = bbox[4 * tid] - 1;
+    }
+  }
   __syncthreads();
   const int tiles_x = p.W >> 3, ntiles = npix >> 6;
   for (;;) {
@@ -861,6 +875,7 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
       const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
       const float along = dotf(oc, d), off2 = dotf(oc, oc) - along * along, br = pr[17];  // per-ray bounding-sphere reject
       if (!(off2 <= br * br && along + br > 0.0f)) continue;
+      if (along - br > s.t) continue;  // every point of the bound lies beyond the nearest hit so far: it cannot pass the strict-< update
       exact_test(pr, eye, d, s);
     }
     if (FIXED) {

@@ -8,8 +8,11 @@ attributes and methods SB3's algorithms call (``num_envs``, ``observation_space`
 ``get_attr`` / ``set_attr`` / ``env_method``, ``env_is_wrapped``), with SB3's conventions:
 numpy dict observations, same-step auto-reset with ``infos[i]["terminal_observation"]``,
 ``infos[i]["TimeLimit.truncated"]``, ``dones = terminated | truncated``. All N envs live on one
-GPU and are stepped by one kernel launch; the only host traffic per step is the batched copy
-SB3's numpy replay buffer needs anyway.
+GPU and are stepped by one kernel launch; the host traffic per step is ONE device->host copy of the
+output arena (observations, rewards, flags, terminal observations: all fields are views of one
+device buffer) into one pinned staging buffer, what SB3's numpy replay buffer needs anyway; the
+per-env ``infos`` dicts are built from one vectorised ``is_success`` array and only envs that
+ended get the extra keys (tools/host_rate.py: host time per ``step_wait``).
 
 Subclasses ``stable_baselines3.common.vec_env.VecEnv`` when SB3 is importable (it is not part
 of this repository's environment), otherwise it is duck-typed.
@@ -47,6 +50,11 @@ class HipSB3VecEnv(_Base):
         self._ep_length = np.zeros(num_envs, dtype=np.int64)
         self._lo = torch.as_tensor(np.asarray(self.venv.action_low), dtype=torch.float64, device=self.venv.device)
         self._hi = torch.as_tensor(np.asarray(self.venv.action_high), dtype=torch.float64, device=self.venv.device)
+        # pinned host mirror of the env's output arena + numpy views of its fields (re-used every step)
+        self._host_arena = torch.empty(self.venv._arena.shape, dtype=torch.uint8, pin_memory=True)
+        self._host = {name: self._host_arena[o:o + nb].view(dt).view(shape).numpy() for name, dt, shape, o, nb in self.venv._arena_layout}
+        self._act_host = torch.empty(num_envs, self.venv.action_dim, dtype=torch.float64, pin_memory=True)
+        self._act_dev = torch.empty(num_envs, self.venv.action_dim, dtype=torch.float64, device=self.venv.device)
 
     # ------------------------------------------------------------------ helpers
     def _obs_numpy(self, flat: torch.Tensor):
@@ -72,22 +80,33 @@ class HipSB3VecEnv(_Base):
         return self._obs_numpy(self.venv.flat_obs)
 
     def step_async(self, actions):
-        self._actions = torch.as_tensor(np.asarray(actions), device=self.venv.device).to(torch.float64)
+        # one pinned staging buffer, one host->device copy on the env's stream
+        self._act_host.numpy()[...] = np.asarray(actions, dtype=np.float64).reshape(self.num_envs, self.venv.action_dim)
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        self._actions = self._act_dev
 
     def step_wait(self):
-        b = self.venv.step_flat(self._actions.contiguous())
-        # one device->host copy per field (what a numpy replay buffer needs)
-        obs = self._obs_numpy(b["obs"])
-        reward = b["reward"].cpu().numpy().astype(np.float32)
-        terminated = b["terminated"].cpu().numpy().astype(bool)
-        truncated = b["truncated"].cpu().numpy().astype(bool)
-        success = b["is_success"].cpu().numpy()
+        b = self.venv.step_flat(self._actions)
+        visual = self.venv._img is not None
+        if visual:
+            obs = self._obs_numpy(b["obs"])  # renders the camera image(s); image tensors are copied on their own
+        # ONE device->host copy for every output field
+        self._host_arena.copy_(self.venv._arena, non_blocking=True)
+        torch.cuda.current_stream(self.venv.device).synchronize()
+        h = self._host
+        if not visual:
+            flat = h["obs"]
+            obs = OrderedDict((k, flat[:, s:s + n].copy()) for k, s, n in self.venv._state_layout)
+        reward = h["reward"].astype(np.float32)
+        terminated = h["terminated"].astype(bool)
+        truncated = h["truncated"].astype(bool)
         dones = terminated | truncated
-        infos = [{"is_success": float(success[i])} for i in range(self.num_envs)]
+        # SB3 wants one dict per env (a shared dict would alias): built from ONE vectorised array; extra keys only where an episode ended
+        infos = [{"is_success": x} for x in h["is_success"].astype(np.float64).tolist()]
         self._ep_return += reward
         self._ep_length += 1
         if dones.any():
-            term_obs = b["terminal_obs"].cpu().numpy()
+            term_obs = h["terminal_obs"]
             for i in np.nonzero(dones)[0]:
                 infos[i]["terminal_observation"] = self._terminal_obs_numpy(term_obs, i)
                 infos[i]["TimeLimit.truncated"] = bool(truncated[i] and not terminated[i])

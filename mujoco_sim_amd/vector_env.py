@@ -149,18 +149,19 @@ class HipVectorEnv:
             S = self.state_dim - 1
             self.algorithmic_bytes_per_env_step = 8 * S + 8 * (S - 3) + 2 + 8 * self.action_dim + 8 * self.obs_dim + 25
         N, dev = self.num_envs, self.device
-        self._buf = {
-            "obs": torch.zeros(N, self.obs_dim, dtype=torch.float64, device=dev),
-            "terminal_obs": torch.zeros(N, self.obs_dim, dtype=torch.float64, device=dev),
-            "reward": torch.zeros(N, dtype=torch.float64, device=dev),
-            "discount": torch.ones(N, dtype=torch.float64, device=dev),
-            "terminated": torch.zeros(N, dtype=torch.uint8, device=dev),
-            "truncated": torch.zeros(N, dtype=torch.uint8, device=dev),
-            "is_success": torch.zeros(N, dtype=torch.uint8, device=dev),
-            "step_type": torch.zeros(N, dtype=torch.uint8, device=dev),
-            "fault": torch.zeros(N, dtype=torch.uint8, device=dev),
-            "ncon": torch.zeros(N, dtype=torch.int32, device=dev),
-        }
+        # every output field is a typed view into ONE device arena (64-byte aligned slots), so that a host-side consumer (the SB3
+        # adapter's numpy replay buffer, scripts/sb3/reach_sac.py:93-131) needs ONE device->host copy per step for all of them
+        fields = (("obs", torch.float64, (N, self.obs_dim)), ("terminal_obs", torch.float64, (N, self.obs_dim)), ("reward", torch.float64, (N,)),
+                  ("discount", torch.float64, (N,)), ("ncon", torch.int32, (N,)), ("terminated", torch.uint8, (N,)), ("truncated", torch.uint8, (N,)),
+                  ("is_success", torch.uint8, (N,)), ("step_type", torch.uint8, (N,)), ("fault", torch.uint8, (N,)))
+        self._arena_layout, off = [], 0
+        for name, dt, shape in fields:
+            nbytes = int(np.prod(shape)) * torch.empty((), dtype=dt).element_size()
+            self._arena_layout.append((name, dt, shape, off, nbytes))
+            off += (nbytes + 63) // 64 * 64
+        self._arena = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self._buf = {name: self._arena[o:o + nb].view(dt).view(shape) for name, dt, shape, o, nb in self._arena_layout}
+        self._buf["discount"].fill_(1.0)
         self._out = self._make_outputs(self._buf)
         self._out_ref = C.byref(self._out)  # step_flat's hot path: no per-call ctypes object construction
         self._mjs_step = self._lib.mjs_step
