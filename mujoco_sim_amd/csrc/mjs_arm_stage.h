@@ -79,6 +79,39 @@ static_assert(MJS_UR_COL_BODY[1] == 2 && MJS_UR_COL_TYPE[1] == 3 && MJS_UR_COL_Q
                   MJS_UR_BODY_POS[2][0] == 0.0 && MJS_UR_BODY_POS[2][2] == 0.0 && MJS_UR_BODY_POS[1][2] - MJS_UR_COL_SIZE[1][0] > 0,
               "the upper arm's shoulder-side capsule is assumed to lie on the (horizontal) shoulder-lift axis at the shoulder's height");
 
+// mjc_PlaneCylinder against the floor z = 0 (normal +z): the deepest rim point, the same rim point of the other disk, and two
+// side points of the lower disk, in MuJoCo's order; emit(pos, dist) for every DETECTED contact (dist <= 0). gp = centre, axis =
+// the cylinder's axis (geom z), xaxis = geom x (used when the disks are parallel to the floor).
+template <class Emit>
+MJS_DEV void plane_cylinder_contacts(V3 gp, V3 axis, V3 xaxis, double rad, double half, Emit emit) {
+  const double dist0 = gp.z;
+  double prjaxis = axis.z;
+  if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
+  V3 vec = prjaxis * axis - v3(0, 0, 1);
+  const double len = sqrt(dot(vec, vec));
+  if (len < 1e-12) vec = rad * xaxis;
+  else vec = (rad / len) * vec;
+  const double prjvec = vec.z;
+  axis = half * axis;
+  prjaxis *= half;
+  double dd = dist0 + prjaxis + prjvec;
+  if (dd > 0) return;
+  emit(v3(gp.x + vec.x + axis.x, gp.y + vec.y + axis.y, gp.z + vec.z + axis.z - dd * 0.5), dd);
+  dd = dist0 - prjaxis + prjvec;
+  if (dd <= 0) emit(v3(gp.x + vec.x - axis.x, gp.y + vec.y - axis.y, gp.z + vec.z - axis.z - dd * 0.5), dd);
+  V3 side = cross(vec, axis);
+  const double sl = sqrt(dot(side, side));
+  if (sl > 1e-12) {
+    side = (rad * sqrt(3.0) * 0.5 / sl) * side;
+    dd = dist0 + prjaxis - 0.5 * prjvec;
+    if (dd <= 0) {
+#pragma unroll
+      for (int s = -1; s <= 1; s += 2)
+        emit(v3(gp.x + s * side.x + axis.x - 0.5 * vec.x, gp.y + s * side.y + axis.y - 0.5 * vec.y, gp.z + s * side.z + axis.z - 0.5 * vec.z - dd * 0.5), dd);
+    }
+  }
+}
+
 // every DETECTED arm-floor contact (dist <= 0, what mj_collision lists) in MuJoCo's pair order: emit(body, pos, dist).
 // Same arithmetic as count_floor_contacts (mjc_PlaneCapsule: one contact per end sphere; mjc_PlaneCylinder: up to 4).
 template <class Emit>
@@ -99,34 +132,7 @@ MJS_DEV void arm_floor_contacts(const Chain& c, Emit emit) {
         }
       }
     } else {
-      const M3 R = c.R[b];
-      const double dist0 = gp.z;
-      double prjaxis = axis.z;
-      if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
-      V3 vec = prjaxis * axis - v3(0, 0, 1);
-      const double len = sqrt(dot(vec, vec));
-      if (len < 1e-12) vec = rad * R.cx;
-      else vec = (rad / len) * vec;
-      const double prjvec = vec.z;
-      axis = half * axis;
-      prjaxis *= half;
-      double dd = dist0 + prjaxis + prjvec;
-      if (!(dd > 0)) {
-        emit(b, v3(gp.x + vec.x + axis.x, gp.y + vec.y + axis.y, gp.z + vec.z + axis.z - dd * 0.5), dd);
-        dd = dist0 - prjaxis + prjvec;
-        if (dd <= 0) emit(b, v3(gp.x + vec.x - axis.x, gp.y + vec.y - axis.y, gp.z + vec.z - axis.z - dd * 0.5), dd);
-        V3 side = cross(vec, axis);
-        const double sl = sqrt(dot(side, side));
-        if (sl > 1e-12) {
-          side = (rad * sqrt(3.0) * 0.5 / sl) * side;
-          dd = dist0 + prjaxis - 0.5 * prjvec;
-          if (dd <= 0) {
-#pragma unroll
-            for (int s = -1; s <= 1; s += 2)
-              emit(b, v3(gp.x + s * side.x + axis.x - 0.5 * vec.x, gp.y + s * side.y + axis.y - 0.5 * vec.y, gp.z + s * side.z + axis.z - 0.5 * vec.z - dd * 0.5), dd);
-          }
-        }
-      }
+      plane_cylinder_contacts(gp, axis, c.R[b].cx, rad, half, [&](V3 pos, double dist) { emit(b, pos, dist); });
     }
   }
 }
@@ -141,8 +147,8 @@ struct GenStageOut {
   bool overflow;
 };
 
-// SC (scene): dof_invweight(j), link_invweight(b), MEANINERTIA, struct Extra (by value), extra_contacts(ch, ex, emit) with
-// emit(ndof, pos, nrm, sgn, dist, invweight, on_switch), in_touch_site(ex, pos).
+// SC (scene): dof_invweight(j), link_invweight(b), solver_scale(ex) = 1 / (meaninertia * nv) of the WHOLE model, struct Extra (by
+// value), extra_contacts(ch, ex, emit) with emit(ndof, pos, nrm, sgn, dist, invweight, on_switch), in_touch_site(ex, pos).
 template <class SC>
 __device__ __noinline__ GenStageOut gen_stage(GenStageIn in, typename SC::Extra ex, Ws ws) {
   const double mu = MJS_GEOM_FRICTION_SLIDE;
@@ -339,7 +345,7 @@ __device__ __noinline__ GenStageOut gen_stage(GenStageIn in, typename SC::Extra 
 #pragma unroll
     for (int i = 0; i < NJ; i++) a[i] = keep ? a[i] : a_s[i];
   }
-  const double scale = 1 / (SC::MEANINERTIA * NJ);
+  const double scale = SC::solver_scale(ex);
   double oldcost = 0;
 #pragma unroll 1
   for (int iter = 0; iter <= MJS_SOLVER_ITERATIONS; iter++) {

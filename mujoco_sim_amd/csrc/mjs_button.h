@@ -513,7 +513,7 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
 // tip 1 - button; and the touch sensor's site test.
 struct SceneButton {
   struct Extra { double sw[3], grip_th; bool wb_hit; double wb_dist, wb_pos[3], wb_nrm[3]; };
-  static constexpr double MEANINERTIA = UR5E_BP_MEANINERTIA;
+  MJS_DEV static double solver_scale(Extra) { return 1 / (UR5E_BP_MEANINERTIA * NJ); }
   MJS_DEV static double dof_invweight(int j) { return UR5E_BP_DOF_INVWEIGHT0[j]; }
   MJS_DEV static double link_invweight(int b) { return UR5E_BP_LINK_BODY_INVWEIGHT0[b]; }
   template <class E>

@@ -413,6 +413,13 @@ MJS_DEV Geom eef_geom(const rr::Chain& ch) {  // CylinderEEF: axis = flange z = 
   g.cat = -1;
   return g;
 }
+// number of DETECTED EEF cylinder - floor contacts (what mj_collision lists: 0..4)
+MJS_DEV int count_eef_floor_contacts(const rr::Chain& ch) {
+  const Geom eg = eef_geom(ch);
+  int n = 0;
+  rr::plane_cylinder_contacts(eg.c, eg.R.cz, eg.R.cx, eg.s.x, eg.s.y, [&](V3, double) { n++; });
+  return n;
+}
 MJS_DEV Geom wrist3_proxy_geom(const rr::Chain& ch) {  // the arm's last collision proxy is a CYLINDER (MJS_UR_COL_* index 9):
   Geom g;                                             // the only arm geom whose pair with a box is evaluated (convex-convex)
   constexpr int G = MJS_UR_NCOLGEOM - 1;
@@ -537,11 +544,11 @@ MJS_DEV int detect_contacts(const rr::Chain& ch, const World& s, const M3* Rb, i
   int n = 0;
   extra = rr::count_floor_contacts(ch);
   const Geom eg = eef_geom(ch);
-  {  // mjc_PlaneCylinder first test: the deepest rim point of the EEF cylinder (active only if the arm sags by 19 mm)
+  {  // mjc_PlaneCylinder: up to four contacts once the deepest rim point of the EEF cylinder reaches the floor (the arm sagging by 19 mm)
     const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
     const double lowest = eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x;
     eef_floor_active = lowest < 0.0;
-    if (!(lowest > 0.0)) extra += 1;
+    extra += count_eef_floor_contacts(ch);
   }
   Geom bg[NB];
   for (int b = 0; b < nb; b++) {
@@ -788,6 +795,7 @@ MJS_DEV void quad_block_floor(const M3 R, const Shape& sh, const double* qvel, c
 
 struct StepInfo {
   bool bad, rows_active, unsupported;
+  bool arm_floor;  // this substep: an arm collision geom or the EEF cylinder is in the floor (set by the detection phase)
   int ncon;
 #ifdef MJS_STAMPS
   unsigned long long cyc[16];  // 0..5 phase cycles, 6 = cooperative solves, 7 = their Newton iterations, 8..15 = phases inside them
@@ -1605,7 +1613,8 @@ MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& 
   {
     const Geom eg = eef_geom(ch), wg = wrist3_proxy_geom(ch);
     const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
-    info.unsupported = info.unsupported || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);  // EEF cylinder below the floor (D-8)
+    // the arm's own geoms or the EEF cylinder in the floor: rows of the arm alone, solved by the general stage in physics_step
+    info.arm_floor = !(rr::min_floor_clearance(ch) >= 0.0) || (eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x < 0.0);
     // publish this env's geoms for the group-parallel pair evaluation below
     DetLds& dl = det_lds();
     const int lane_ = threadIdx.x & 63;
@@ -1816,10 +1825,7 @@ __device__ __noinline__ int count_contacts_group(int nb, bool live) {
     const EnvLds& env = env_lds();
     rr::Chain ch;
     rr::fk_cs(env.cs, env.sn, ch);
-    n = rr::count_floor_contacts(ch);
-    const Geom eg = eef_geom(ch);
-    const double prj = eg.R.cz.z, rad = sqrt(fmax(0.0, 1.0 - prj * prj));
-    if (!(eg.c.z - fabs(prj) * eg.s.y - rad * eg.s.x > 0.0)) n += 1;  // mjc_PlaneCylinder's first test (detect_contacts)
+    n = rr::count_floor_contacts(ch) + count_eef_floor_contacts(ch);
 #pragma unroll
     for (int b = 0; b < NB; b++)
       if (b < nb) n += fln[b] + (hit[b] ? 1 : 0) + (hit[NB + b] ? 1 : 0);
@@ -1833,9 +1839,27 @@ __device__ __noinline__ int count_contacts_group(int nb, bool live) {
   return n;
 }
 
+// The arm's floor contacts in this scene (rr::gen_stage, mjs_arm_stage.h): the arm's ten collision geoms come from the stage
+// itself; this adds the CylinderEEF (geom on the EEF body welded to wrist_3: all six joints move it) against the floor,
+// mjc_PlaneCylinder's up to four contacts, after the arm geoms in MuJoCo's pair order. The solver's stopping rules are scaled
+// by the WHOLE model of this env (arm + blocks: mj_setConst's meaninertia, nv = 6 + 6 n), as in the oracle's one Newton problem.
+struct ScenePush {
+  struct Extra { double scale; };
+  MJS_DEV static double solver_scale(Extra ex) { return ex.scale; }
+  MJS_DEV static double dof_invweight(int j) { return UR5E_PP_DOF_INVWEIGHT0[j]; }
+  MJS_DEV static double link_invweight(int b) { return UR5E_PP_LINK_BODY_INVWEIGHT0[b]; }
+  template <class E>
+  MJS_DEV static void extra_contacts(const rr::Chain& ch, Extra, E emit) {
+    const Geom eg = eef_geom(ch);
+    rr::plane_cylinder_contacts(eg.c, eg.R.cz, eg.R.cx, eg.s.x, eg.s.y,
+                                [&](V3 pos, double dist) { emit(NJ, pos, v3(0, 0, 1), 1.0, dist, UR5E_PP_EEF_BODY_INVWEIGHT0[0], false); });
+  }
+  MJS_DEV static bool in_touch_site(Extra, V3) { return false; }
+};
+
 // The substep is inlined into its two call sites (the control-step loop and the same-step auto-reset's settle loop): as a
 // non-inlined function it saved and restored ~130 callee-saved registers per call, every lane, every substep.
-__device__ __forceinline__ void physics_step(int nb, bool live) {
+__device__ __forceinline__ void physics_step(int nb, bool live, rr::Ws ws) {
   EnvLds& env = env_lds();
   World& s = env.w;
   const double* ctrl = env.ctrl;
@@ -1955,6 +1979,29 @@ __device__ __forceinline__ void physics_step(int nb, bool live) {
   coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb, arm_in, blk_in, meaninertia);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
+  // Arm geoms / EEF cylinder in the floor (an unreachable or low target drags the tool over the floor; mjs_set_state): the
+  // arm's own 6-dof constraint problem (floor contacts + joint limits) goes through the general stage, cold-started like every
+  // solve of this kernel. Only while the arm is not ALSO coupled with a block (an arm-block contact puts the arm into the
+  // cooperative 18-dof solve, whose row format has no link-specific arm rows): that combination is reported, not solved.
+  if (info.arm_floor) {
+    if (arm_in && coupled) info.unsupported = true;
+    else {
+      rr::GenStageIn gi;
+#pragma unroll
+      for (int j = 0; j < NJ; j++) { gi.q[j] = s.q[j]; gi.v[j] = s.v[j]; gi.cs[j] = cs[j]; gi.sn[j] = sn[j]; gi.qs[j] = qacc[j]; gi.warm[j] = 0.0; }
+#pragma unroll
+      for (int i = 0; i < NJ; i++) {
+#pragma unroll
+        for (int j = 0; j <= i; j++) gi.M[i * (i + 1) / 2 + j] = Marm[i * (i + 1) / 2 + j] + (i == j ? MJS_UR_ARMATURE : 0.0);
+      }
+      gi.has_warm = false;
+      const rr::GenStageOut go = rr::gen_stage<ScenePush>(gi, ScenePush::Extra{1.0 / (meaninertia * nv)}, ws);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) qacc[j] = go.qs[j];
+      info.rows_active = true;
+      info.unsupported = info.unsupported || go.overflow;
+    }
+  }
   // integrator: arm implicitfast (M + armature + dt * kd on unclamped actuators), blocks M qacc = f
   {
     double A[NJ][NJ], rhs[NJ], Dinv[NJ];
@@ -2180,7 +2227,7 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
       } else {
         for (int j = 0; j < NJ; j++) env.ctrl[j] = ctrl0[j];
       }
-      physics_step(nb, pass == 0 ? sub < nsub : (again && valid));
+      physics_step(nb, pass == 0 ? sub < nsub : (again && valid), rr::Ws{p.ws, p.N, i});
     }
     s = env.w;
     for (int j = 0; j < NJ; j++) { cs[j] = env.cs[j]; sn[j] = env.sn[j]; }

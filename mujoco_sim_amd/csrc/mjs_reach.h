@@ -992,7 +992,7 @@ namespace rr {
 
 struct SceneReach {  // Robot-Reach: UR5e + lumped gripper payload, no collision geom beyond the arm's own
   struct Extra {};
-  static constexpr double MEANINERTIA = UR5E_MEANINERTIA;
+  MJS_DEV static double solver_scale(Extra) { return 1 / (UR5E_MEANINERTIA * NJ); }
   MJS_DEV static double dof_invweight(int j) { return UR5E_DOF_INVWEIGHT0[j]; }
   MJS_DEV static double link_invweight(int b) { return UR5E_LINK_BODY_INVWEIGHT0[b]; }
   template <class E>

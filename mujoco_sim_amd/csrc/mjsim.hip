@@ -302,7 +302,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::PP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
-  if (e == hipSuccess && (cfg->task == MJS_TASK_ROBOT_REACH || cfg->task == MJS_TASK_BUTTON_PUSH))  // 2.3 KB per env, touched by the robust path only
+  if (e == hipSuccess && cfg->task != MJS_TASK_POINTMASS_REACH)  // 3.4 KB per env, touched only by lanes with an arm geom in the floor
     e = hipMalloc(&h->ws, sizeof(double) * rr::WS_ROWS * N);
 #ifdef MJS_STAMPS
   if (e == hipSuccess) e = hipMalloc(&h->stamps, sizeof(unsigned long long) * 16 * N);  // one slot block per workgroup, at most N workgroups

@@ -914,6 +914,47 @@ def test_planar_push_controlled_scenarios(oracle_mod):
     assert q2[5, 6] - qp[5, 6] > 0.03 and q2[6, 13] - qp[6, 13] > 0.01  # the pushes really moved the blocks
 
 
+def test_planar_push_arm_on_the_floor_matches_oracle(oracle_mod):
+    """Planar-Push with the arm's own collision geoms and the CylinderEEF pushed into the floor through mjs_set_state
+    (shoulder-lift offsets from grazing to 1.1 rad; blocks parked away from the arm): plane-capsule and plane-cylinder
+    contacts of the arm (mjc_PlaneCapsule, mjc_PlaneCylinder: up to four per cylinder) are solved by the general constraint
+    stage next to the blocks' own floor contacts; joint positions, block poses, reward and ncon equal the oracle's. The
+    combination the kernel reports instead of solving (arm on the floor AND coupled to a block, fault bit 8) does not occur here."""
+    import mujoco_sim_amd as m
+
+    N = 24
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=4, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 4, nthreads=8, block_shape=1)
+    venv.reset()
+    o = ob.reset()
+    qp, qv, tm = ob.get_state()
+    tcp = o["obs"][:, :3].copy()
+    qv[:] = 0
+    qp[:, 6:13] = [0.55, 0.55, 0.0, 1, 0, 0, 0]   # the two blocks rest on the floor, out of the arm's way
+    qp[:, 13:20] = [-0.55, 0.55, 0.0, 1, 0, 0, 0]
+    qp[:, 1] += np.linspace(0.05, 1.1, N)          # shoulder lift: the forearm / wrist / EEF go through the floor
+    ob.set_state(qp, qv)
+    _push_state_to_gpu(venv, qp, qv, tm)
+    act = tcp[:, :2].copy()
+    n_arm = n_rows = 0
+    for t in range(5):
+        venv.step(torch.from_numpy(act))
+        r = ob.step(act)
+        g = venv.get_state().cpu().numpy()
+        q2, v2, _ = ob.get_state()
+        fault = venv._buf["fault"].cpu().numpy()
+        assert not (fault & (1 | 8)).any(), (t, fault)
+        np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-8, err_msg=f"joints, step {t}")
+        np.testing.assert_allclose(g[6:12].T, v2[:, :6], rtol=0, atol=1e-6, err_msg=f"joint velocities, step {t}")
+        for b in range(2):
+            np.testing.assert_allclose(g[17 + 15 * b: 24 + 15 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-9, err_msg=f"block {b} pose, step {t}")
+        assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), (t, venv._buf["ncon"].cpu().numpy(), r["ncon"])
+        np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-8)
+        n_arm += int(ob.arm_floor_seen().sum())
+        n_rows += int(((fault & 4) > 0).sum())
+    assert n_arm >= 10 and n_rows >= 10, (n_arm, n_rows)
+
+
 @pytest.mark.parametrize("block_shape", ["mesh", "box"])
 def test_planar_push_full_size_shard_invariance_and_determinism(block_shape):
     """BASELINE config 4 size (4096 envs per GPU) on config 4's OWN code path (the reference's mesh blocks: group-parallel
