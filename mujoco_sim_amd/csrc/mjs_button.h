@@ -18,6 +18,7 @@
 #pragma once
 #include "mjs_kernel_common.h"
 #include "mjs_reach.h"
+#include <type_traits>
 #include "mjs_push.h"  // the convex-pair machinery (MPR) for the one convex pair of this scene: wrist cylinder - switch box
 
 namespace bp {
@@ -506,6 +507,215 @@ __device__ __noinline__ StageOut constraint_stage(StageIn in) {
   return out;
 }
 
+// ---- the LEAN stage: at most two active finger-tip contacts, no joint-limit rows ------------------------------------------
+// What almost every constraint solve of this task is (a tip or both on the floor / the switch after a reset, the button being
+// pressed): the static-slot stage above is sized for 12 limit slots + 4 contacts and executes ~10 k instructions per call with
+// a quarter of them register spills (14 k static instructions, 2.4 k v_accvgpr moves, 1.2 k scratch accesses: the post-reset
+// tail of the launch is 20 such calls in a row on the slowest wavefront, profiles/r03_e_*). This one keeps the contact FRAME
+// formulation of the general stage (per contact: W = Jc a + B Jc v, Jc search, D, K imp dist; edges formed on the fly), takes
+// the two contacts from the caller's detection instead of detecting again, has no slot compaction, no limit arrays, and uses
+// reciprocal / reciprocal-square-root refinements instead of IEEE division sequences. Same problem, same warm start, same
+// stopping rules: it returns the same minimiser (to the solver's own rounding), so which of the three stages runs is invisible
+// beyond the last bits.
+template <int NC>
+struct SmallIn {
+  double v[NJ], cs[NJ], sn[NJ], M[21], qs[NJ], warm[NJ], sw[3];
+  double pos[NC][3], nrm[NC][3], sgn[NC], dist[NC];
+  bool on[NC], on_switch[NC], has_warm;
+};
+template <int NC>  // NC = 2 (the usual case) or 4 (both tips on two surfaces each)
+__device__ __noinline__ StageOut constraint_stage_small(SmallIn<NC> in) {
+  const double mu = MJS_GEOM_FRICTION_SLIDE;
+  const double tc = fmax(MJS_SOLREF_TIMECONST, 2 * MJS_RR_PHYSICS_DT), dmax = MJS_SOLIMP_DWIDTH;
+  const double K = 1 / fmax(MJS_MINVAL, dmax * dmax * tc * tc * MJS_SOLREF_DAMPRATIO * MJS_SOLREF_DAMPRATIO);
+  const double B = 2 / fmax(MJS_MINVAL, dmax * tc);
+  double Jc[NC][3][NJ], D[NC], kid[NC], bv[NC][3], W[NC][3], us[NC][3];
+  bool use[NC];  // wave-uniform slot masks: a slot no lane of the wavefront fills costs a scalar branch
+#pragma unroll
+  for (int c = 0; c < NC; c++) use[c] = c == 0 || __any(in.on[c]);
+  {
+    rr::Chain ch;
+    rr::fk_cs(in.cs, in.sn, ch);
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if (!use[c]) continue;
+      const V3 n = v3(in.nrm[c][0], in.nrm[c][1], in.nrm[c][2]), pos = v3(in.pos[c][0], in.pos[c][1], in.pos[c][2]);
+      // mju_makeFrame
+      V3 y = (n.y > -0.5 && n.y < 0.5) ? v3(0, 1, 0) : v3(0, 0, 1);
+      y = madd(y, -dot(n, y), n);
+      const V3 t1 = rr::rsqrt_fast(dot(y, y)) * y, t2 = cross(n, t1);
+      double vel[3] = {0, 0, 0};
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const V3 col = in.sgn[c] * cross(rr::joint_axis(ch, j), pos - ch.p[j + 1]);  // (jac2 - jac1) column
+        Jc[c][0][j] = dot(n, col); Jc[c][1][j] = dot(t1, col); Jc[c][2][j] = dot(t2, col);
+#pragma unroll
+        for (int r = 0; r < 3; r++) vel[r] = fma(Jc[c][r][j], in.v[j], vel[r]);
+      }
+      const double imp = impedance_default(in.dist[c]);
+      const double dA = UR5E_BP_EEF_BODY_INVWEIGHT0[0] + mu * mu * UR5E_BP_EEF_BODY_INVWEIGHT0[0];
+      D[c] = imp * rr::rcp_fast(2 * mu * mu * fmax(MJS_MINVAL * imp, (1 - imp) * dA));  // 1 / (2 mu^2 max(MINVAL, (1 - imp) dA / imp))
+      kid[c] = K * imp * in.dist[c];
+#pragma unroll
+      for (int r = 0; r < 3; r++) bv[c][r] = B * vel[r];
+    }
+  }
+  auto Mat = [&](int i, int j) { return i >= j ? in.M[i * (i + 1) / 2 + j] : in.M[j * (j + 1) / 2 + i]; };
+  double a[NJ], a_s[NJ], Ma[NJ], fc[NJ], H[NJ][NJ], touch = 0;
+  {
+    double L[NJ][NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+#pragma unroll
+      for (int j = 0; j <= i; j++) L[i][j] = in.M[i * (i + 1) / 2 + j];
+      a_s[i] = in.qs[i];
+    }
+    rr::chol6(L);
+    rr::chol6_solve(L, a_s);  // qacc_smooth
+  }
+  const double sr = MJS_SW_BUTTON_RADIUS * MJS_SW_SITE_SCALE, sh = MJS_SW_BUTTON_HALF * MJS_SW_SITE_SCALE;
+  // cost at `a`, J^T force, the frame residuals W and (need_H) the Hessian's lower triangle
+  auto eval = [&](bool need_H) -> double {
+    double cost = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m = fma(Mat(i, k), a[k], m);
+      Ma[i] = m;
+      fc[i] = 0;
+#pragma unroll
+      for (int j = 0; j <= i; j++) H[i][j] = in.M[i * (i + 1) / 2 + j];
+    }
+    touch = 0;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if (!use[c]) continue;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double u = bv[c][r];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) u = fma(Jc[c][r][j], a[j], u);
+        W[c][r] = u;
+      }
+      double f[4], nact[4];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const double x = W[c][0] + ((e & 1) ? -mu : mu) * W[c][1 + (e >> 1)] + kid[c];
+        const bool act = in.on[c] && x < 0;
+        nact[e] = act ? 1.0 : 0.0;
+        f[e] = act ? -D[c] * x : 0.0;
+        if (act) cost += 0.5 * D[c] * x * x;
+      }
+      const double fn = f[0] + f[1] + f[2] + f[3], f1 = mu * (f[0] - f[1]), f2 = mu * (f[2] - f[3]);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) fc[i] += fn * Jc[c][0][i] + f1 * Jc[c][1][i] + f2 * Jc[c][2][i];
+      {  // touch sensor (mj_sensorAcc): normal force of a contact with the switch whose point lies inside the site
+        const double lx = in.pos[c][0] - in.sw[0], ly = in.pos[c][1] - in.sw[1], lz = in.pos[c][2] - (in.sw[2] + MJS_SW_BUTTON_Z);
+        if (in.on[c] && in.on_switch[c] && !(lx * lx + ly * ly > sr * sr || fabs(lz) > sh)) touch += fn;
+      }
+      if (need_H) {
+        const double wn = D[c] * (nact[0] + nact[1] + nact[2] + nact[3]), w1 = D[c] * mu * (nact[0] - nact[1]), w2 = D[c] * mu * (nact[2] - nact[3]);
+        const double w11 = D[c] * mu * mu * (nact[0] + nact[1]), w22 = D[c] * mu * mu * (nact[2] + nact[3]);
+#pragma unroll
+        for (int i = 0; i < NJ; i++) {
+          const double jn = Jc[c][0][i], j1 = Jc[c][1][i], j2 = Jc[c][2][i];
+          const double rn = wn * jn + w1 * j1 + w2 * j2, r1 = w1 * jn + w11 * j1, r2 = w2 * jn + w22 * j2;
+#pragma unroll
+          for (int j = 0; j <= i; j++) H[i][j] += rn * Jc[c][0][j] + r1 * Jc[c][1][j] + r2 * Jc[c][2][j];
+        }
+      }
+    }
+    double gauss = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) gauss += (Ma[i] - in.qs[i]) * (a[i] - a_s[i]);
+    return cost + 0.5 * gauss;
+  };
+#pragma unroll
+  for (int i = 0; i < NJ; i++) a[i] = a_s[i];
+  if (__any(in.has_warm)) {  // mj_fwdConstraint: the cheaper of qacc_warmstart and qacc_smooth, ties to the warm start
+    const double cost_s = eval(false);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) a[i] = in.has_warm ? in.warm[i] : a_s[i];
+    const double cost_w = eval(false);
+    const bool keep = in.has_warm && !(cost_s < cost_w);
+#pragma unroll
+    for (int i = 0; i < NJ; i++) a[i] = keep ? a[i] : a_s[i];
+  }
+  const double scale = 1 / (UR5E_BP_MEANINERTIA * NJ);
+  double oldcost = 0;
+#pragma unroll 1
+  for (int iter = 0; iter <= MJS_SOLVER_ITERATIONS; iter++) {
+    const double cost = eval(true);
+    double grad[NJ], gn = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { grad[i] = Ma[i] - in.qs[i] - fc[i]; gn = fma(grad[i], grad[i], gn); }
+    if (iter > 0 && (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE)) break;
+    if (iter == MJS_SOLVER_ITERATIONS) break;
+    oldcost = cost;
+    double search[NJ], Mv[NJ];
+#pragma unroll
+    for (int i = 0; i < NJ; i++) search[i] = -grad[i];
+    if (!rr::chol6(H)) break;
+    rr::chol6_solve(H, search);
+    double g1 = 0, g2 = 0, snorm = 0;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) {
+      double m = 0;
+#pragma unroll
+      for (int k = 0; k < NJ; k++) m = fma(Mat(i, k), search[k], m);
+      Mv[i] = m;
+    }
+#pragma unroll
+    for (int i = 0; i < NJ; i++) { g1 += search[i] * (Ma[i] - in.qs[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
+    if (sqrt(snorm) < MJS_MINVAL) break;
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+      if (!use[c]) continue;
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        double u = 0;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) u = fma(Jc[c][r][j], search[j], u);
+        us[c][r] = u;
+      }
+    }
+    const double gtol = MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale;
+    double alpha = 0, lo = 0, hi = INFINITY;
+#pragma unroll 1
+    for (int it = 0; it < 50; it++) {
+      double d1 = g1 + alpha * g2, d2 = g2;
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        if (!use[c]) continue;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const double sm = (e & 1) ? -mu : mu;
+          const double jar = W[c][0] + sm * W[c][1 + (e >> 1)] + kid[c], jv = us[c][0] + sm * us[c][1 + (e >> 1)];
+          const double x = jar + alpha * jv;
+          if (in.on[c] && x < 0) { d1 += D[c] * x * jv; d2 += D[c] * jv * jv; }
+        }
+      }
+      if (fabs(d1) < gtol) break;
+      if (d1 < 0) lo = alpha; else hi = alpha;
+      if (d2 <= 0) break;
+      double next = alpha - d1 * rr::rcp_fast(d2);
+      if (!(next > lo && next < hi)) next = isfinite(hi) ? 0.5 * (lo + hi) : (alpha > 0 ? 2 * alpha : 1.0);
+      if (fabs(next - alpha) <= 1e-15 * fmax(1.0, fabs(alpha))) { alpha = next; break; }
+      alpha = next;
+    }
+    if (alpha == 0) break;
+#pragma unroll
+    for (int i = 0; i < NJ; i++) a[i] = fma(alpha, search[i], a[i]);
+  }
+  StageOut out;
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { out.qs[j] = in.qs[j] + fc[j]; out.qacc[j] = a[j]; }
+  out.touch = touch;
+  out.overflow = false;
+  return out;
+}
+
 // The scene as the general constraint stage (mjs_arm_stage.h) sees it: the arm's own geoms against the floor come from the
 // stage itself; this adds the two finger-tip spheres' contacts (body = the gripper lump on wrist_3: all six joints move it)
 // in MuJoCo's pair order (geom ids: floor, arm, tip +y, tip -y, switch box, button): floor - tip 0, floor - tip 1,
@@ -578,7 +788,55 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   rows = rows || arm;
   if (rows) {  // rare: hand copies to an out-of-line constraint stage, nothing of the hot path lives in memory
     if (w.lazy) { rr::smooth_acceleration(w.pM, w.pqs, w.warm); w.has_warm = true; w.lazy = false; }
-    if (__any(arm)) {
+    // which stage? Decided per LANE from the lane's own rows (the three stages agree to the solver's rounding, not to the bit: a
+    // choice that looked at the other lanes of the wavefront would make an env's last bits depend on its neighbours and break
+    // the bitwise shard invariance the multi-GPU path relies on); lanes of one wavefront that differ run their stages in turn
+    int n_tip = 0;
+#pragma unroll
+    for (int c = 0; c < NCS; c++) n_tip += (con.hit[c] && con.dist[c] < 0.0) ? 1 : 0;
+    const bool lean = !(arm || n_tip > 4 || rr::joint_outside_range(q));
+    auto run_lean = [&](auto tag) {
+      constexpr int NC = decltype(tag)::value;
+      SmallIn<NC> in;
+#pragma unroll
+      for (int i = 0; i < NJ; i++) { in.v[i] = v[i]; in.cs[i] = cs[i]; in.sn[i] = sn[i]; in.qs[i] = rhs[i]; in.warm[i] = w.warm[i]; }
+#pragma unroll
+      for (int k = 0; k < 21; k++) in.M[k] = M[k];
+      in.sw[0] = sw.x; in.sw[1] = sw.y; in.sw[2] = sw.z;
+      in.has_warm = w.has_warm;
+      // the lane's active tip contacts in detection order, by branch-free selects
+#pragma unroll
+      for (int j = 0; j < NC; j++) {
+        in.on[j] = false; in.on_switch[j] = false; in.sgn[j] = 1.0; in.dist[j] = 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { in.pos[j][k] = 0.0; in.nrm[j][k] = k == 2 ? 1.0 : 0.0; }
+      }
+      int cnt = 0;
+#pragma unroll
+      for (int c = 0; c < NCS; c++) {
+        const bool act = con.hit[c] && con.dist[c] < 0.0;
+#pragma unroll
+        for (int j = 0; j < NC; j++) {
+          const bool take = act && cnt == j;
+          in.on[j] = take ? true : in.on[j];
+          in.on_switch[j] = take ? con.on_switch[c] : in.on_switch[j];
+          in.sgn[j] = take ? con.sgn[c] : in.sgn[j];
+          in.dist[j] = take ? con.dist[c] : in.dist[j];
+          in.pos[j][0] = take ? con.pos[c].x : in.pos[j][0]; in.pos[j][1] = take ? con.pos[c].y : in.pos[j][1]; in.pos[j][2] = take ? con.pos[c].z : in.pos[j][2];
+          in.nrm[j][0] = take ? con.nrm[c].x : in.nrm[j][0]; in.nrm[j][1] = take ? con.nrm[c].y : in.nrm[j][1]; in.nrm[j][2] = take ? con.nrm[c].z : in.nrm[j][2];
+        }
+        cnt += act ? 1 : 0;
+      }
+      const StageOut out = constraint_stage_small<NC>(in);
+#pragma unroll
+      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; w.warm[i] = out.qacc[i]; }
+      touch = out.touch;
+    };
+    if (lean && n_tip <= 2) {
+      run_lean(std::integral_constant<int, 2>{});
+    } else if (lean) {
+      run_lean(std::integral_constant<int, 4>{});
+    } else if (arm) {
       rr::GenStageIn gi;
 #pragma unroll
       for (int i = 0; i < NJ; i++) { gi.q[i] = q[i]; gi.v[i] = v[i]; gi.cs[i] = cs[i]; gi.sn[i] = sn[i]; gi.qs[i] = rhs[i]; gi.warm[i] = w.warm[i]; }
