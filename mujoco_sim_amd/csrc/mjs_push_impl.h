@@ -1756,7 +1756,10 @@ MJS_DEV void detect_body(int nb, bool live, M3* Rb, FloorSlots* fs, ConvexHits& 
   }  // live
 }
 
-__device__ __noinline__ void detect_phase(int nb, bool live) {
+// (round 3) inlined into the substep: as a call it saved / restored the callee-saved registers it used in every substep for all 64
+// lanes, 0.37 GB of scratch writes per 4096-env launch; inlined the launch moves 0.14 GB instead of 0.44 GB at the same speed
+// within the run-to-run spread (profiles/r03_f_push_traffic.txt; in round 2's build the same change cost 8 %).
+__device__ __forceinline__ void detect_phase(int nb, bool live) {
   EnvLds& env = env_lds();
   bool arm_in = false, blk_in[NB];
 #pragma unroll
