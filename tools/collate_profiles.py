@@ -4,7 +4,7 @@ JSON files bench.py reads: profiles/<round>_traffic_all_tasks.json (HBM bytes pe
 WRITE_SIZE passes, FETCH_SIZE corrected by the gfx950 calibration 0.5039 of profiles/r01_traffic.json) and
 profiles/<round>_reach_valu.json (VALU busy share of a wavefront's lifetime for the default Robot-Reach launch).
 
-usage: python tools/collate_profiles.py r2p r02
+usage: python tools/collate_profiles.py r3p r03
 """
 import csv
 import json
@@ -16,7 +16,7 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parents[1]
 FETCH_CALIBRATION = 0.5039
 STEP_KERNELS = {"robot_reach": "rr::kernel3", "point_mass_reach": "pm::kernel<false>", "robot_push_button": "bp::kernel<false", "robot_planar_push": "pp::kernel<false>"}
-ALG_BYTES = {"robot_reach": 379, "point_mass_reach": 267, "robot_push_button": 419, "robot_planar_push": 843}
+ALG_BYTES = {"robot_reach": 571, "point_mass_reach": 267, "robot_push_button": 643, "robot_planar_push": 843}  # mjs_algorithmic_bytes_per_env_step (abi 2)
 
 
 def find(d, suffix):

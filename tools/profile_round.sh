@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round profiles (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r2p'): rocprofv3 kernel-trace statistics of the
+# Round profiles (run on the GPU box: gpurun -- 'bash tools/profile_round.sh r3p'): rocprofv3 kernel-trace statistics of the
 # default bench command and of the secondary workloads, and the PMC passes (FETCH_SIZE and WRITE_SIZE in SEPARATE passes, as
 # /opt/skills/guides/MI355X_MICROARCH.md prescribes; the SQ counters in a third). Counter passes never combine with the
 # hip / hsa / memory-copy trace domains. Outputs land under gpurun_out/<tag>/; tools/collate_profiles.py copies the summaries
 # into profiles/.
 set -o pipefail
-tag=${1:-r2p}
+tag=${1:-r3p}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
