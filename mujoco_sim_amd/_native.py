@@ -97,12 +97,26 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     # enable-ipra=0: with inter-procedural register allocation the call to the (rare, register-hungry) robust path clobbers every
     # AGPR in the step kernels' eyes, and their hot loops then spill to scratch instead of to AGPRs: Robot-Reach 39.7 -> 36.8 us,
     # Button-Push 110.9 -> 93.9 us per launch (profiles/r03_c_ipra_ab.txt); Planar-Push / Pointmass unchanged.
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-comment",
-           "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-enable-ipra=0", f'-DMJS_SOURCE_HASH="{want}"',
-           "-o", str(LIB_PATH), str(_PKG / "csrc" / "mjsim.hip")]
-    res = subprocess.run(cmd, capture_output=True, text=True)
-    if res.returncode != 0:
-        raise MjsError(f"hipcc failed:\n{res.stderr}")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-comment", "-mllvm", "-amdgpu-sched-strategy=max-ilp", "-mllvm", "-enable-ipra=0",
+             f'-DMJS_SOURCE_HASH="{want}"']
+    src = str(_PKG / "csrc" / "mjsim.hip")
+    # the same compilation once more, to device assembly, for the ISA lint (_isa_lint.py: a code-generation fault of this
+    # compiler that the flags above provoke around out-of-line calls); both run side by side
+    asm_path = LIB_PATH.with_suffix(".gfx950.s")
+    asm = subprocess.Popen([hipcc, *flags, "-S", "--cuda-device-only", "-Wno-unused-command-line-argument", "-o", str(asm_path), src],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    res = subprocess.run([hipcc, *flags, "-fPIC", "-shared", "-o", str(LIB_PATH), src], capture_output=True, text=True)
+    asm_err = asm.communicate()[1]
+    if res.returncode != 0 or asm.returncode != 0:
+        LIB_PATH.unlink(missing_ok=True)
+        raise MjsError(f"hipcc failed:\n{res.stderr}\n{asm_err}")
+    from ._isa_lint import lint
+    findings = lint(asm_path.read_text().split("\n"))
+    asm_path.unlink(missing_ok=True)
+    if findings:
+        LIB_PATH.unlink(missing_ok=True)
+        raise MjsError("ISA lint: register copies ahead of an exec-mask restore (see mujoco_sim_amd/_isa_lint.py): "
+                       + "; ".join(f"{fn} {label}: {copies[:2]}" for fn, label, copies, _ in findings))
     if verbose:
         print(res.stderr)
     return LIB_PATH

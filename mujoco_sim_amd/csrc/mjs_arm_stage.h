@@ -65,10 +65,16 @@ MJS_DEV double min_floor_clearance(const Chain& c) {
     const M3 R = c.R[b];
     const double gz = c.p[b].z + MJS_UR_COL_POS[g][0] * R.cx.z + MJS_UR_COL_POS[g][1] * R.cy.z + MJS_UR_COL_POS[g][2] * R.cz.z;
     const double az = (MJS_UR_COL_QUAT[g][1] != 0.0) ? R.cy.z : R.cz.z;
-    m = fmin(m, gz - MJS_UR_COL_SIZE[g][1] * fabs(az) - MJS_UR_COL_SIZE[g][0]);
+    // geom 2 (the upper arm's long capsule along local z) has its near end sphere ON the shoulder-lift axis (offset - half-length
+    // = 0): that end stays 0.163 - 0.05 m above the floor whatever the joints do; only its far (elbow) end can come down
+    const double lowest_end = g == 2 ? MJS_UR_COL_SIZE[g][1] * az : -MJS_UR_COL_SIZE[g][1] * fabs(az);
+    m = fmin(m, gz + lowest_end - MJS_UR_COL_SIZE[g][0]);
   }
   return m;
 }
+static_assert(MJS_UR_COL_BODY[2] == 2 && MJS_UR_COL_TYPE[2] == 3 && MJS_UR_COL_QUAT[2][1] == 0.0 && MJS_UR_COL_POS[2][0] == 0.0 && MJS_UR_COL_POS[2][1] == 0.0 &&
+                  MJS_UR_COL_POS[2][2] == MJS_UR_COL_SIZE[2][1] && MJS_UR_BODY_POS[1][2] - MJS_UR_COL_SIZE[2][0] > 0,
+              "the upper arm's long capsule is assumed to start on the shoulder-lift axis");
 // geom 0: capsule on the shoulder link along its vertical joint axis: lowest point 3 mm above the floor, fixed.
 // geom 1: capsule on the upper arm along the shoulder-lift axis (local y, horizontal in every configuration: the only joint
 // before it turns about the vertical), centred on that axis at the shoulder's height: lowest point 0.163 - 0.06 m, fixed.

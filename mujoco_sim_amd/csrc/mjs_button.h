@@ -24,7 +24,7 @@
 namespace bp {
 
 using rr::NJ;
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16, HOT_STATE_DIM = 18;  // S_GRIP: driver angle, velocity of the reduced 2F-85
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_SWITCH = 13, S_GRIP = 16;  // S_GRIP: driver angle, velocity of the reduced 2F-85
 constexpr int S_WARM = 18;  // rows 18-23: qacc_warmstart, robust path only (see rr::S_WARM)
 constexpr int S_CS = 24, S_SN = 30, STATE_DIM = 36;  // rows 24-35: the carried cos / sin of the joint angles (see rr::S_CS)
 constexpr int HOT_ROWS_READ = 18 + 12, HOT_ROWS_WRITTEN = 15 + 12;
@@ -756,23 +756,11 @@ struct WarmState {
 
 // One Physics.step() of a lane on the robust path: smooth dynamics (generated, Button-Push payload variant), detection of
 // every row this scene can have (joint ranges, the arm's geoms on the floor, the finger tips on floor / switch box / button),
-// the constraint stage for the lanes that have one — the static-slot stage above while only limits and tip contacts are
-// active in the wavefront, the general stage (rr::gen_stage: any number of arm-floor contacts) as soon as a lane has a link
-// in the floor —, then the implicitfast solve. Returns the integrator's acceleration.
+// the constraint stage for the lanes that have rows (a lean stage for up to four tip contacts, the static-slot stage with the
+// joint limits, the general stage rr::gen_stage as soon as the lane has a link in the floor or the wrist on the switch box),
+// then the implicitfast solve. Returns the integrator's acceleration.
 MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl, const double* cs, const double* sn, V3 sw, double grip_th,
                             double* qacc_int, double& touch, int& ncon_proxy, bool& rows_active, bool& slot_overflow, WarmState& w, rr::Ws ws) {
-  double M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
-  ur5e_bp_M_gen(cs, sn, M);
-  ur5e_bp_bias_gen(cs, sn, v, bias);
-#pragma unroll
-  for (int i = 0; i < NJ; i++) {
-#pragma unroll
-    for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
-    M[i * (i + 1) / 2 + i] += MJS_UR_ARMATURE;
-  }
-  const int clamped = rr::actuator_forces(q, v, ctrl, fact);
-#pragma unroll
-  for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];
   touch = 0;
   // cheap in-line detection: any joint beyond its range, an arm geom in the floor, an active contact of a finger-tip sphere?
   bool rows = rr::joint_outside_range(q);
@@ -783,19 +771,47 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
   ContactSet con;
   detect_contacts(ch, grip_th, sw, con);
   ncon_proxy = con.n + (wb.hit ? 1 : 0);
+  int n_tip = 0;
 #pragma unroll
-  for (int c = 0; c < NCS; c++) rows = rows || (con.hit[c] && con.dist[c] < 0.0);
-  rows = rows || arm;
-  if (rows) {  // rare: hand copies to an out-of-line constraint stage, nothing of the hot path lives in memory
-    if (w.lazy) { rr::smooth_acceleration(w.pM, w.pqs, w.warm); w.has_warm = true; w.lazy = false; }
-    // which stage? Decided per LANE from the lane's own rows (the three stages agree to the solver's rounding, not to the bit: a
-    // choice that looked at the other lanes of the wavefront would make an env's last bits depend on its neighbours and break
-    // the bitwise shard invariance the multi-GPU path relies on); lanes of one wavefront that differ run their stages in turn
-    int n_tip = 0;
+  for (int c = 0; c < NCS; c++) n_tip += (con.hit[c] && con.dist[c] < 0.0) ? 1 : 0;
+  rows = rows || arm || n_tip > 0;
+  // Rows are rare. Every out-of-line function below is CALLED BY THE WHOLE WAVEFRONT behind a wave-uniform branch and its
+  // results are taken by per-lane selects (rr::solo_control_step says why: hipcc's split copies ahead of the exec restore of
+  // a divergent join next to a call, _isa_lint.py).
+  // 1. the warm start a row-free step left behind as (pM, pqs), needed now: qacc_warmstart = pM^-1 pqs
+  const bool eval_lazy = rows && w.lazy;
+  if (__any(eval_lazy)) {
+    double wl[NJ];
+    rr::smooth_acceleration(w.pM, w.pqs, wl);
 #pragma unroll
-    for (int c = 0; c < NCS; c++) n_tip += (con.hit[c] && con.dist[c] < 0.0) ? 1 : 0;
+    for (int j = 0; j < NJ; j++) w.warm[j] = eval_lazy ? wl[j] : w.warm[j];
+    w.has_warm = w.has_warm || eval_lazy;
+  }
+  // 2. smooth dynamics; M + armature and qfrc_smooth go straight into (pM, pqs): what a row-free step leaves for the next one
+  double bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
+  double* const M = w.pM;
+  ur5e_bp_M_gen(cs, sn, M);
+  ur5e_bp_bias_gen(cs, sn, v, bias);
+#pragma unroll
+  for (int i = 0; i < NJ; i++) {
+#pragma unroll
+    for (int j = 0; j <= i; j++) A[i][j] = M[i * (i + 1) / 2 + j];
+    M[i * (i + 1) / 2 + i] += MJS_UR_ARMATURE;
+  }
+  const int clamped = rr::actuator_forces(q, v, ctrl, fact);
+#pragma unroll
+  for (int j = 0; j < NJ; j++) { rhs[j] = fact[j] - bias[j]; w.pqs[j] = rhs[j]; }
+  w.lazy = !rows;
+  // 3. the constraint stage of the lanes with rows. Which stage? Decided per LANE from the lane's own rows (the stages agree to
+  // the solver's rounding, not to the bit: a choice that looked at the other lanes of the wavefront would make an env's last
+  // bits depend on its neighbours and break the bitwise shard invariance the multi-GPU path relies on); a wavefront whose
+  // lanes differ runs their stages in turn and each lane keeps the result of its own. Exactly one of the four per lane: a lane
+  // that has taken its stage's result feeds the later stages changed inputs and discards what they make of them.
+  if (__any(rows)) {
     const bool lean = !(arm || n_tip > 4 || rr::joint_outside_range(q));
-    auto run_lean = [&](auto tag) {
+    const bool want_lean2 = rows && lean && n_tip <= 2, want_lean4 = rows && lean && n_tip > 2;
+    const bool want_general = rows && !lean && arm, want_static = rows && !lean && !arm;
+    auto run_lean = [&](auto tag, bool mine) {
       constexpr int NC = decltype(tag)::value;
       SmallIn<NC> in;
 #pragma unroll
@@ -829,14 +845,12 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
       }
       const StageOut out = constraint_stage_small<NC>(in);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; w.warm[i] = out.qacc[i]; }
-      touch = out.touch;
+      for (int i = 0; i < NJ; i++) { rhs[i] = mine ? out.qs[i] : rhs[i]; w.warm[i] = mine ? out.qacc[i] : w.warm[i]; }
+      touch = mine ? out.touch : touch;
     };
-    if (lean && n_tip <= 2) {
-      run_lean(std::integral_constant<int, 2>{});
-    } else if (lean) {
-      run_lean(std::integral_constant<int, 4>{});
-    } else if (arm) {
+    if (__any(want_lean2)) run_lean(std::integral_constant<int, 2>{}, want_lean2);
+    if (__any(want_lean4)) run_lean(std::integral_constant<int, 4>{}, want_lean4);
+    if (__any(want_general)) {
       rr::GenStageIn gi;
 #pragma unroll
       for (int i = 0; i < NJ; i++) { gi.q[i] = q[i]; gi.v[i] = v[i]; gi.cs[i] = cs[i]; gi.sn[i] = sn[i]; gi.qs[i] = rhs[i]; gi.warm[i] = w.warm[i]; }
@@ -846,10 +860,11 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
       const rr::GenStageOut go = rr::gen_stage<SceneButton>(
           gi, SceneButton::Extra{{sw.x, sw.y, sw.z}, grip_th, wb.hit, wb.dist, {wb.pos.x, wb.pos.y, wb.pos.z}, {wb.nrm.x, wb.nrm.y, wb.nrm.z}}, ws);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) { rhs[i] = go.qs[i]; w.warm[i] = go.qacc[i]; }
-      touch = go.touch;
-      slot_overflow = slot_overflow || go.overflow;
-    } else {
+      for (int i = 0; i < NJ; i++) { rhs[i] = want_general ? go.qs[i] : rhs[i]; w.warm[i] = want_general ? go.qacc[i] : w.warm[i]; }
+      touch = want_general ? go.touch : touch;
+      slot_overflow = slot_overflow || (want_general && go.overflow);
+    }
+    if (__any(want_static)) {
       StageIn in;
 #pragma unroll
       for (int i = 0; i < NJ; i++) { in.q[i] = q[i]; in.v[i] = v[i]; in.cs[i] = cs[i]; in.sn[i] = sn[i]; in.qs[i] = rhs[i]; in.warm[i] = w.warm[i]; }
@@ -860,18 +875,12 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
       in.has_warm = w.has_warm;
       const StageOut out = constraint_stage(in);
 #pragma unroll
-      for (int i = 0; i < NJ; i++) { rhs[i] = out.qs[i]; w.warm[i] = out.qacc[i]; }
-      touch = out.touch;
-      slot_overflow = slot_overflow || out.overflow;
+      for (int i = 0; i < NJ; i++) { rhs[i] = want_static ? out.qs[i] : rhs[i]; w.warm[i] = want_static ? out.qacc[i] : w.warm[i]; }
+      touch = want_static ? out.touch : touch;
+      slot_overflow = slot_overflow || (want_static && out.overflow);
     }
-    w.has_warm = true;
-    rows_active = true;
-  } else {
-#pragma unroll
-    for (int k = 0; k < 21; k++) w.pM[k] = M[k];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) w.pqs[j] = rhs[j];
-    w.lazy = true;
+    w.has_warm = w.has_warm || rows;
+    rows_active = rows_active || rows;
   }
   rr::factor_system(A, clamped, Dinv);
   rr::udu_solve(A, Dinv, rhs);
@@ -1033,8 +1042,9 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, rr::Ws ws) {
   for (int k = 0; k < 21; k++) w.pM[k] = 0;
   w.has_warm = in.has_warm; w.lazy = false;
   int ncon_proxy = 0;
+  const int first_substep = __builtin_amdgcn_readfirstlane(in.first_substep);  // wave-uniform (the kernel's solo_from): a scalar loop counter
 #pragma unroll 1
-  for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
+  for (int s = first_substep; s < MJS_RR_NSUB; s++) {
     double t = fmin(fmax(time, t0), t1);
     double ctrl[NJ], qacc[NJ], touch;
 #pragma unroll

@@ -30,7 +30,7 @@
 
 namespace rr {
 
-constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, HOT_STATE_DIM = 16;
+constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13;
 // rows 16-21: qacc_warmstart (mjData state: the solver acceleration of the last Physics.step()). Only the robust path reads or
 // writes them (flag FLAG_WARM_VALID says whether they belong to the current state); the row-free fast path never touches them.
 constexpr int S_WARM = 16;
@@ -1209,11 +1209,34 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
   const double t0 = in.t0, t1 = in.t1, inv_span = 1.0 / (in.t1 - in.t0);
   bool bad = false, rows_active = false, overflow = false;
   bool has_warm = in.has_warm, lazy = false;  // lazy: the warm start is M^-1 qfrc_smooth of (pM, pqs), not yet evaluated
+  const int first_substep = __builtin_amdgcn_readfirstlane(in.first_substep);  // the same for every lane of a caller: a scalar loop counter
 #pragma unroll 1
-  for (int s = in.first_substep; s < MJS_RR_NSUB; s++) {
-    // before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47)
+  for (int s = first_substep; s < MJS_RR_NSUB; s++) {
+    // rows this substep? A joint beyond its range or a collision geom in the floor: rare
+    bool rows = joint_outside_range(q);
+    {
+      Chain ch;
+      fk_cs(cs, sn, ch);
+      rows = rows || !(min_floor_clearance(ch) >= 0.0);
+    }
+    // The out-of-line functions below are CALLED BY THE WHOLE WAVEFRONT (wave-uniform branches only around a call, per-lane
+    // selects of its results; a lane without rows discards them, so what a lane computes never depends on its neighbours):
+    // hipcc places live-range split copies ahead of the exec-mask restore of a divergent join next to a call
+    // (mujoco_sim_amd/_isa_lint.py), which lost the sub-step counter of the lanes that skipped the `if`.
+    // 1. the warm start a row-free substep left behind as (pM, pqs), needed now: qacc_warmstart = pM^-1 pqs
+    const bool eval_lazy = rows && lazy;
+    if (__any(eval_lazy)) {
+      double wl[NJ];
+      smooth_acceleration(pM, pqs, wl);
+#pragma unroll
+      for (int j = 0; j < NJ; j++) warm[j] = eval_lazy ? wl[j] : warm[j];
+      has_warm = has_warm || eval_lazy;
+    }
+    // 2. before_substep: ctrl = q0 + (q1 - q0) * (clip(t) - t0) / (t1 - t0)  (joint_trajectory.py:41-47), smooth dynamics;
+    // M + armature and qfrc_smooth go straight into (pM, pqs): what a row-free substep leaves for the next one
     double t = fmin(fmax(time, t0), t1);
-    double ctrl[NJ], M[21], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
+    double ctrl[NJ], bias[NJ], A[NJ][NJ], rhs[NJ], Dinv[NJ], fact[NJ];
+    double* const M = pM;
 #pragma unroll
     for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
     ur5e_dynamics_gen(cs, sn, v, M, bias);
@@ -1225,15 +1248,10 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
     }
     const int clamped = actuator_forces(q, v, ctrl, fact);
 #pragma unroll
-    for (int j = 0; j < NJ; j++) rhs[j] = fact[j] - bias[j];  // qfrc_smooth = passive - bias + actuator
-    bool rows = joint_outside_range(q);
-    {
-      Chain ch;
-      fk_cs(cs, sn, ch);
-      rows = rows || !(min_floor_clearance(ch) >= 0.0);
-    }
-    if (rows) {  // rare: a joint beyond its range or a collision geom in the floor
-      if (lazy) { smooth_acceleration(pM, pqs, warm); has_warm = true; lazy = false; }
+    for (int j = 0; j < NJ; j++) { rhs[j] = fact[j] - bias[j]; pqs[j] = rhs[j]; }  // qfrc_smooth = passive - bias + actuator
+    lazy = !rows;
+    // 3. the constraint stage
+    if (__any(rows)) {
       GenStageIn gi;
 #pragma unroll
       for (int j = 0; j < NJ; j++) { gi.q[j] = q[j]; gi.v[j] = v[j]; gi.cs[j] = cs[j]; gi.sn[j] = sn[j]; gi.qs[j] = rhs[j]; gi.warm[j] = warm[j]; }
@@ -1242,16 +1260,10 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
       gi.has_warm = has_warm;
       const GenStageOut go = gen_stage<SceneReach>(gi, SceneReach::Extra{}, ws);
 #pragma unroll
-      for (int j = 0; j < NJ; j++) { rhs[j] = go.qs[j]; warm[j] = go.qacc[j]; }
-      has_warm = true;
-      rows_active = true;
-      overflow = overflow || go.overflow;
-    } else {
-#pragma unroll
-      for (int k = 0; k < 21; k++) pM[k] = M[k];
-#pragma unroll
-      for (int j = 0; j < NJ; j++) pqs[j] = rhs[j];
-      lazy = true;
+      for (int j = 0; j < NJ; j++) { rhs[j] = rows ? go.qs[j] : rhs[j]; warm[j] = rows ? go.qacc[j] : warm[j]; }
+      has_warm = has_warm || rows;
+      rows_active = rows_active || rows;
+      overflow = overflow || (rows && go.overflow);
     }
     factor_system(A, clamped, Dinv);
     udu_solve(A, Dinv, rhs);

@@ -573,6 +573,71 @@ def test_reach_links_on_the_floor_match_oracle(oracle_mod, variant):
     assert n_rows > 30 and n_arm > 30, (n_rows, n_arm)
 
 
+def _top_down_ik_is_a_tie(oracle_mod, tcp, guess, tcp_z=0.174, eps=1e-9):
+    """inverse_kinematics_closest picks, per solution and joint, the 2*pi-shifted angle when it is STRICTLY closer to the guess,
+    then the solution with the smallest distance. Where two candidates are equally far to the last bit (the wrist_2 joint rests
+    at exactly pi/2 after a reset; a solution with wrist_2 = -pi/2 is pi away in both directions) the winner is decided by the
+    rounding of the solver's arithmetic, in the reference's library as much as in the oracle: such commands have no defined
+    answer to compare."""
+    R = np.array([[1.0, 0, 0], [0, -1, 0], [0, 0, -1]])  # TOP_DOWN_QUATERNION (1, 0, 0, 0), scalar last
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = np.asarray(tcp) - R[:, 2] * tcp_z
+    sols = oracle_mod.ur5e_ik_all(T)
+    if len(sols) == 0:
+        return False
+    alt = sols + np.where(guess > sols, 2 * np.pi, -2 * np.pi)
+    d_plain = np.abs(sols - guess)
+    d_alt = np.where(np.abs(alt) <= 2 * np.pi + eps, np.abs(alt - guess), np.inf)
+    dist = (np.minimum(d_plain, d_alt) ** 2).sum(axis=1)
+    order = np.argsort(dist)
+    if len(order) > 1 and dist[order[1]] - dist[order[0]] < eps:
+        return True  # two solutions equally far
+    return bool((np.abs(d_plain[order[0]] - d_alt[order[0]]) < eps).any())  # the winner's own 2*pi shift equally far
+
+
+def test_reach_arbitrary_actions_match_oracle(oracle_mod):
+    """Robot-Reach is registered with the workspace box as its action bounds, but nothing clips an action: targets far outside
+    the box (below the floor, beside the base, out of reach: IK failures hold the joints) send the workgroup to the robust path
+    (the fast path's guard accepts in-box targets only), where links land on the floor and joints reach their ranges. Every env
+    against the oracle for 60 steps; an env leaves the comparison when a command's closest IK solution is an exact tie
+    (_top_down_ik_is_a_tie: a handful, right after a reset)."""
+    import mujoco_sim_amd as m
+
+    N, T = 192, 60
+    venv = m.HipVectorEnv("robot_reach", N, seed=31)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, N, 31, nthreads=8)
+    venv.reset()
+    q_now = ob.reset()["obs"][:, 3:9].copy()
+    rs = np.random.RandomState(8)
+    n_arm = n_rows = n_ik = n_tie = 0
+    alive = np.ones(N, bool)
+    for t in range(T):
+        a = rs.uniform([-0.6, -0.9, -0.15], [0.6, 0.1, 0.5], (N, 3))
+        a[: N // 3] = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N // 3, 3))  # a third of the envs stays in the box
+        for i in np.nonzero(alive)[0]:
+            if _top_down_ik_is_a_tie(oracle_mod, a[i], q_now[i]):
+                alive[i] = False
+                n_tie += 1
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        q_now = o["obs"][:, 3:9].copy()
+        n_arm += int(ob.arm_floor_seen()[alive].sum())
+        alive &= ~o["fault"] & ~(g["fault"] & (1 | 8 | 16)).astype(bool)
+        np.testing.assert_allclose(g["obs"][alive], o["obs"][alive], rtol=0, atol=1e-7, err_msg=f"step {t}")
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[alive].astype(np.int64), np.asarray(o[k])[alive].astype(np.int64)), (k, t)
+        assert np.array_equal((g["fault"] & 2).astype(bool)[alive], o["ik_failed"][alive].astype(bool)), t
+        n_rows += int(((g["fault"] & 4) > 0)[alive].sum())
+        n_ik += int(o["ik_failed"][alive].sum())
+    print("Robot-Reach, arbitrary actions:", dict(alive=alive.mean(), ik_ties=n_tie, arm_floor_env_steps=n_arm, rows_env_steps=n_rows, ik_failed_env_steps=n_ik))
+    assert alive.mean() > 0.9 and n_tie < 0.08 * N and n_arm > 50 and n_rows > 50 and n_ik > 50, (alive.mean(), n_tie, n_arm, n_rows, n_ik)
+    # the in-box third never left the fast path's domain: no rows, no reports, no ties
+    assert not (g["fault"][: N // 3] & (4 | 8 | 16)).any() and alive[: N // 3].all()
+    venv.close()
+
+
 def test_reach_guard_is_velocity_aware(oracle_mod):
     """mjs_set_state can inject any joint velocity: an elbow 1.2 rad from its range moving at up to 14 rad/s. The fast
     path's guard counts the velocity (0.6 rad + |v| * 0.1 s: such envs take the robust path, which checks limits and floor

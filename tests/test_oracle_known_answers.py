@@ -678,3 +678,76 @@ def test_static_equilibrium_closed_form(oracle_mod):
             tau = gravity_torque(q)
             assert np.abs(tau).max() > 0.5  # the lump does load the joints
             np.testing.assert_allclose(kp * (home - q), -tau, rtol=0, atol=1e-6)
+
+
+def test_reach_fast_path_guard_assumptions_hold_in_the_action_box(oracle_mod):
+    """The Robot-Reach fast path (mjs_reach.h, "the fast path's guard") assumes about the task's OWN action box
+    (robot_reach.py:187-201, x in [-0.1, 0.1], y in [-0.6, -0.4], z in [0.02, 0.2], tool down): every configuration the
+    oracle reaches under uniform in-box targets keeps the arm's collision geoms (all but the two that cannot move vertically)
+    at least CLEAR_MARGIN = 0.10 m above the floor, and the joint-space travel measure of a control step,
+    sum_j (|q1_j - q0_j| + 0.05 |v_j|)^2 with q1 the IK target, stays below TRAVEL2_MAX = 2.5. Checked here on the CPU with an
+    independent numpy FK of include/mjs_scene_spec.h (so that a change of the scene constants that breaks the assumption is
+    caught without a GPU)."""
+    import re
+    from pathlib import Path
+
+    spec = (Path(__file__).resolve().parents[1] / "include" / "mjs_scene_spec.h").read_text()
+
+    def arr(name, shape):
+        m = re.search(name + r"(?:\[[^\]]*\])*\s*=\s*\{(.*?)\};", spec, re.S)
+        body = re.sub(r"/\*.*?\*/", "", m.group(1), flags=re.S)
+        return np.array([float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", body)]).reshape(shape)
+
+    BP, BQ, AX = arr("MJS_UR_BODY_POS", (7, 3)), arr("MJS_UR_BODY_QUAT", (7, 4)), arr("MJS_UR_JNT_AXIS", (6, 3))
+    CB, CP, CQ, CS = arr("MJS_UR_COL_BODY", (10,)).astype(int), arr("MJS_UR_COL_POS", (10, 3)), arr("MJS_UR_COL_QUAT", (10, 4)), arr("MJS_UR_COL_SIZE", (10, 2))
+
+    def q2m(q):
+        w, x, y, z = q / np.linalg.norm(q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def rot(ax, a):
+        K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+        return np.eye(3) + np.sin(a) * K + (1 - np.cos(a)) * K @ K
+
+    def clearance(q):
+        R, p, Rs, ps = np.eye(3), np.zeros(3), [], []
+        for b in range(7):
+            p = p + R @ BP[b]
+            R = R @ q2m(BQ[b])
+            if b > 0:
+                R = R @ rot(AX[b - 1], q[b - 1])
+            Rs.append(R.copy()); ps.append(p.copy())
+        m = 1e9
+        for g in range(2, 10):  # geoms 0, 1 and the shoulder-side end of geom 2 sit on the first two joint axes: fixed heights (mjs_arm_stage.h)
+            b = CB[g]
+            gp, ax = ps[b] + Rs[b] @ CP[g], (Rs[b] @ q2m(CQ[g]))[:, 2]
+            ends = [gp[2] + CS[g][1] * ax[2]] if g == 2 else [gp[2] - CS[g][1] * abs(ax[2])]
+            m = min(m, min(ends) - CS[g][0])
+        return m
+
+    N, T = 64, 110
+    b = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, N, 2025, nthreads=8)
+    o = b.reset()
+    acts = np.random.RandomState(12345).uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (T, N, 3))
+    q, qold = o["obs"][:, 3:9].copy(), o["obs"][:, 3:9].copy()
+    min_clr, max_t2 = 1e9, 0.0
+    for t in range(T):
+        v = (q - qold) / 0.1
+        for i in range(0, N, 4):
+            min_clr = min(min_clr, clearance(q[i]))
+            Tm = np.eye(4)
+            Tm[:3, :3] = np.diag([1.0, -1.0, -1.0])
+            Tm[:3, 3] = acts[t, i] + np.array([0, 0, 0.174])
+            r = oracle_mod.ur5e_ik_closest(Tm, q[i])
+            q1 = r[0] if isinstance(r, tuple) else r
+            if q1 is not None:
+                d = np.abs(np.asarray(q1) - q[i]) + 0.05 * np.abs(v[i])
+                max_t2 = max(max_t2, float((d * d).sum()))
+        qold = q.copy()
+        o = b.step(acts[t])
+        q = o["obs"][:, 3:9].copy()
+        fresh = o["step_type"] == 0
+        qold[fresh] = q[fresh]
+    assert min_clr > 0.14, min_clr     # CLEAR_MARGIN 0.10 with room (the wrist_3 capsule, 0.154 m at the lowest target)
+    assert max_t2 < 1.6, max_t2        # TRAVEL2_MAX 2.5 with room
