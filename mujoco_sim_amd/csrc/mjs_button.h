@@ -848,8 +848,11 @@ MJS_DEV void physics_forces(const double* q, const double* v, const double* ctrl
       for (int i = 0; i < NJ; i++) { rhs[i] = mine ? out.qs[i] : rhs[i]; w.warm[i] = mine ? out.qacc[i] : w.warm[i]; }
       touch = mine ? out.touch : touch;
     };
-    if (__any(want_lean2)) run_lean(std::integral_constant<int, 2>{}, want_lean2);
-    if (__any(want_lean4)) run_lean(std::integral_constant<int, 4>{}, want_lean4);
+    // (the 4-slot instance does a lane with <= 2 contacts bit for bit like the 2-slot one — unused slots are skipped, not
+    // added as zeros — so it serves both kinds when the wavefront has both: one call instead of two, and still nothing in a
+    // lane's result depends on its neighbours; test_contact_tasks_shard_invariance)
+    if (__any(want_lean4)) run_lean(std::integral_constant<int, 4>{}, want_lean2 || want_lean4);
+    else if (__any(want_lean2)) run_lean(std::integral_constant<int, 2>{}, want_lean2);
     if (__any(want_general)) {
       rr::GenStageIn gi;
 #pragma unroll
