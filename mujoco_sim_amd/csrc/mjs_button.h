@@ -1300,7 +1300,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
               (slot_overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
   uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0) | (solo ? FLAG_WARM_VALID : 0));
-  rr::store_state(p, i, st);
+  rr::store_state_stepped(p, i, st);  // q, v, time: a step only reads the switch rows
   rr::store_cs(p, i, S_CS, cs, sn);
   if (solo) rr::store_warm(p, i, S_WARM, warm_out);
   p.state[(size_t)S_GRIP * p.N + i] = grip.th;

@@ -1078,12 +1078,18 @@ MJS_DEV State load_state(const KernelParams& p, int i) {
   for (int k = 0; k < 3; k++) st.target[k] = s[(S_TARGET + k) * N];
   return st;
 }
-MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
+// the rows a control step changes: q, v, time (a step only reads the target / switch rows: resets write those)
+MJS_DEV void store_state_stepped(const KernelParams& p, int i, const State& st) {
   double* s = p.state + i;
   const size_t N = p.N;
 #pragma unroll
   for (int j = 0; j < NJ; j++) { s[(S_Q + j) * N] = st.q[j]; s[(S_V + j) * N] = st.v[j]; }
   s[S_TIME * N] = st.time;
+}
+MJS_DEV void store_state(const KernelParams& p, int i, const State& st) {
+  store_state_stepped(p, i, st);
+  double* s = p.state + i;
+  const size_t N = p.N;
 #pragma unroll
   for (int k = 0; k < 3; k++) s[(S_TARGET + k) * N] = st.target[k];
 }
@@ -1222,7 +1228,7 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
     // The out-of-line functions below are CALLED BY THE WHOLE WAVEFRONT (wave-uniform branches only around a call, per-lane
     // selects of its results; a lane without rows discards them, so what a lane computes never depends on its neighbours):
     // hipcc places live-range split copies ahead of the exec-mask restore of a divergent join next to a call
-    // (mujoco_sim_amd/_isa_lint.py, DESIGN.md D-9), which lost the sub-step counter of the lanes that skipped the `if`.
+    // (mujoco_sim_amd/_isa_lint.py, DESIGN.md section 4), which lost the sub-step counter of the lanes that skipped the `if`.
     // 1. the warm start a row-free substep left behind as (pM, pqs), needed now: qacc_warmstart = pM^-1 pqs
     const bool eval_lazy = rows && lazy;
     if (__any(eval_lazy)) {
@@ -1298,6 +1304,7 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, Ws ws) {
 // termination, the a-posteriori checks, fault word, flags, state and output stores, same-step auto-reset.
 struct StepEnd {
   bool solo, bad, rows_active, overflow;
+  bool peer_stored_state = false;  // the other dynamics wavefront (same numbers) has written the q / v / time / cos / sin rows meanwhile
 };
 MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, const double* cs, const double* sn, uint8_t flags, const double* warm_out, StepEnd e,
                          double* obs_tile) {
@@ -1333,8 +1340,10 @@ MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, cons
   uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0) | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0) | (e.solo ? FLAG_WARM_VALID : 0));
   // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
   // has to stay live across that call
-  store_state(p, i, st);
-  store_cs(p, i, S_CS, cs, sn);
+  if (!e.peer_stored_state) {
+    store_state_stepped(p, i, st);
+    store_cs(p, i, S_CS, cs, sn);
+  }
   if (e.solo) store_warm(p, i, S_WARM, warm_out);
   p.flags[i] = newflags;
   // observations [N, 12] row-major: a lane-per-env store is a 96-B-strided scatter (2.5x write
@@ -1534,8 +1543,18 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
       if (role == 0 && s == 10) MJS_STAMP(p, 12);
     }
   }
-  if (role != 0) return;
-  finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false}, obs_tile);
+  // epilogue on both wavefronts (they hold the same numbers): role 1 writes the 25 state rows the step changed while role 0
+  // works out observables, reward, flags and outputs. Not with the same-step auto-reset: role 0 may then rewrite the state rows
+  // of a finished env in this launch.
+  const bool split_stores = p.autoreset != MJS_AUTORESET_SAME_STEP;
+  if (role != 0) {
+    if (split_stores) {
+      store_state_stepped(p, i, st);
+      store_cs(p, i, S_CS, cs, sn);
+    }
+    return;
+  }
+  finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false, split_stores}, obs_tile);
 }
 
 
@@ -1746,10 +1765,18 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
         st.time += MJS_RR_PHYSICS_DT;
         if (role == 0 && s == 10) MJS_STAMP(p, 12);
       }
-      if (role == 1) return;  // (the floor-contact count it used to take here is a by-product of role 0's clearance bound now)
+      // epilogue on both wavefronts (same numbers): role 1 writes the 25 state rows the step changed while role 0 works out
+      // observables, reward, flags and outputs (not with the same-step auto-reset: role 0 may then rewrite those rows)
+      if (role == 1) {
+        if (p.autoreset != MJS_AUTORESET_SAME_STEP) {
+          store_state_stepped(p, i, st);
+          store_cs(p, i, S_CS, cs, sn);
+        }
+        return;
+      }
+      finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false, p.autoreset != MJS_AUTORESET_SAME_STEP}, obs_tile);
     }
   }
-  finish_step(p, i, lane, st, cs, sn, flags, nullptr, StepEnd{false, bad, false, false}, obs_tile);
 }
 
 
