@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Large-batch parity soak (development tool, run on the GPU box): the GPU tests' comparisons at batch sizes and horizons the
+test suite does not afford, on the inputs that reach the rarely taken paths. Every env against the oracle, every step; an env
+leaves a comparison when the oracle reports a bad state, the device reports bit 1 / 8 / 16, or (Robot-Reach) a command's closest
+IK solution is an exact tie. Prints one summary line per scenario; exit code 1 if any scenario saw a divergence."""
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+import mujoco_sim_amd as m  # noqa: E402
+import oracle  # noqa: E402
+from test_gpu_parity import _gpu_result, _top_down_ik_is_a_tie  # noqa: E402
+
+oracle.build()
+NT = 16
+bad_total = 0
+
+
+def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_kw=None, atol=1e-7):
+    global bad_total
+    t0 = time.time()
+    venv = m.HipVectorEnv(task, N, seed=seed, **(venv_kw or {}))
+    ob = oracle.OracleBatch(tid, N, seed, nthreads=NT, **(ob_kw or {}))
+    venv.reset()
+    o = ob.reset()
+    g = _gpu_result(venv)
+    assert np.abs(g["obs"] - o["obs"]).max() < 1e-9, "reset"
+    alive = np.ones(N, bool)
+    n_div = n_rows = n_tie = n_guard = n_last = 0
+    worst = 0.0
+    for t in range(T):
+        a = actions(t)
+        if tie_check:
+            q_now = o["obs"][:, 3:9]
+            for i in np.nonzero(alive)[0]:
+                if _top_down_ik_is_a_tie(oracle, a[i], q_now[i]):
+                    alive[i] = False
+                    n_tie += 1
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        n_guard += int(((g["fault"] & (8 | 16)) > 0)[alive].sum())
+        alive &= ~o["fault"] & ~(g["fault"] & (1 | 8 | 16)).astype(bool) & (np.abs(o["obs"]).max(axis=1) < 50)
+        d = np.abs(g["obs"] - o["obs"]).max(axis=1)
+        badenv = np.nonzero(alive & ~(d <= atol))[0]
+        if badenv.size:
+            print(f"  {name} step {t}: {badenv.size} env(s) beyond {atol}: {badenv[:8]} max {d[badenv].max():.3g} fault {g['fault'][badenv[:8]]} ncon {g['ncon'][badenv[:8]]} / {o['ncon'][badenv[:8]]}")
+        worst = max(worst, float(d[alive & (d <= atol)].max(initial=0.0)))
+        n_div += badenv.size
+        alive[badenv] = False
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            mism = np.nonzero(alive & (np.asarray(g[k]).astype(np.int64) != np.asarray(o[k]).astype(np.int64)))[0]
+            if mism.size:
+                print(f"  {name} step {t}: {k} differs for env(s) {mism[:8]}")
+                n_div += mism.size
+                alive[mism] = False
+        n_rows += int(((g["fault"] & 4) > 0)[alive].sum())
+        n_last += int((np.asarray(g["step_type"]) == 2).sum())
+    venv.close()
+    bad_total += n_div
+    print(f"{name}: {N} envs x {T} steps, alive {alive.mean():.4f}, divergences {n_div}, rows env-steps {n_rows}, guard reports {n_guard}, ik ties {n_tie}, "
+          f"episode ends {n_last}, worst accepted |d obs| {worst:.2e}, {time.time() - t0:.0f} s", flush=True)
+
+
+rs = np.random.RandomState(123)
+which = sys.argv[1:] or ["reach_box", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "pointmass"]  # (Planar-Push: its own tests carry the conditioning mask that contact-rich free bodies need)
+if "reach_box" in which:
+    run("Robot-Reach, workspace actions, 3 episodes", "robot_reach", oracle.TASK_ROBOT_REACH, 4096, 250, lambda t: rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (4096, 3)), 11)
+if "reach_wild" in which:
+    def wild(t, N=2048):
+        a = rs.uniform([-0.6, -0.9, -0.15], [0.6, 0.1, 0.5], (N, 3))
+        a[: N // 4] = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N // 4, 3))
+        return a
+    run("Robot-Reach, actions far outside the box", "robot_reach", oracle.TASK_ROBOT_REACH, 2048, 120, wild, 12, tie_check=True)
+if "button_eef" in which:
+    run("Button-Push, EEF actions, same-step reset", "robot_push_button", oracle.TASK_BUTTON_PUSH, 2048, 220,
+        lambda t: rs.uniform([-0.2, -0.6, 0.02, 0.0], [0.2, -0.3, 0.3, 0.085], (2048, 4)), 13,
+        venv_kw=dict(autoreset="same_step", action_type="absolute_eef_action"), ob_kw=dict(autoreset=1, action_type=1))
+if "button_joint_full" in which:
+    run("Button-Push, full-range joint actions", "robot_push_button", oracle.TASK_BUTTON_PUSH, 2048, 110,
+        lambda t: np.concatenate([rs.uniform(-3.14, 3.14, (2048, 6)), rs.uniform(0, 0.085, (2048, 1))], axis=1), 14)
+if "button_joint_nominal" in which:
+    nominal = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04])
+    run("Button-Push, joint actions around the nominal pose", "robot_push_button", oracle.TASK_BUTTON_PUSH, 2048, 220,
+        lambda t: nominal + rs.uniform(-1, 1, (2048, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04]), 15)
+if "pointmass" in which:
+    run("Pointmass-Reach, 4 episodes", "point_mass_reach", oracle.TASK_POINTMASS, 4096, 420, lambda t: rs.uniform(-0.1, 0.1, (4096, 2)).astype(np.float32).astype(np.float64), 16, atol=1e-9)
+print("soak:", "OK" if bad_total == 0 else f"{bad_total} divergence(s)")
+sys.exit(1 if bad_total else 0)
