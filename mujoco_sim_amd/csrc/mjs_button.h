@@ -1121,6 +1121,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, r.ncon);
     return;
   }
+  MJS_STAMP(p, 0);
   rr::State st = rr::load_state(p, i);
   Grip grip{p.state[(size_t)S_GRIP * p.N + i], p.state[(size_t)(S_GRIP + 1) * p.N + i]};
   const V3 sw = v3(st.target[0], st.target[1], st.target[2]);
@@ -1170,6 +1171,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   }
   const bool links_solo = __any(link_unsafe);
   const bool guarded = links_solo || __any(rows_possible(st.q, st.v, c, sw, grip, grip_ctrl, MJS_RR_CONTROL_DT));  // some env may get rows during this control step
+  MJS_STAMP(p, 1);
   int solo_from = (ROLES == 1 || links_solo) ? 0 : MJS_RR_NSUB;                      // first substep of the robust path
   if constexpr (ROLES == 2) {
 #pragma unroll 1
@@ -1272,12 +1274,14 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   }
   const bool solo = solo_from < MJS_RR_NSUB;
   if (role != 0) return;
+  MJS_STAMP(p, 2);
   // after_step (robot_push_button.py:159-165): rand() is drawn only for an active, released switch
   if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = disturb(p.rng, i, flags);
 #pragma unroll
   for (int j = 0; j < NJ; j++) bad = bad || bad_value(st.q[j]) || bad_value(st.v[j]);
   rr::fk_cs(cs, sn, c);
   make_obs(st, c, flags, obs);
+  MJS_STAMP(p, 3);
   // goal: switch active and TCP within 0.05 of the end position (robot_push_button.py:205-219)
   double dx = obs[6] - MJS_BP_ROBOT_END_POS[0], dy = obs[7] - MJS_BP_ROBOT_END_POS[1], dz = obs[8] - MJS_BP_ROBOT_END_POS[2];
   bool success = (flags & FLAG_SWITCH_ACTIVE) && sqrt(dx * dx + dy * dy + dz * dz) < MJS_BP_GOAL_THRESHOLD;
@@ -1295,6 +1299,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
     ncon_proxy = con.n + (detect_wrist_box(c, sw).hit ? 1 : 0);
     ncon += ncon_proxy;
   }
+  MJS_STAMP(p, 4);
   const bool violated = !solo && (ncon_proxy > 0 || arm_touches_floor || rr::joint_outside_range(st.q));  // a-posteriori check of the row-free path (solo: every lane detects)
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
               (slot_overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
@@ -1307,6 +1312,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   p.state[(size_t)(S_GRIP + 1) * p.N + i] = grip.vel;
   p.flags[i] = newflags;
   write_outputs<OBS_DIM>(p, i, obs, reward, discount, terminate ? MJS_STEP_LAST : MJS_STEP_MID, terminated, truncated, success, fault, ncon);
+  MJS_STAMP(p, 5);
   if (terminate && p.autoreset == MJS_AUTORESET_SAME_STEP) {
     if (p.out.terminal_obs) {
 #pragma unroll
