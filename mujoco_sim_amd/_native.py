@@ -30,6 +30,7 @@ STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART, FAULT_UNSUPPORTED_CONTACT, FAULT_FASTPATH_VIOLATED = 1, 2, 4, 8, 16
 BLOCKS_MESH, BLOCKS_BOX = 0, 1
+VARIANT_DEFAULT, VARIANT_SINGLE_WAVE, VARIANT_TWO_ROLES, VARIANT_RESET_GROUPS = 0, 1, 2, 3
 UR_STATE = 34
 UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
 UR_EEF_NONE, UR_EEF_GRIPPER = 0, 1

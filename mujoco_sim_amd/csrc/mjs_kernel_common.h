@@ -13,7 +13,10 @@
 // (4, 8: Button-Push switch bits.) FLAG_WARM_VALID: the state's qacc_warmstart rows hold the solver acceleration of the last
 // Physics.step() (written by the robust path and by resets; a row-free step leaves them stale and clears the bit).
 // FLAG_CLEAR (Robot-Reach): every arm collision geom was >= rr::CLEAR_MARGIN above the floor in the step's final configuration.
-enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2, FLAG_WARM_VALID = 16, FLAG_CLEAR = 32 };
+// FLAG_FRESH / FLAG_EPOCH (Robot-Reach's default step kernel): the env was reset by a reset workgroup of the step launch whose
+// parity FLAG_EPOCH holds; a stepping wavefront of THAT launch which reads the byte after the reset leaves the lane alone, the
+// next launch (other parity) steps it and clears both bits (rr::kernel3).
+enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2, FLAG_WARM_VALID = 16, FLAG_CLEAR = 32, FLAG_FRESH = 64, FLAG_EPOCH = 128 };
 
 struct KernelParams {
   int N;
@@ -25,6 +28,8 @@ struct KernelParams {
   int n_objects;          // Planar-Push
   int max_episode_steps;  // Planar-Push
   int block_shape;        // Planar-Push: MJS_BLOCKS_MESH / MJS_BLOCKS_BOX
+  int epoch;              // parity of this step launch (0 / 1, toggled per launch): see FLAG_EPOCH
+  int reset_groups;       // Robot-Reach kernel3: 1 = the grid's second half are reset workgroups, 0 = a workgroup resets its own envs
   double time_limit;
   double* state;    // [state_dim][N] struct-of-arrays float64
   uint8_t* flags;   // [N]

@@ -1135,7 +1135,7 @@ __device__ __noinline__ State episode_init(DevRng rng, int i) {
 }
 // everything a reset publishes: state, zeroed warm start, flags (fresh mjData: qacc_warmstart = 0 is the valid warm start of
 // the first step), FIRST outputs. Returns nothing live.
-MJS_DEV void publish_reset(const KernelParams& p, int i, const State& st, bool write_first) {
+MJS_DEV void publish_reset(const KernelParams& p, int i, const State& st, bool write_first, uint8_t extra_flags = 0) {
   Chain c;
   double obs[OBS_DIM];
   store_state(p, i, st);
@@ -1148,7 +1148,7 @@ MJS_DEV void publish_reset(const KernelParams& p, int i, const State& st, bool w
     fk_cs(cs, sn, c);
   }
   const double minclr = min_floor_clearance(c);
-  p.flags[i] = (uint8_t)(FLAG_WARM_VALID | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0));
+  p.flags[i] = (uint8_t)(FLAG_WARM_VALID | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0) | extra_flags);  // ONE store: a concurrent reader sees the old or the new byte
   V3 tcp = tcp_position(c);
   obs[0] = tcp.x; obs[1] = tcp.y; obs[2] = tcp.z;
 #pragma unroll
@@ -1588,6 +1588,11 @@ __device__ __attribute__((always_inline)) inline IkOut ik_for_wave_body(double a
   }
   return o;
 }
+// next-step auto-reset of one lane, out of line: the step kernel's own code stays what its fast path needs
+__device__ __noinline__ void reset_lane_next_step(KernelParams p, int i, uint8_t extra_flags) {
+  State fresh = episode_init(p.rng, i);
+  publish_reset(p, i, fresh, true, extra_flags);
+}
 // out-of-line copy for the rare solo path (the IK wavefront inlines its own)
 __device__ __noinline__ IkOut ik_out_of_line(double ax, double ay, double az, double g0, double g1, double g2, double g3, double g4, double g5) {
   return ik_for_wave_body<false>(ax, ay, az, g0, g1, g2, g3, g4, g5);
@@ -1597,20 +1602,33 @@ template <int DUMMY>
 __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int i = blockIdx.x * 64 + lane;
+  // The grid is twice the number of 64-env groups: workgroup g < G steps group g, workgroup G + g resets the envs of group g
+  // whose episode ended (next-step auto-reset), on another CU and at the same time. An env is handled by exactly one of the
+  // two: a stepping lane leaves when its flag byte says "reset pending" (read before the reset workgroup got there) or "reset
+  // in THIS launch" (read after: FLAG_FRESH with this launch's parity). With the reset inside the stepping workgroup, episodes
+  // that end at different times cost every launch the reset's time and its instruction-cache footprint next to the substep
+  // loop (tools/desync_probe.py).
+  const int groups = (p.N + 63) >> 6;
+  const bool resetter = (int)blockIdx.x >= groups;  // only in launches with p.reset_groups
+  const int i = (resetter ? (int)blockIdx.x - groups : (int)blockIdx.x) * 64 + lane;
   __shared__ double xch[12][64];    // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
   __shared__ double ikx[7][64];     // q1[6], found
   __shared__ double obs_tile[OBS_DIM * 64];
   if (i >= p.N) return;
-  // Every wavefront takes the same branch below from its OWN read of flags[i]; wave 0 rewrites flags[i] (reset path: at once;
-  // step path: in the epilogue). The barrier orders every wavefront's read before any such write (a wavefront
-  // scheduled late could otherwise see the flag already cleared and step the freshly reset lane).
+  // Every wavefront takes the same branch below from its OWN read of flags[i]; wave 0 rewrites flags[i] in the epilogue. The
+  // barrier orders every wavefront's read before that write.
   uint8_t flags = p.flags[i];
+  const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
+  if (resetter) {
+    if (wave == 0 && pending) reset_lane_next_step(p, i, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
+    return;
+  }
   __syncthreads();
-  if ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP) {
-    if (wave != 0) return;
-    State fresh = episode_init(p.rng, i);
-    publish_reset(p, i, fresh, true);
+  if (p.reset_groups) {
+    if (pending || ((flags & FLAG_FRESH) && ((flags & FLAG_EPOCH) != 0) == (p.epoch != 0))) return;
+    flags = (uint8_t)(flags & ~(FLAG_FRESH | FLAG_EPOCH));
+  } else if (pending) {  // synchronous episodes (the default): the workgroup resets its own envs
+    if (wave == 0) reset_lane_next_step(p, i, 0);
     return;
   }
   MJS_STAMP(p, 0);

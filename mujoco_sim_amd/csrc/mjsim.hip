@@ -33,6 +33,7 @@ struct mjs_handle {
   int bg_H = 0, bg_W = 0;
   float* cams;                 // [N][12] wrist-camera poses (Button-Push)
   double* ws = nullptr;        // [rr::WS_ROWS][N] contact workspace of the general constraint stage (Robot-Reach, Button-Push)
+  int epoch = 0;               // parity of the next step launch (FLAG_EPOCH)
   std::string err;
 };
 
@@ -163,6 +164,8 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.n_objects = h->cfg.n_objects;
   p.max_episode_steps = h->cfg.max_episode_steps;
   p.block_shape = h->cfg.block_shape;
+  p.epoch = h->epoch;
+  p.reset_groups = h->cfg.task == MJS_TASK_ROBOT_REACH && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -196,6 +199,14 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   // then has twice the throughput (profiles/r02_j_batch_size_scaling.txt: 65536 envs 435 vs 822 M env-steps/s).
   else if (h->cfg.kernel_variant == MJS_VARIANT_TWO_ROLES || (h->cfg.kernel_variant == MJS_VARIANT_DEFAULT && p.N > 16384))
     rr::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
+  else if (p.reset_groups) {
+    // MJS_VARIANT_RESET_GROUPS, for episodes that end at different times: the second half of the grid are reset workgroups
+    // (one per 64 envs, on other CUs: an env whose episode ended is reset there while the first half steps the others: 54 -> 38 us
+    // per launch with 1 % of the envs ending in every step); the launch parity tells a freshly reset env from one that waits.
+    // Not the default for synchronous episodes: the 64 extra workgroups cost 0.9 us per launch at 4096 envs.
+    rr::kernel3<0><<<dim3(2 * grid_for(p.N).x), 3 * BLOCK, 0, s>>>(p);
+    h->epoch ^= 1;
+  }
   else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;

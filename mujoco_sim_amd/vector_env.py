@@ -101,7 +101,7 @@ class HipVectorEnv:
 
     def __init__(self, task: str, num_envs: int, device: str | int | torch.device = "cuda:0", seed: int | None = None,
                  autoreset: str = "next_step", reward_type: str | None = None, time_limit: float | None = None,
-                 terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int = 0,
+                 terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int | None = None,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
                  button_disturbances: bool = False, use_wrist_camera: bool = True, n_objects: int | None = None,
                  max_episode_steps: int | None = None, block_shape: str = "mesh"):
@@ -131,6 +131,9 @@ class HipVectorEnv:
         self.autoreset = autoreset
         self.env_index_offset = int(env_index_offset)
         self._lib = nat.lib()
+        if kernel_variant is None:
+            # Robot-Reach episodes that end at different times (terminate_on_success): resets on workgroups of their own (mjsim.h)
+            kernel_variant = nat.VARIANT_RESET_GROUPS if task == "robot_reach" and terminate_on_success and autoreset == "next_step" and self.num_envs <= 16384 else 0
         cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self._dev_index,
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),

@@ -573,6 +573,41 @@ def test_reach_links_on_the_floor_match_oracle(oracle_mod, variant):
     assert n_rows > 30 and n_arm > 30, (n_rows, n_arm)
 
 
+@pytest.mark.parametrize("kernel_variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_robot_reach_episodes_ending_at_different_times(oracle_mod, autoreset, kernel_variant):
+    """With terminate_on_success (D-2's opt-in) an env's episode ends when ITS gripper reaches ITS target: resets fall on
+    different control steps in different envs, so a workgroup's wavefronts hold lanes that reset next to lanes that step (the
+    benchmark's and the other tests' Robot-Reach episodes all end together at the time limit). Policy: three quarters of the
+    envs servo to their target (obs 9:12) with a little noise and succeed after a few steps, the rest act at random. Every
+    output of every env against the oracle, 150 steps, both auto-reset modes, every kernel shape: 0 = three wavefronts, a
+    workgroup resets its own envs; 1 = one wavefront; 2 = two role wavefronts; 3 = three wavefronts with the resets on
+    workgroups of their own (what the host picks for this configuration: launch-parity flag protocol of rr::kernel3)."""
+    import mujoco_sim_amd as m
+
+    N, T = 256, 150
+    venv = m.HipVectorEnv("robot_reach", N, seed=77, autoreset=autoreset, terminate_on_success=True, kernel_variant=kernel_variant)
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_ROBOT_REACH, N, 77, autoreset={"next_step": 0, "same_step": 1}[autoreset], terminate_on_success=True, nthreads=8)
+    venv.reset()
+    o = ob.reset()
+    rs = np.random.RandomState(9)
+    n_last, steps_with_mixed_groups = 0, 0
+    for t in range(T):
+        a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N, 3))
+        seek = np.arange(N) % 4 != 0
+        a[seek] = o["obs"][seek, 9:12] + rs.normal(0, 0.002, (int(seek.sum()), 3))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        _compare(t, g, o)
+        last = np.asarray(o["step_type"]) == 2
+        n_last += int(last.sum())
+        per_group = last.reshape(-1, 64).sum(axis=1)
+        steps_with_mixed_groups += int(((per_group > 0) & (per_group < 64)).any())
+    assert n_last > 5 * N and steps_with_mixed_groups > 100, (n_last, steps_with_mixed_groups)
+    venv.close()
+
+
 def _top_down_ik_is_a_tie(oracle_mod, tcp, guess, tcp_z=0.174, eps=1e-9):
     """inverse_kinematics_closest picks, per solution and joint, the 2*pi-shifted angle when it is STRICTLY closer to the guess,
     then the solution with the smallest distance. Where two candidates are equally far to the last bit (the wrist_2 joint rests
