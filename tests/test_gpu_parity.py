@@ -741,6 +741,38 @@ def test_button_push_demonstration_policy(oracle_mod, action_type, disturb):
     assert (n_disturbed > 0) == disturb, n_disturbed
 
 
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_button_push_episodes_ending_at_different_times(oracle_mod, autoreset):
+    """Button-Push ends an episode on success (robot_push_button.py:205-219): under the scripted policy the envs succeed after
+    different numbers of steps, so resets, first steps of new episodes (finger tips near the switch: robust path) and ordinary
+    steps share workgroups — the other Button-Push tests end all episodes together at the time limit or disable the auto-reset.
+    160 steps of the policy (computed from the device observations, the same actions on both sides), every env, both modes."""
+    import mujoco_sim_amd as m
+
+    N, T = 128, 160
+    task = m.RobotPushButtonTask(observation_type="state_observations", action_type="absolute_eef_action")
+    venv = m.HipVectorEnv("robot_push_button", N, seed=91, autoreset=autoreset, action_type="absolute_eef_action")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 91, autoreset={"next_step": 0, "same_step": 1}[autoreset], nthreads=8, action_type=1)
+    venv.reset()
+    ob.reset()
+    n_last, steps_with_mixed_groups = 0, 0
+    for t in range(T):
+        a = task.demonstration_actions(venv).cpu().numpy()
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        np.testing.assert_allclose(g["obs"], o["obs"], rtol=0, atol=1e-8, err_msg=f"step {t}")
+        np.testing.assert_allclose(g["reward"], o["reward"], rtol=0, atol=1e-8, err_msg=f"step {t}")
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k]).astype(int), np.asarray(o[k]).astype(int)), (k, t)
+        last = np.asarray(o["step_type"]) == 2
+        n_last += int(last.sum())
+        per_group = last.reshape(-1, 64).sum(axis=1)
+        steps_with_mixed_groups += int(((per_group > 0) & (per_group < 64)).any())
+    assert n_last > N and steps_with_mixed_groups > 40, (n_last, steps_with_mixed_groups)
+    venv.close()
+
+
 def test_button_push_gripper_follows_the_reference_map(oracle_mod):
     """Reduced 2F-85: the commanded finger opening goes through Robotiq2f85.move's map (gripper.py:77-84) to the
     fingers_actuator ctrl; the driver angle (state rows 16, 17) follows the actuator and must equal the oracle's at every step;
