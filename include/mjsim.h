@@ -51,7 +51,7 @@ enum { MJS_AUTORESET_NEXT_STEP = 0, MJS_AUTORESET_SAME_STEP = 1, MJS_AUTORESET_D
  * the single-wavefront step kernels of Robot-Reach / Button-Push (default: two role-specialised wavefronts) and the
  * 8x8-tile camera kernel for every image (default: the rectangle walk for images up to 64x64) */
 enum { MJS_VARIANT_DEFAULT = 0, MJS_VARIANT_SINGLE_WAVE = 1, MJS_VARIANT_TWO_ROLES = 2 /* Robot-Reach: round 1's two-wavefront kernel */,
-       MJS_VARIANT_RESET_GROUPS = 3 /* Robot-Reach: the default (three-wavefront) kernel with the next-step auto-resets on workgroups
+       MJS_VARIANT_RESET_GROUPS = 3 /* Robot-Reach (Button-Push accepts it too): the default kernel with the next-step auto-resets on workgroups
                                        of their own (other CUs, same launch). For episodes that END AT DIFFERENT TIMES
                                        (terminate_on_success): 38 instead of 54 us per launch at 4096 envs with 1 % of the envs ending
                                        in every step; with synchronous episodes it costs 0.9 us per launch. Bitwise the default's

@@ -1085,6 +1085,28 @@ __device__ __noinline__ SoloOut solo_control_step(SoloIn in, rr::Ws ws) {
   return o;
 }
 
+// reset of one lane (mjs_reset, or the next-step auto-reset of an env whose episode ended), out of line: state rows, flag byte
+// (ONE store: a concurrent reader sees the old or the new byte), the FIRST time step's outputs
+__device__ __noinline__ void reset_lane(KernelParams p, int i, uint8_t flags, rr::Ws ws, uint8_t extra_flags) {
+  double obs[OBS_DIM];
+  rr::Chain c;
+  ResetOut r = episode_init(p.rng, i, flags, ws);
+  rr::store_state(p, i, r.st);
+  p.state[(size_t)S_GRIP * p.N + i] = 0.0;  // mj_resetData: gripper open, at rest
+  p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
+  rr::store_warm(p, i, S_WARM, nullptr);
+  p.flags[i] = (uint8_t)(r.flags | extra_flags);
+  {
+    double cs[NJ], sn[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) sincos(r.st.q[j], &sn[j], &cs[j]);
+    rr::store_cs(p, i, S_CS, cs, sn);
+    rr::fk_cs(cs, sn, c);
+  }
+  make_obs(r.st, c, r.flags, obs);
+  write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, r.ncon);
+}
+
 // ROLES == 2 (default for stepping): the role-specialised pair of wavefronts of rr::kernel (role 0: M(q), U D U^T,
 // U^-1; role 1: servo set-point, actuators, bias forces; two LDS exchanges per substep) with this scene's
 // generated dynamics, for workgroups in which no env can get constraint rows during the control step; the others
@@ -1093,32 +1115,30 @@ template <bool IS_RESET, int ROLES>
 __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const int lane = threadIdx.x & 63;
   const int role = (ROLES == 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-  const int i = blockIdx.x * 64 + lane;
+  // MJS_VARIANT_RESET_GROUPS (p.reset_groups; rr::kernel3 explains the protocol): the grid's second half are reset workgroups,
+  // workgroup G + g resets the envs of group g whose episode ended while workgroup g steps the others on another CU
+  const int groups = (p.N + 63) >> 6;
+  const bool resetter = !IS_RESET && ROLES == 2 && (int)blockIdx.x >= groups;
+  const int i = (resetter ? (int)blockIdx.x - groups : (int)blockIdx.x) * 64 + lane;
   __shared__ double xch[ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
   if (i >= p.N) return;
   uint8_t flags = p.flags[i];
-  if (ROLES == 2) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it (see rr::kernel3)
+  const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
   const rr::Ws ws{p.ws, p.N, i};
+  if (resetter) {
+    if (role == 0 && pending) reset_lane(p, i, flags, ws, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
+    return;
+  }
+  if (ROLES == 2) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it (see rr::kernel3)
   double obs[OBS_DIM];
   rr::Chain c;
-  if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+  if (!IS_RESET && ROLES == 2 && p.reset_groups) {
+    if (pending || ((flags & FLAG_FRESH) && ((flags & FLAG_EPOCH) != 0) == (p.epoch != 0))) return;
+    flags = (uint8_t)(flags & ~(FLAG_FRESH | FLAG_EPOCH));
+  } else if (IS_RESET || pending) {
     if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
-    ResetOut r = episode_init(p.rng, i, flags, ws);
-    rr::store_state(p, i, r.st);
-    p.state[(size_t)S_GRIP * p.N + i] = 0.0;  // mj_resetData: gripper open, at rest
-    p.state[(size_t)(S_GRIP + 1) * p.N + i] = 0.0;
-    rr::store_warm(p, i, S_WARM, nullptr);
-    p.flags[i] = r.flags;
-    {
-      double cs[NJ], sn[NJ];
-#pragma unroll
-      for (int j = 0; j < NJ; j++) sincos(r.st.q[j], &sn[j], &cs[j]);
-      rr::store_cs(p, i, S_CS, cs, sn);
-      rr::fk_cs(cs, sn, c);
-    }
-    make_obs(r.st, c, r.flags, obs);
-    write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, 0, r.ncon);
+    reset_lane(p, i, flags, ws, 0);
     return;
   }
   MJS_STAMP(p, 0);

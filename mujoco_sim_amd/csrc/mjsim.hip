@@ -165,7 +165,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.max_episode_steps = h->cfg.max_episode_steps;
   p.block_shape = h->cfg.block_shape;
   p.epoch = h->epoch;
-  p.reset_groups = h->cfg.task == MJS_TASK_ROBOT_REACH && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
+  p.reset_groups = (h->cfg.task == MJS_TASK_ROBOT_REACH || h->cfg.task == MJS_TASK_BUTTON_PUSH) && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -190,6 +190,10 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+    else if (p.reset_groups) {  // MJS_VARIANT_RESET_GROUPS: the second half of the grid resets the envs whose episode ended
+      bp::kernel<false, 2><<<dim3(2 * grid_for(p.N).x), 2 * BLOCK, 0, s>>>(p);
+      h->epoch ^= 1;
+    }
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
   }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);

@@ -15,7 +15,7 @@ from bench import make_actions  # noqa: E402
 N = 4096
 TIME_ROW = 12  # S_TIME of the three robot scenes
 for task in sys.argv[1:] or ["robot_reach", "robot_push_button", "robot_planar_push"]:
-    for desync, variant in ((False, 0), (True, 0)) + (((False, 3), (True, 3)) if task == "robot_reach" else ()):
+    for desync, variant in ((False, 0), (True, 0)) + (((False, 3), (True, 3)) if task in ("robot_reach", "robot_push_button") else ()):
         kw = {"max_episode_steps": 100} if task == "robot_planar_push" else {}
         venv = m.HipVectorEnv(task, N, seed=0, kernel_variant=variant, **kw)
         acts = make_actions(task, 64, N, "cuda", 1)
