@@ -741,17 +741,18 @@ def test_button_push_demonstration_policy(oracle_mod, action_type, disturb):
     assert (n_disturbed > 0) == disturb, n_disturbed
 
 
-@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
-def test_button_push_episodes_ending_at_different_times(oracle_mod, autoreset):
+@pytest.mark.parametrize("autoreset,kernel_variant", [("next_step", 0), ("next_step", 3), ("next_step", 1), ("same_step", 0)])
+def test_button_push_episodes_ending_at_different_times(oracle_mod, autoreset, kernel_variant):
     """Button-Push ends an episode on success (robot_push_button.py:205-219): under the scripted policy the envs succeed after
     different numbers of steps, so resets, first steps of new episodes (finger tips near the switch: robust path) and ordinary
     steps share workgroups — the other Button-Push tests end all episodes together at the time limit or disable the auto-reset.
-    160 steps of the policy (computed from the device observations, the same actions on both sides), every env, both modes."""
+    160 steps of the policy (computed from the device observations, the same actions on both sides), every env; kernel
+    shapes: 0 = the workgroup resets its own envs, 3 = reset workgroups (MJS_VARIANT_RESET_GROUPS), 1 = single wavefront."""
     import mujoco_sim_amd as m
 
     N, T = 128, 160
     task = m.RobotPushButtonTask(observation_type="state_observations", action_type="absolute_eef_action")
-    venv = m.HipVectorEnv("robot_push_button", N, seed=91, autoreset=autoreset, action_type="absolute_eef_action")
+    venv = m.HipVectorEnv("robot_push_button", N, seed=91, autoreset=autoreset, action_type="absolute_eef_action", kernel_variant=kernel_variant)
     ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 91, autoreset={"next_step": 0, "same_step": 1}[autoreset], nthreads=8, action_type=1)
     venv.reset()
     ob.reset()
