@@ -240,6 +240,15 @@ class OracleBatch:
         lib().om_batch_reset(self._h, self._out.ctypes.data)
         return self._result()
 
+    def reset_envs(self, indices):
+        """reset some envs now (what mjs_reset does with a mask); the other envs' last results stay in the returned dict"""
+        L = lib()
+        L.om_env_reset.argtypes = [C.c_void_p, C.c_void_p]
+        L.om_env_reset.restype = None
+        for i in indices:
+            L.om_env_reset(L.om_batch_env(self._h, int(i)), self._out[int(i):int(i) + 1].ctypes.data)
+        return self._result()
+
     def step(self, actions):
         a = np.ascontiguousarray(actions, dtype=np.float64).reshape(self.n, self.action_dim)
         lib().om_batch_step(self._h, a.ctypes.data, self._out.ctypes.data, self.nthreads)

@@ -1442,6 +1442,65 @@ def test_planar_push_variants(oracle_mod, n_objects, reward_type, autoreset):
     assert sens.mean() < 0.2 and n_last >= N
 
 
+def test_planar_push_episodes_ending_at_different_times(oracle_mod):
+    """A wavefront of the Planar-Push kernel carries four envs through ONE substep loop; the other tests end all episodes at
+    the same step, so the four always reset together. Here one env of every wavefront is reset on its own after five steps
+    (mjs_reset with a mask; the oracle resets the same envs), which shifts its step limit: from then on a wavefront holds
+    envs that run the reset's 150 settle substeps next to envs that take their 20 (next-step auto-reset), twice per env.
+    Conditioning mask as in test_planar_push_variants."""
+    import ctypes as C
+
+    import mujoco_sim_amd as m
+
+    N, T, LIMIT = 64, 34, 12
+    knob = C.c_double.in_dll(oracle_mod.lib(), "om_dbg_perturb")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=52, max_episode_steps=LIMIT, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 52, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 52, max_episode_steps=LIMIT, nthreads=8, block_shape=1)
+    venv.reset()
+    o = ob.reset()
+    knob.value = 1e-13
+    o2 = ob2.reset()
+    knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    early = np.arange(N) % 4 == 1
+    rs = np.random.RandomState(8)
+    n_last = n_mixed = 0
+    for t in range(T):
+        if t == 5:  # the masked reset: these envs start a new episode now
+            venv.reset(mask=torch.from_numpy(early))
+            o = ob.reset_envs(np.nonzero(early)[0])
+            knob.value = 1e-13
+            o2 = ob2.reset_envs(np.nonzero(early)[0])
+            knob.value = 0.0
+            sens = np.where(early, np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-12, sens)
+            g = _gpu_result(venv)
+            ok = early & ~sens
+            np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg="masked reset")
+            assert (np.asarray(g["step_type"])[early] == 0).all()
+        tcp, blk = o["obs"][:, :2], o["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + rs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        knob.value = 1e-13
+        o2 = ob2.step(a)
+        knob.value = 0.0
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] == 0) & (o2["step_type"] == 0)
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
+        g = _gpu_result(venv)
+        ok = ~sens
+        np.testing.assert_allclose(g["obs"][ok], o["obs"][ok], rtol=0, atol=1e-8, err_msg=f"obs step {t}")
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k])[ok].astype(int), np.asarray(o[k])[ok].astype(int)), (k, t)
+        first = np.asarray(o["step_type"]) == 0
+        n_last += int((np.asarray(o["step_type"]) == 2).sum())
+        per_wave = first.reshape(-1, 4).sum(axis=1)
+        n_mixed += int(((per_wave > 0) & (per_wave < 4)).sum())
+    assert sens.mean() < 0.2 and n_last >= 2 * N and n_mixed >= 3 * (N // 4), (sens.mean(), n_last, n_mixed)
+    venv.close()
+
+
 @pytest.mark.parametrize("n_objects,shape", [(3, "box"), (5, "box"), (5, "mesh"), (4, "mesh")])
 def test_planar_push_many_objects(oracle_mod, n_objects, shape):
     """n_objects 3..5 (5 = RobotPushConfig's default, robot_planar_push.py:61) run the 5-slot kernel instance: 15-wide flat
