@@ -22,13 +22,15 @@ NT = 16
 bad_total = 0
 
 
-def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_kw=None, atol=1e-7):
+def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_kw=None, atol=1e-7, obs_sink=None):
     global bad_total
     t0 = time.time()
     venv = m.HipVectorEnv(task, N, seed=seed, **(venv_kw or {}))
     ob = oracle.OracleBatch(tid, N, seed, nthreads=NT, **(ob_kw or {}))
     venv.reset()
     o = ob.reset()
+    if obs_sink is not None:
+        obs_sink["obs"] = o["obs"]
     g = _gpu_result(venv)
     assert np.abs(g["obs"] - o["obs"]).max() < 1e-9, "reset"
     alive = np.ones(N, bool)
@@ -44,6 +46,8 @@ def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_
                     n_tie += 1
         venv.step(torch.from_numpy(a))
         o = ob.step(a)
+        if obs_sink is not None:
+            obs_sink["obs"] = o["obs"]
         g = _gpu_result(venv)
         n_guard += int(((g["fault"] & (8 | 16)) > 0)[alive].sum())
         alive &= ~o["fault"] & ~(g["fault"] & (1 | 8 | 16)).astype(bool) & (np.abs(o["obs"]).max(axis=1) < 50)
@@ -69,9 +73,20 @@ def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_
 
 
 rs = np.random.RandomState(123)
-which = sys.argv[1:] or ["reach_box", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "pointmass"]  # (Planar-Push: its own tests carry the conditioning mask that contact-rich free bodies need)
+which = sys.argv[1:] or ["reach_box", "reach_success", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "pointmass"]  # (Planar-Push: its own tests carry the conditioning mask that contact-rich free bodies need)
 if "reach_box" in which:
     run("Robot-Reach, workspace actions, 3 episodes", "robot_reach", oracle.TASK_ROBOT_REACH, 4096, 250, lambda t: rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (4096, 3)), 11)
+if "reach_success" in which:
+    # episodes that end at different times (terminate_on_success): three quarters of the envs servo to their target; the host picks the reset-groups kernel
+    state = {}
+    def seek(t, N=4096):
+        a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N, 3))
+        if "obs" in state:
+            k = np.arange(N) % 4 != 0
+            a[k] = state["obs"][k, 9:12] + rs.normal(0, 0.002, (int(k.sum()), 3))
+        return a
+    run("Robot-Reach, success-terminated episodes (reset groups)", "robot_reach", oracle.TASK_ROBOT_REACH, 4096, 300, seek, 18,
+        venv_kw=dict(terminate_on_success=True), ob_kw=dict(terminate_on_success=True), obs_sink=state)
 if "reach_wild" in which:
     def wild(t, N=2048):
         a = rs.uniform([-0.6, -0.9, -0.15], [0.6, 0.1, 0.5], (N, 3))
