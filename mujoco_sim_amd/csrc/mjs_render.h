@@ -737,6 +737,134 @@ MJS_DEV void exact_test(const float* pr, F3 eye, F3 d, Surf& s) {
   else if (type == PRIM_CYLINDER) hit_cylinder(eye, d, p0, p1, pr[13], rgb, s);
   else hit_obb(eye, d, p0, p1, f3(pr[7], pr[8], pr[9]), f3(pr[10], pr[11], pr[12]), rgb, s);
 }
+// The exact tests again with everything that does not depend on the ray taken out: for one env image the eye is fixed, so
+// ba, oa, their dot products and the whole constant term of the quadratic (capsule / cylinder), oc and cc (sphere), the third
+// axis and the eye in box coordinates (box) are the same for every pixel. prim_consts evaluates them once per primitive with
+// the expressions of hit_* above (same operations in the same order: the rays' results are bitwise those of exact_test,
+// test_scene_camera_kernels_agree_byte_for_byte compares the two walks); exact_test_pre reads them from LDS.
+constexpr int PRIM_CONSTS = 12;
+MJS_DEV void prim_consts(const float* pr, F3 o, float* pc) {
+  const int type = (int)pr[0];
+  const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+  if (type == PRIM_SPHERE) {
+    const float r = pr[13];
+    F3 oc = sub(o, p0);
+    float cc = dotf(oc, oc) - r * r;
+    pc[0] = oc.x; pc[1] = oc.y; pc[2] = oc.z; pc[3] = cc;
+  } else if (type == PRIM_CAPSULE || type == PRIM_CYLINDER) {
+    const float r = pr[13];
+    F3 ba = sub(p1, p0), oa = sub(o, p0);
+    float baba = dotf(ba, ba), baoa = dotf(ba, oa), oaoa = dotf(oa, oa);
+    float c = baba * oaoa - baoa * baoa - r * r * baba;
+    pc[0] = ba.x; pc[1] = ba.y; pc[2] = ba.z; pc[3] = oa.x; pc[4] = oa.y; pc[5] = oa.z; pc[6] = baba; pc[7] = baoa; pc[8] = c;
+    pc[9] = 1.0f / r;             // the normals' scale (a division per hit)
+    pc[10] = 1.0f / sqrtf(baba);  // cylinder caps
+  } else {
+    const F3 u = p1, v = f3(pr[7], pr[8], pr[9]);
+    F3 w = F3{u.y * v.z - u.z * v.y, u.z * v.x - u.x * v.z, u.x * v.y - u.y * v.x};
+    F3 oc = sub(o, p0);
+    pc[0] = w.x; pc[1] = w.y; pc[2] = w.z; pc[3] = dotf(oc, u); pc[4] = dotf(oc, v); pc[5] = dotf(oc, w);
+  }
+}
+MJS_DEV void exact_test_pre(const float* pr, const float* pc, F3 o, F3 d, Surf& s) {
+  const int type = (int)pr[0];
+  const F3 rgb = f3(pr[14], pr[15], pr[16]);
+  if (type == PRIM_SPHERE) {
+    const F3 c = f3(pr[1], pr[2], pr[3]), oc = f3(pc[0], pc[1], pc[2]);
+    float b = dotf(oc, d), cc = pc[3];
+    float disc = b * b - cc;
+    if (disc < 0.0f) return;
+    float t = -b - sqrtf(disc);
+    if (!(t > 0.0f) || !(t < s.t)) return;
+    s.t = t;
+    F3 p = add(o, mul(t, d));
+    s.n = normalize(sub(p, c));
+    s.rgb = rgb;
+  } else if (type == PRIM_CAPSULE) {
+    const float r = pr[13];
+    const F3 pb = f3(pr[4], pr[5], pr[6]), ba = f3(pc[0], pc[1], pc[2]), oa = f3(pc[3], pc[4], pc[5]);
+    const float baba = pc[6], baoa = pc[7], c = pc[8];
+    float bard = dotf(ba, d), rdoa = dotf(d, oa);
+    float a = baba - bard * bard, b = baba * rdoa - baoa * bard;
+    float h = b * b - a * c;
+    if (h < 0.0f) return;
+    if (a > 0.0f) {
+      float t = (-b - sqrtf(h)) / a;
+      float y = baoa + t * bard;
+      if (y > 0.0f && y < baba) {
+        if (!(t > 0.0f) || !(t < s.t)) return;
+        s.t = t;
+        F3 pn = sub(add(oa, mul(t, d)), mul(y / baba, ba));
+        s.n = mul(pc[9], pn);
+        s.rgb = rgb;
+        return;
+      }
+      // end caps
+      F3 oc = y <= 0.0f ? oa : sub(o, pb);
+      float bb = dotf(d, oc), cc = dotf(oc, oc) - r * r;
+      float hh = bb * bb - cc;
+      if (hh > 0.0f) {
+        float tc = -bb - sqrtf(hh);
+        if (!(tc > 0.0f) || !(tc < s.t)) return;
+        s.t = tc;
+        s.n = mul(pc[9], add(oc, mul(tc, d)));
+        s.rgb = rgb;
+      }
+    }
+  } else if (type == PRIM_CYLINDER) {
+    const float r = pr[13];
+    const F3 ba = f3(pc[0], pc[1], pc[2]), oa = f3(pc[3], pc[4], pc[5]);
+    const float baba = pc[6], baoa = pc[7], k0 = pc[8];
+    float bard = dotf(ba, d);
+    float k2 = baba - bard * bard, k1 = baba * dotf(oa, d) - baoa * bard;
+    float h = k1 * k1 - k2 * k0;
+    if (h < 0.0f) return;
+    if (k2 > 0.0f) {
+      float t = (-k1 - sqrtf(h)) / k2;
+      float y = baoa + t * bard;
+      if (y > 0.0f && y < baba) {
+        if (!(t > 0.0f) || !(t < s.t)) return;
+        s.t = t;
+        s.n = mul(pc[9], sub(add(oa, mul(t, d)), mul(y / baba, ba)));
+        s.rgb = rgb;
+        return;
+      }
+    }
+    // caps
+    if (bard == 0.0f) return;
+    float tc = ((bard < 0.0f ? baba : 0.0f) - baoa) / bard;  // the cap facing the ray
+    if (!(tc > 0.0f) || !(tc < s.t)) return;
+    F3 q = add(oa, mul(tc, d));
+    float yc = bard < 0.0f ? baba : 0.0f;
+    F3 radial = sub(q, mul(yc / baba, ba));
+    if (dotf(radial, radial) > r * r) return;
+    s.t = tc;
+    float inv = pc[10];
+    s.n = mul(bard < 0.0f ? inv : -inv, ba);
+    s.rgb = rgb;
+  } else {
+    const F3 u = f3(pr[4], pr[5], pr[6]), v = f3(pr[7], pr[8], pr[9]), w = f3(pc[0], pc[1], pc[2]);
+    const float oo[3] = {pc[3], pc[4], pc[5]}, dd[3] = {dotf(d, u), dotf(d, v), dotf(d, w)}, hh[3] = {pr[10], pr[11], pr[12]};
+    float tmin = 0.0f, tmax = s.t, sg = 0.0f;
+    int ax = -1;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      if (dd[k] == 0.0f) {
+        if (oo[k] < -hh[k] || oo[k] > hh[k]) return;
+        continue;
+      }
+      float t1 = (-hh[k] - oo[k]) / dd[k], t2 = (hh[k] - oo[k]) / dd[k], sgn = -1.0f;
+      if (t1 > t2) { float tmp = t1; t1 = t2; t2 = tmp; sgn = 1.0f; }
+      if (t1 > tmin) { tmin = t1; ax = k; sg = sgn; }
+      if (t2 < tmax) tmax = t2;
+      if (tmin > tmax) return;
+    }
+    if (ax < 0 || !(tmin > 0.0f) || !(tmin < s.t)) return;
+    s.t = tmin;
+    s.n = mul(sg, ax == 0 ? u : ax == 1 ? v : w);
+    s.rgb = rgb;
+  }
+}
 // Pixel rectangle [r0, r1] x [c0, c1] that bounds every pixel whose ray can hit the primitive (empty: r1 < r0). Far
 // primitives: tangent extents of the bounding sphere(s); primitives whose spheres reach the camera plane (the gripper and
 // the last wrist links next to the wrist camera): the primitive's box clipped at 1 mm depth; both when both apply.
@@ -801,6 +929,15 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
   __shared__ int bbox[MAX_NPRIM * 4];
   __shared__ uint32_t image[RECT_WALK_MAX_PIXELS];  // packed colours, written out coalesced at the end
   __shared__ int next_tile;                        // tiles are taken in turn by whichever wavefront is free
+  // body-mounted camera: the image-plane coordinates of a column / a row (pixel_ray_axes' px, py: two IEEE divisions per
+  // pixel) are the same for every pixel of that column / row: computed once per workgroup with the same expressions, read
+  // from LDS per pixel (bitwise the same rays; W <= RECT_WALK_MAX_PIXELS / 8)
+  // per primitive, the same for every pixel of the env's image: centre of the bounding sphere relative to the eye and its
+  // squared length (the per-ray reject of the candidate walk computed them per pixel)
+  __shared__ float bound_oc[MAX_NPRIM][4];
+  __shared__ float pconst[MAX_NPRIM][PRIM_CONSTS];  // prim_consts: the ray-independent part of each primitive's exact test
+  __shared__ float pxtab[FIXED ? 1 : RECT_WALK_MAX_PIXELS / 8];
+  __shared__ float pytab[FIXED ? 1 : RECT_WALK_MAX_PIXELS / 8];
   // one workgroup per (env, band of rows): images above 4096 pixels are cut into bands of band_rows rows (a multiple of 8,
   // band_rows * W <= 4096) that stage their 16 KB of colours each; a band is contiguous in the output
   const int env = blockIdx.x, nprim = p.nprim, tid = threadIdx.x, lane = tid & 63;
@@ -812,6 +949,11 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
     if (tid == 0) next_tile = 0;
     if (FIXED)  // the env-independent image first; only tiles a primitive touches are revisited
       for (int k = tid; k < npix; k += 256) image[k] = bg.rgb[pix0 + k];
+    else {
+      const float aspect = (float)p.W / (float)p.H;
+      for (int col = tid; col < p.W; col += 256) pxtab[col] = (2.0f * ((float)col + 0.5f) / (float)p.W - 1.0f) * p.cam.tan_half * aspect;
+      for (int r = tid; r < rows; r += 256) pytab[r] = (1.0f - 2.0f * ((float)(band0 + r) + 0.5f) / (float)p.H) * p.cam.tan_half;
+    }
   }
   F3 eye = f3(p.cam.pos[0], p.cam.pos[1], p.cam.pos[2]);
   const float* right = p.cam.right;
@@ -824,6 +966,14 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
   }
   __syncthreads();
   if (tid < nprim) {
+    {
+      const float* pr = lds_prims + tid * PRIM_FLOATS;
+      const int type = (int)pr[0];
+      const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
+      const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
+      bound_oc[tid][0] = oc.x; bound_oc[tid][1] = oc.y; bound_oc[tid][2] = oc.z; bound_oc[tid][3] = dotf(oc, oc);
+      prim_consts(pr, eye, pconst[tid]);
+    }
     prim_rect(p, lds_prims + tid * PRIM_FLOATS, eye, right, up, back, bbox + 4 * tid);
     // A capped cylinder that FOLLOWS a capsule on the same segment with the same radius (the UR5e's last two collision
     // proxies, MJS_UR_COL_* 8 and 9) can never win a pixel: it lies inside the capsule, its side hits have the capsule's
@@ -863,20 +1013,19 @@ __global__ __launch_bounds__(256) void robot_scene_rect_walk_kernel(RenderParams
       t_floor = r4.w;
       s.t = t_floor;  // the floor's hit bounds the walk exactly as in the sequential test order (floor first)
     } else {
-      d = pixel_ray_axes(p, row, col, right, up, back);
+      const float px = pxtab[col], py = pytab[row - band0];
+      d = normalize(f3(px * right[0] + py * up[0] - back[0], px * right[1] + py * up[1] - back[1], px * right[2] + py * up[2] - back[2]));  // = pixel_ray_axes
       hit_rect_z(eye, d, 0.0f, (float)MJS_ROBOT_ARENA_HALF, (float)MJS_ROBOT_ARENA_HALF, f3(MJS_RR_FLOOR_RGB[0], MJS_RR_FLOOR_RGB[1], MJS_RR_FLOOR_RGB[2]), false, s);
     }
     while (cand) {  // ascending primitive index = the oracle's test order
       const int k = __ffs(cand) - 1;
       cand &= cand - 1;
       const float* pr = lds_prims + k * PRIM_FLOATS;
-      const int type = (int)pr[0];
-      const F3 p0 = f3(pr[1], pr[2], pr[3]), p1 = f3(pr[4], pr[5], pr[6]);
-      const F3 oc = sub((type == PRIM_CAPSULE || type == PRIM_CYLINDER) ? mul(0.5f, add(p0, p1)) : p0, eye);
-      const float along = dotf(oc, d), off2 = dotf(oc, oc) - along * along, br = pr[17];  // per-ray bounding-sphere reject
+      const F3 oc = f3(bound_oc[k][0], bound_oc[k][1], bound_oc[k][2]);
+      const float along = dotf(oc, d), off2 = bound_oc[k][3] - along * along, br = pr[17];  // per-ray bounding-sphere reject
       if (!(off2 <= br * br && along + br > 0.0f)) continue;
       if (along - br > s.t) continue;  // every point of the bound lies beyond the nearest hit so far: it cannot pass the strict-< update
-      exact_test(pr, eye, d, s);
+      exact_test_pre(pr, pconst[k], eye, d, s);
     }
     if (FIXED) {
       if (s.t < t_floor) image[(row - band0) * p.W + col] = pack_rgb(shade<6>(add(eye, mul(s.t, d)), s.n, eye, s.rgb, MJS_RR_LIGHT_POS));  // a primitive won the pixel
