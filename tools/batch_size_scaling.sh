@@ -1,5 +1,5 @@
 #!/bin/bash
-out=gpurun_out/r3k; mkdir -p $out
+out=gpurun_out/${1:-r3k}; mkdir -p $out
 run() { python bench.py "$@" --no-cpu-baseline | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['config']['workload'].split(':')[0], d['config']['envs_per_gpu'], round(d['value']/1e6,3), round(d['ms_per_step']*1000,1))"; }
 for n in 4096 16384 65536 262144; do run --envs-per-gpu $n --steps 300 --warmup 30; done
 for n in 4096 65536 262144; do run --task point_mass_reach --envs-per-gpu $n --steps 300 --warmup 30; done
