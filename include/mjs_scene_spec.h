@@ -176,6 +176,69 @@ MJS_K double MJS_G2F85_ACT_FORCE = 5.0;
 MJS_K double MJS_G2F85_CTRL_MAX = 255.0;
 MJS_K double MJS_G2F85_DRIVER_ARMATURE = 0.005;
 MJS_K double MJS_G2F85_DRIVER_DAMPING = 0.1;
+/* ---- Robotiq 2F-85, ARTICULATED [MEN]: robotiq_2f85/2f85.xml of mujoco_menagerie as recalled (the package
+ * robot_descriptions that the reference loads it from, gripper.py:5,37, is absent: unverified, parity unpinned). What the
+ * reference itself holds agrees with it: 8 hinge joints in the order of gripper.py:40 (right driver, coupler, spring_link,
+ * follower, then left), the driver range 0..0.8 (gripper.py:38), an 85 mm stroke (gripper.py:50-52: the pads' inner faces are
+ * 2 x 42.7 mm apart at q = 0 and 0.2 mm at 0.8 rad in this geometry), the actuator `fingers_actuator` with ctrl 0..255
+ * (gripper.py:58-60,81-84), TCP = the finger tips when CLOSED (gripper.py:46-48: 0.174 m; pads end 0.160 m from the flange
+ * when open, 0.174 m when closed).
+ * Bodies in MJCF (depth-first) order; parent -1 = the attachment frame (dm_control `attach` puts the gripper's worldbody in
+ * a body at the flange site). Every joint is a hinge about the body's local x (default class "2f85": axis 1 0 0). The
+ * mesh collision geoms of base_mount / base / driver / coupler / spring_link / follower are NOT modelled (the meshes are not
+ * in the reference): the pads' boxes are the gripper's only collision geoms. base_mount has no <inertial>
+ * in the MJCF (MuJoCo derives it from the mesh): the value here makes the gripper weigh 0.925 kg like the lump of D-1. */
+#define MJS_G85_NBODY 12
+#define MJS_G85_NJ 8
+MJS_K int MJS_G85_PARENT[MJS_G85_NBODY] = {-1, 0, 1, 2, 1, 4, 5, 1, 7, 1, 9, 10};
+MJS_K double MJS_G85_POS[MJS_G85_NBODY][3] = {
+    {0, 0, 0.007}, {0, 0, 0.0038},
+    {0, 0.0306011, 0.054904}, {0, 0.0315, -0.0041}, {0, 0.0132, 0.0609}, {0, 0.055, 0.0375}, {0, -0.0189, 0.01352},
+    {0, -0.0306011, 0.054904}, {0, 0.0315, -0.0041}, {0, -0.0132, 0.0609}, {0, 0.055, 0.0375}, {0, -0.0189, 0.01352}};
+MJS_K double MJS_G85_QUAT[MJS_G85_NBODY][4] = {
+    {1, 0, 0, 0}, {1, 0, 0, -1},
+    {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0}, {1, 0, 0, 0},
+    {0, 0, 0, 1}, {1, 0, 0, 0}, {0, 0, 0, 1}, {1, 0, 0, 0}, {1, 0, 0, 0}};
+MJS_K double MJS_G85_MASS[MJS_G85_NBODY] = {0.02500014, 0.777441, 0.00899563, 0.0140974, 0.0221642, 0.0125222, 0.0035,
+                                            0.00899563, 0.0140974, 0.0221642, 0.0125222, 0.0035};
+MJS_K double MJS_G85_IPOS[MJS_G85_NBODY][3] = {
+    {0, 0, 0.002}, {0, -2.70394e-05, 0.0354675},
+    {2.96931e-12, 0.0177547, 0.00107314}, {0, 0.00301209, 0.0232175}, {-8.65005e-09, 0.0181624, 0.0212658}, {0, -0.011046, 0.0124786}, {0, -0.0025, 0.0185},
+    {2.96931e-12, 0.0177547, 0.00107314}, {0, 0.00301209, 0.0232175}, {-8.65005e-09, 0.0181624, 0.0212658}, {0, -0.011046, 0.0124786}, {0, -0.0025, 0.0185}};
+MJS_K double MJS_G85_IQUAT[MJS_G85_NBODY][4] = {
+    {1, 0, 0, 0}, {1, -0.00152849, 0, 0},
+    {0.681301, 0.732003, 0, 0}, {0.705636, -0.0455904, 0.0455904, 0.705636}, {0.663403, -0.244737, 0.244737, 0.663403}, {1, 0.1664, 0, 0}, {0.707107, 0, 0, 0.707107},
+    {0.681301, 0.732003, 0, 0}, {0.705636, -0.0455904, 0.0455904, 0.705636}, {0.663403, -0.244737, 0.244737, 0.663403}, {1, 0.1664, 0, 0}, {0.707107, 0, 0, 0.707107}};
+MJS_K double MJS_G85_DIAGINERTIA[MJS_G85_NBODY][3] = {
+    {6.0e-06, 6.0e-06, 1.1e-05}, {0.000260285, 0.000225381, 0.000152708},
+    {1.72352e-06, 1.60906e-06, 3.22006e-07}, {4.16206e-06, 3.52216e-06, 8.88131e-07}, {8.96853e-06, 6.71733e-06, 2.63931e-06}, {2.67415e-06, 2.4559e-06, 6.02031e-07}, {4.73958e-07, 3.64583e-07, 1.23958e-07},
+    {1.72352e-06, 1.60906e-06, 3.22006e-07}, {4.16206e-06, 3.52216e-06, 8.88131e-07}, {8.96853e-06, 6.71733e-06, 2.63931e-06}, {2.67415e-06, 2.4559e-06, 6.02031e-07}, {4.73958e-07, 3.64583e-07, 1.23958e-07}};
+/* joint of a body: -1 none, else the class 0 driver, 1 coupler, 2 spring_link, 3 follower */
+MJS_K int MJS_G85_JCLASS[MJS_G85_NBODY] = {-1, -1, 0, 1, 2, 3, -1, 0, 1, 2, 3, -1};
+MJS_K double MJS_G85_JRANGE[4][2] = {{0, 0.8}, {-1.57, 0}, {-0.29670597283, 0.8}, {-0.872664, 0.872664}};
+MJS_K double MJS_G85_JARMATURE[4] = {0.005, 0.001, 0.001, 0.001};
+MJS_K double MJS_G85_JDAMPING[4] = {0.1, 0, 0.00125, 0};
+MJS_K double MJS_G85_JSTIFFNESS[4] = {0, 0, 0.05, 0};
+MJS_K double MJS_G85_JSPRINGREF[4] = {0, 0, 2.62, 0};
+MJS_K double MJS_G85_JPOS[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, -0.018, 0.0065}};
+/* solreflimit / solimplimit of the driver, coupler and follower classes; the spring_link class keeps MuJoCo's defaults. The
+ * two connects and the driver coupling use the same pair. */
+MJS_K int    MJS_G85_JSTIFFLIMIT[4] = {1, 1, 0, 1};
+MJS_K double MJS_G85_SOLREF[2] = {0.005, 1};
+MJS_K double MJS_G85_SOLIMP[5] = {0.95, 0.99, 0.001, 0.5, 2};
+/* pad boxes (classes pad_box1 / pad_box2) on the two pad bodies: mass 0, priority 1, condim 3 */
+MJS_K double MJS_G85_PAD_SIZE[3] = {0.011, 0.004, 0.009375};
+MJS_K double MJS_G85_PAD_POS[2][3] = {{0, -0.0026, 0.028125}, {0, -0.0026, 0.009375}};
+MJS_K double MJS_G85_PAD_FRICTION[2] = {0.7, 0.6};
+MJS_K double MJS_G85_PAD_SOLREF[2] = {0.004, 1};
+MJS_K double MJS_G85_PAD_SOLIMP[5] = {0.95, 0.99, 0.001, 0.5, 2};
+/* table indices */
+MJS_K int MJS_G85_B_RIGHT_COUPLER = 3, MJS_G85_B_RIGHT_FOLLOWER = 5, MJS_G85_B_RIGHT_PAD = 6;
+MJS_K int MJS_G85_B_LEFT_COUPLER = 8, MJS_G85_B_LEFT_FOLLOWER = 10, MJS_G85_B_LEFT_PAD = 11;
+MJS_K int MJS_G85_J_RIGHT_DRIVER = 0, MJS_G85_J_LEFT_DRIVER = 4;
+/* <option cone="elliptic" impratio="10"/> of the gripper's MJCF merges into the scene's options on attach */
+MJS_K double MJS_G85_IMPRATIO = 10.0;
+MJS_K double MJS_G85_TENDON_COEF = 0.5;        /* fixed tendon "split": 0.5 right_driver_joint + 0.5 left_driver_joint */
 /* cylinder EEF [REF] entities/eef/cylinder.py:17-41 */
 MJS_K double MJS_CYL_RADIUS = 0.02;
 MJS_K double MJS_CYL_HALFLEN = 0.05;

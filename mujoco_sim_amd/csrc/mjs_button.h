@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
   const rr::Ws ws{p.ws, p.N, i};
   if (resetter) {
-    if (role == 0 && pending) reset_lane(p, i, flags, ws, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
+    if (role == 0 && pending && pending_is_due(p, flags)) reset_lane(p, i, flags, ws, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
     return;
   }
   if (ROLES == 2) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it (see rr::kernel3)
@@ -1324,7 +1324,7 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
               (slot_overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | (violated ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? FLAG_RESET_PENDING : 0) | (solo ? FLAG_WARM_VALID : 0));
+  uint8_t newflags = (uint8_t)((flags & (FLAG_IK_FAILED | FLAG_SWITCH_ACTIVE | FLAG_SWITCH_PRESSED)) | (terminate ? pending_mark(p) : 0) | (solo ? FLAG_WARM_VALID : 0));
   rr::store_state_stepped(p, i, st);  // q, v, time: a step only reads the switch rows
   rr::store_cs(p, i, S_CS, cs, sn);
   if (solo) rr::store_warm(p, i, S_WARM, warm_out);

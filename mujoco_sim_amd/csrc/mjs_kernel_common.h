@@ -15,7 +15,11 @@
 // FLAG_CLEAR (Robot-Reach): every arm collision geom was >= rr::CLEAR_MARGIN above the floor in the step's final configuration.
 // FLAG_FRESH / FLAG_EPOCH (Robot-Reach's default step kernel): the env was reset by a reset workgroup of the step launch whose
 // parity FLAG_EPOCH holds; a stepping wavefront of THAT launch which reads the byte after the reset leaves the lane alone, the
-// next launch (other parity) steps it and clears both bits (rr::kernel3).
+// next launch (other parity) steps it and clears both bits (rr::kernel3). In such launches a NEW "reset pending" carries the parity
+// of the launch whose stepping workgroup set it (FLAG_EPOCH without FLAG_FRESH, pending_mark): a reset workgroup acts only on a
+// pending env of the OTHER parity (pending_is_due), i.e. one whose episode ended in an earlier launch - the reset workgroups are
+// the grid's second half and may start after a stepping workgroup of the same launch has retired (> 256 resident workgroups).
+// Host-written bytes are normalised to that rule (init_kernel, mjs_set_state); mjs_get_state exports neither bit.
 enum { FLAG_RESET_PENDING = 1, FLAG_IK_FAILED = 2, FLAG_WARM_VALID = 16, FLAG_CLEAR = 32, FLAG_FRESH = 64, FLAG_EPOCH = 128 };
 
 struct KernelParams {
@@ -40,6 +44,13 @@ struct KernelParams {
   mjs_outputs out;
   unsigned long long* stamps;  // diagnostic builds only (-DMJS_STAMPS): [workgroup][16] shader-clock stamps
 };
+
+__device__ __forceinline__ uint8_t pending_mark(const KernelParams& p) {
+  return (uint8_t)(FLAG_RESET_PENDING | ((p.reset_groups && p.epoch) ? FLAG_EPOCH : 0));
+}
+__device__ __forceinline__ bool pending_is_due(const KernelParams& p, uint8_t flags) {
+  return !(flags & FLAG_FRESH) && ((flags & FLAG_EPOCH) != 0) != (p.epoch != 0);
+}
 
 // In-kernel phase stamps for a SEPARATE diagnostic build (never in the shipped library): the real
 // kernel executes no stamp. s_memtime + lgkmcnt(0) as one asm statement (guide section 7).

@@ -1337,7 +1337,9 @@ MJS_DEV void finish_step(const KernelParams& p, int i, int lane, State& st, cons
   int fault = (bad ? MJS_FAULT_BAD_STATE : 0) | ((flags & FLAG_IK_FAILED) ? MJS_FAULT_IK_FAILED : 0) | (e.rows_active ? MJS_FAULT_LIMIT_COLDSTART : 0) |
               (e.overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0) | ((!e.solo && (ncon > 0 || joint_outside_range(st.q))) ? MJS_FAULT_FASTPATH_VIOLATED : 0);
   bool terminated = terminate && discount == 0.0, truncated = terminate && discount > 0.0;
-  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? FLAG_RESET_PENDING : 0) | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0) | (e.solo ? FLAG_WARM_VALID : 0));
+  // reset-groups launches mark a new "reset pending" with the launch's parity: a reset workgroup of THIS launch that reads the
+  // byte after this store leaves the env to the next launch (pending_mark, mjs_kernel_common.h)
+  uint8_t newflags = (uint8_t)((flags & FLAG_IK_FAILED) | (terminate ? pending_mark(p) : 0) | (minclr >= CLEAR_MARGIN ? FLAG_CLEAR : 0) | (e.solo ? FLAG_WARM_VALID : 0));
   // everything is written out BEFORE the (rare, real function call) same-step reset so that no value
   // has to stay live across that call
   if (!e.peer_stored_state) {
@@ -1620,7 +1622,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
   uint8_t flags = p.flags[i];
   const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
   if (resetter) {
-    if (wave == 0 && pending) reset_lane_next_step(p, i, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
+    if (wave == 0 && pending && pending_is_due(p, flags)) reset_lane_next_step(p, i, (uint8_t)(FLAG_FRESH | (p.epoch ? FLAG_EPOCH : 0)));
     return;
   }
   __syncthreads();

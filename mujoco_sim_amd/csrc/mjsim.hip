@@ -87,10 +87,12 @@ __global__ __launch_bounds__(64) void seed_kernel(DevRng rng, uint32_t base_seed
 }
 
 // Pointmass bookkeeping starts at 1.0 at construction (point_reach.py:112-113); flags = reset pending
-__global__ void init_kernel(double* state, uint8_t* flags, int N, int task) {
+// host_pending: the byte of an env that waits for its next-step reset, as the host writes it (reset-groups handles: with the
+// parity OPPOSITE to the next step launch's, i.e. "ended in an earlier launch", mjs_kernel_common.h)
+__global__ void init_kernel(double* state, uint8_t* flags, int N, int task, uint8_t host_pending) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
-  flags[i] = FLAG_RESET_PENDING;
+  flags[i] = host_pending;
   if (task == MJS_TASK_POINTMASS_REACH) {
     state[(size_t)pm::S_DIST * N + i] = 1.0;
     state[(size_t)pm::S_PREV * N + i] = 1.0;
@@ -101,13 +103,16 @@ __global__ void get_state_kernel(const double* state, const uint8_t* flags, doub
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   for (int k = 0; k < S; k++) out[(size_t)k * N + i] = state[(size_t)k * N + i];
-  out[(size_t)S * N + i] = (double)flags[i];
+  // the launch-parity protocol of the reset-groups variant is not part of a checkpoint: a restored env is neither "reset in
+  // this launch" nor marked with a parity of the handle it came from
+  out[(size_t)S * N + i] = (double)(uint8_t)(flags[i] & ~(FLAG_FRESH | FLAG_EPOCH));
 }
-__global__ void set_state_kernel(double* state, uint8_t* flags, const double* in, int N, int S, int task) {
+__global__ void set_state_kernel(double* state, uint8_t* flags, const double* in, int N, int S, int task, uint8_t host_pending) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   for (int k = 0; k < S; k++) state[(size_t)k * N + i] = in[(size_t)k * N + i];
-  uint8_t f = (uint8_t)in[(size_t)S * N + i];
+  uint8_t f = (uint8_t)((uint8_t)in[(size_t)S * N + i] & ~(FLAG_FRESH | FLAG_EPOCH));
+  if (f & FLAG_RESET_PENDING) f = (uint8_t)(f | host_pending);
   if (task == MJS_TASK_ROBOT_REACH || task == MJS_TASK_BUTTON_PUSH) {
     // the caller may have edited the joints: the carried cos / sin rows are kept when they belong to the given q (a checkpoint
     // resumes bit for bit) and rewritten with exact values when they do not
@@ -153,6 +158,14 @@ __global__ void tcp_to_joints_kernel(const double* pos, const double* guess, dou
   ok[i] = found;
 }
 
+bool uses_reset_groups(const mjs_handle* h) {
+  return (h->cfg.task == MJS_TASK_ROBOT_REACH || h->cfg.task == MJS_TASK_BUTTON_PUSH) && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS &&
+         h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
+}
+uint8_t host_pending_byte(const mjs_handle* h) {
+  return (uint8_t)(FLAG_RESET_PENDING | ((uses_reset_groups(h) && !h->epoch) ? FLAG_EPOCH : 0));
+}
+
 KernelParams make_params(const mjs_handle* h, const double* actions, const uint8_t* mask, const mjs_outputs* out) {
   KernelParams p;
   p.N = h->cfg.num_envs;
@@ -165,7 +178,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.max_episode_steps = h->cfg.max_episode_steps;
   p.block_shape = h->cfg.block_shape;
   p.epoch = h->epoch;
-  p.reset_groups = (h->cfg.task == MJS_TASK_ROBOT_REACH || h->cfg.task == MJS_TASK_BUTTON_PUSH) && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
+  p.reset_groups = uses_reset_groups(h);
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -183,6 +196,7 @@ inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); 
 
 template <bool IS_RESET>
 int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
+  bool flip_epoch = false;
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects <= MJS_PP_FAST_OBJECTS)
     pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, pp::LDS_BYTES, s>>>(p);
@@ -192,7 +206,7 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else if (p.reset_groups) {  // MJS_VARIANT_RESET_GROUPS: the second half of the grid resets the envs whose episode ended
       bp::kernel<false, 2><<<dim3(2 * grid_for(p.N).x), 2 * BLOCK, 0, s>>>(p);
-      h->epoch ^= 1;
+      flip_epoch = true;
     }
     else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
   }
@@ -209,10 +223,11 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     // per launch with 1 % of the envs ending in every step); the launch parity tells a freshly reset env from one that waits.
     // Not the default for synchronous episodes: the 64 extra workgroups cost 0.9 us per launch at 4096 envs.
     rr::kernel3<0><<<dim3(2 * grid_for(p.N).x), 3 * BLOCK, 0, s>>>(p);
-    h->epoch ^= 1;
+    flip_epoch = true;
   }
   else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);
   HIP_TRY(h, hipGetLastError());
+  if (flip_epoch) h->epoch ^= 1;  // only a launch that was accepted consumed its parity
   return MJS_OK;
 }
 
@@ -328,7 +343,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
     mjs_destroy(h);
     return rc;
   }
-  init_kernel<<<grid_for((int)N), BLOCK>>>(h->state, h->flags, (int)N, cfg->task);
+  init_kernel<<<grid_for((int)N), BLOCK>>>(h->state, h->flags, (int)N, cfg->task, host_pending_byte(h));
   seed_kernel<<<grid_for((int)N), BLOCK>>>(DevRng{h->rng_mt, h->rng_pos, (int)N}, 0u, cfg->env_index_offset);
   e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -563,7 +578,7 @@ int mjs_set_state(mjs_handle* h, const double* state_dev, void* stream) {
   DeviceGuard dev_(h->cfg.device);
   HIP_TRY(h, dev_.err);
   h->prims_valid = false;
-  set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim, h->cfg.task);
+  set_state_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state, h->flags, state_dev, h->cfg.num_envs, h->state_dim, h->cfg.task, host_pending_byte(h));
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }

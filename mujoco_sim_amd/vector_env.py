@@ -104,7 +104,7 @@ class HipVectorEnv:
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int | None = None,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
                  button_disturbances: bool = False, use_wrist_camera: bool = True, n_objects: int | None = None,
-                 max_episode_steps: int | None = None, block_shape: str = "mesh"):
+                 max_episode_steps: int | None = None, block_shape: str = "mesh", global_num_envs: int | None = None):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -131,9 +131,21 @@ class HipVectorEnv:
         self.autoreset = autoreset
         self.env_index_offset = int(env_index_offset)
         self._lib = nat.lib()
+        # The default step kernel is chosen from the env count of the whole JOB, not of this shard (include/mjsim.h: bitwise shard
+        # invariance holds only if every handle runs the same kernel shape; Robot-Reach switches shape above 16384 envs per GPU).
+        # A shard (env_index_offset != 0, or a rank of a sharded job) passes the job's total as `global_num_envs`; without it the
+        # lower bound env_index_offset + num_envs is all the handle knows.
+        self.global_num_envs = int(global_num_envs) if global_num_envs is not None else self.env_index_offset + self.num_envs
+        if self.global_num_envs < self.env_index_offset + self.num_envs:
+            raise ValueError("global_num_envs is smaller than env_index_offset + num_envs")
         if kernel_variant is None:
-            # Robot-Reach episodes that end at different times (terminate_on_success): resets on workgroups of their own (mjsim.h)
-            kernel_variant = nat.VARIANT_RESET_GROUPS if task == "robot_reach" and terminate_on_success and autoreset == "next_step" and self.num_envs <= 16384 else 0
+            if task == "robot_reach" and self.global_num_envs > 16384:
+                kernel_variant = nat.VARIANT_TWO_ROLES  # what MJS_VARIANT_DEFAULT runs on a handle of the whole job's size
+            elif task == "robot_reach" and terminate_on_success and autoreset == "next_step":
+                # episodes that end at different times: resets on workgroups of their own (mjsim.h)
+                kernel_variant = nat.VARIANT_RESET_GROUPS
+            else:
+                kernel_variant = 0
         cfg = nat.MjsConfig(task=self.spec.task_id, num_envs=self.num_envs, device=self._dev_index,
                             reward_type=_REWARD_IDS[reward_type] if reward_type else -1, autoreset=_AUTORESET_IDS[autoreset],
                             terminate_on_success=int(terminate_on_success), env_index_offset=self.env_index_offset, kernel_variant=int(kernel_variant),

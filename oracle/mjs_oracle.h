@@ -25,14 +25,15 @@
 extern "C" {
 #endif
 
-#define OM_MAXBODY 16
+#define OM_MAXBODY 24
 #define OM_MAXJNT 24
 #define OM_MAXQ 48
 #define OM_MAXV 36
 #define OM_MAXU 8
 #define OM_MAXGEOM 40
 #define OM_MAXSITE 8
-#define OM_MAXEQ 2
+#define OM_MAXEQ 4
+#define OM_MAXTENDON 1
 #define OM_MAXCON 48
 #define OM_MAXEFC 320
 #define OM_MAXMOCAP 1
@@ -41,7 +42,10 @@ extern "C" {
 enum { OM_JNT_FREE = 0, OM_JNT_BALL = 1, OM_JNT_SLIDE = 2, OM_JNT_HINGE = 3 };
 enum { OM_GEOM_PLANE = 0, OM_GEOM_SPHERE = 2, OM_GEOM_CAPSULE = 3, OM_GEOM_CYLINDER = 5, OM_GEOM_BOX = 6, OM_GEOM_MESH = 7 };
 enum { OM_INT_EULER = 0, OM_INT_IMPLICITFAST = 3 };
-enum { OM_CNSTR_EQUALITY = 0, OM_CNSTR_LIMIT_JOINT = 3, OM_CNSTR_CONTACT_FRICTIONLESS = 5, OM_CNSTR_CONTACT_PYRAMIDAL = 6 };
+enum { OM_CNSTR_EQUALITY = 0, OM_CNSTR_LIMIT_JOINT = 3, OM_CNSTR_CONTACT_FRICTIONLESS = 5, OM_CNSTR_CONTACT_PYRAMIDAL = 6, OM_CNSTR_CONTACT_ELLIPTIC = 7 };
+enum { OM_EQ_CONNECT = 0, OM_EQ_WELD = 1, OM_EQ_JOINT = 2 };   /* mjtEq */
+enum { OM_CONE_PYRAMIDAL = 0, OM_CONE_ELLIPTIC = 1 };            /* mjtCone */
+enum { OM_TRN_JOINT = 0, OM_TRN_TENDON = 3 };                    /* mjtTrn */
 
 typedef struct {
   int nbody, njnt, nq, nv, nu, ngeom, nsite, neq, nmocap;
@@ -54,11 +58,18 @@ typedef struct {
   /* joints / dofs */
   int jnt_type[OM_MAXJNT], jnt_body[OM_MAXJNT], jnt_qposadr[OM_MAXJNT], jnt_dofadr[OM_MAXJNT], jnt_limited[OM_MAXJNT];
   double jnt_pos[OM_MAXJNT][3], jnt_axis[OM_MAXJNT][3], jnt_range[OM_MAXJNT][2], jnt_margin[OM_MAXJNT];
+  /* per-joint limit solver parameters (solreflimit / solimplimit; the scene builder fills the global defaults), joint spring
+   * (stiffness, qpos_spring = springref) */
+  double jnt_solref[OM_MAXJNT][2], jnt_solimp[OM_MAXJNT][5], jnt_stiffness[OM_MAXJNT], qpos_spring[OM_MAXQ];
   int dof_body[OM_MAXV], dof_jnt[OM_MAXV], dof_parent[OM_MAXV];
   double dof_armature[OM_MAXV], dof_damping[OM_MAXV], dof_invweight0[OM_MAXV];
   double qpos0[OM_MAXQ];
   /* geoms */
   int geom_type[OM_MAXGEOM], geom_body[OM_MAXGEOM], geom_contype[OM_MAXGEOM], geom_conaffinity[OM_MAXGEOM], geom_condim[OM_MAXGEOM];
+  /* contact parameter mixing (mj_contactParam): the geom of higher priority gives condim / friction / solref / solimp, equal
+   * priorities take the maxima and (solmix 1 : 1) the mean of solref / solimp */
+  int geom_priority[OM_MAXGEOM];
+  double geom_solref[OM_MAXGEOM][2], geom_solimp[OM_MAXGEOM][5];
   double geom_pos[OM_MAXGEOM][3], geom_quat[OM_MAXGEOM][4], geom_size[OM_MAXGEOM][3], geom_friction[OM_MAXGEOM][3];
   /* OM_GEOM_MESH: category of include/mjs_block_hulls.h (collided by its convex hull, as MuJoCo does) and mesh scale; the geom
    * frame sits at the mesh's centre of mass (MuJoCo re-centres a mesh geom there) */
@@ -67,11 +78,15 @@ typedef struct {
   /* sites */
   int site_body[OM_MAXSITE];
   double site_pos[OM_MAXSITE][3], site_quat[OM_MAXSITE][4];
-  /* actuators: joint transmission, fixed gain, affine bias */
-  int act_jnt[OM_MAXU], act_ctrllimited[OM_MAXU], act_forcelimited[OM_MAXU];
+  /* actuators: joint or fixed-tendon transmission (act_trntype, act_jnt = joint / tendon id), fixed gain, affine bias */
+  int act_jnt[OM_MAXU], act_trntype[OM_MAXU], act_ctrllimited[OM_MAXU], act_forcelimited[OM_MAXU];
+  /* fixed tendons: length = sum_j coef[j] qpos[dof j] (hinge / slide joints only) */
+  int ntendon;
+  double tendon_coef[OM_MAXTENDON][OM_MAXV];
   double act_gain[OM_MAXU], act_bias[OM_MAXU][3], act_ctrlrange[OM_MAXU][2], act_forcerange[OM_MAXU][2];
-  /* equality: weld only */
-  int eq_body1[OM_MAXEQ], eq_body2[OM_MAXEQ];
+  /* equality: weld / connect (eq_body1/2 = bodies; connect data: anchor in body1, anchor in body2) and joint coupling
+   * (eq_body1/2 = JOINT ids; data[0..4] = polycoef) */
+  int eq_type[OM_MAXEQ], eq_body1[OM_MAXEQ], eq_body2[OM_MAXEQ];
   double eq_data[OM_MAXEQ][11], eq_solref[OM_MAXEQ][2], eq_solimp[OM_MAXEQ][5];
   /* reduced 2F-85 (Button-Push): the two finger-tip sphere geoms, re-placed from the driver angle in every substep (-1 none) */
   int gr_geom[2];
@@ -81,12 +96,13 @@ typedef struct {
   /* options + statistics */
   double dt, gravity[3], tolerance, impratio, meaninertia;
   double solref[2], solimp[5]; /* global default contact/limit parameters */
-  int iterations, integrator;
+  int iterations, integrator, cone;
 } om_model;
 
 typedef struct {
   double dist, pos[3], frame[9], includemargin, friction[5], solref[2], solimp[5], mu;
   int dim, geom1, geom2, exclude, efc_address;
+  int zone; /* elliptic cone: 0 top (no force), 1 middle (cone surface), 2 bottom (fully quadratic): PrimalUpdateConstraint's state */
 } om_contact;
 
 typedef struct {
@@ -151,8 +167,12 @@ typedef struct {
   int max_episode_steps;     /* Planar-Push only: RobotTask step limit (base.py:47-51), default 500 */
   int block_shape;           /* Planar-Push only: OM_BLOCKS_MESH (reference: google_block.py, category / colour / scale drawn per
                               * episode from the env's seeded stream, deviation D-5) or OM_BLOCKS_BOX (round 1's stand-in) */
+  int gripper_model;         /* Button-Push only: OM_GRIPPER_REDUCED (D-1b: one driver coordinate + two tip spheres, nv = 6) or
+                              * OM_GRIPPER_ARTICULATED (the 2F-85's eight hinges, two connects, the driver coupling, the
+                              * fixed-tendon actuator, pad boxes, elliptic cones with impratio 10; nv = 14) */
 } om_task_config;
 enum { OM_BLOCKS_MESH = 0, OM_BLOCKS_BOX = 1 };
+enum { OM_GRIPPER_REDUCED = 0, OM_GRIPPER_ARTICULATED = 1 };
 
 #define OM_MAXOBS 16
 typedef struct {
@@ -215,6 +235,11 @@ void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);
 void om_debug_get_gripper(const om_env* e, double* theta_vel);
 void om_debug_set_gripper(om_env* e, double theta, double vel);
 void om_debug_substeps(om_env* e, int n);
+void om_debug_model_dims(const om_env* e, int* out8);
+int om_debug_efc(const om_env* e, int maxrows, double* pos, double* J, int* type, double* force, double* aref, double* D);
+void om_debug_geom_pose(const om_env* e, int g, double* pos3, double* mat9);
+void om_debug_set_ctrl(om_env* e, int u, double value);
+void om_debug_get_dynamics(const om_env* e, double* M, double* qfrc_smooth, double* qacc);
 int om_debug_convex(int type1, const double* size1, const double* pos1, const double* mat1, int type2, const double* size2, const double* pos2,
                     const double* mat2, double* out);
 void om_debug_reach_dynamics(const double* q, const double* v, double* M_out, double* bias_out);

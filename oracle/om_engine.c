@@ -300,13 +300,22 @@ static int add_contact(const om_model* m, om_data* d, int g1, int g2, double dis
   memcpy(c->frame, normal, sizeof(double) * 3);
   make_frame(c->frame);
   c->geom1 = g1; c->geom2 = g2;
-  c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
-  /* equal priority: friction = element-wise max; solref/solimp: equal solmix -> average (all default here) */
+  /* mj_contactParam: the geom of higher priority decides; equal priority: condim and friction = element-wise max, solref / solimp
+   * mixed with the weights solmix1 : solmix2 = 1 : 1 (both solref in the standard, positive format) */
   double fr[3];
-  for (int k = 0; k < 3; k++) fr[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+  if (m->geom_priority[g1] != m->geom_priority[g2]) {
+    const int gp = m->geom_priority[g1] > m->geom_priority[g2] ? g1 : g2;
+    c->dim = m->geom_condim[gp];
+    for (int k = 0; k < 3; k++) fr[k] = m->geom_friction[gp][k];
+    memcpy(c->solref, m->geom_solref[gp], sizeof c->solref);
+    memcpy(c->solimp, m->geom_solimp[gp], sizeof c->solimp);
+  } else {
+    c->dim = m->geom_condim[g1] > m->geom_condim[g2] ? m->geom_condim[g1] : m->geom_condim[g2];
+    for (int k = 0; k < 3; k++) fr[k] = fmax(m->geom_friction[g1][k], m->geom_friction[g2][k]);
+    for (int k = 0; k < 2; k++) c->solref[k] = 0.5 * m->geom_solref[g1][k] + 0.5 * m->geom_solref[g2][k];
+    for (int k = 0; k < 5; k++) c->solimp[k] = 0.5 * m->geom_solimp[g1][k] + 0.5 * m->geom_solimp[g2][k];
+  }
   c->friction[0] = c->friction[1] = fr[0]; c->friction[2] = fr[1]; c->friction[3] = c->friction[4] = fr[2];
-  memcpy(c->solref, m->solref, sizeof c->solref);
-  memcpy(c->solimp, m->solimp, sizeof c->solimp);
   c->includemargin = 0.0; /* margin - gap, both default 0 */
   c->exclude = (c->dist >= c->includemargin);
   c->efc_address = -1;
@@ -715,10 +724,37 @@ static void om_make_constraint(const om_model* m, om_data* d) {
   int nv = m->nv;
   d->nefc = d->ne = d->nl = 0;
   double jt1[3][OM_MAXV], jr1[3][OM_MAXV], jt2[3][OM_MAXV], jr2[3][OM_MAXV], J[OM_MAXV];
-  /* equality: weld (mj_instantiateEquality, mjEQ_WELD) */
+  /* equality (mj_instantiateEquality): connect, weld, joint coupling, in the order of definition */
   for (int e = 0; e < m->neq; e++) {
     int b1 = m->eq_body1[e], b2 = m->eq_body2[e];
     const double* data = m->eq_data[e];
+    if (m->eq_type[e] == OM_EQ_CONNECT) {
+      /* mjEQ_CONNECT: the anchor (data[0:3] in body1, data[3:6] in body2: the same world point at qpos0) must coincide: 3 rows */
+      double p1[3], p2[3], tmp[3];
+      mulMatVec3(tmp, d->xmat[b1], data);
+      for (int k = 0; k < 3; k++) p1[k] = d->xpos[b1][k] + tmp[k];
+      mulMatVec3(tmp, d->xmat[b2], data + 3);
+      for (int k = 0; k < 3; k++) p2[k] = d->xpos[b2][k] + tmp[k];
+      om_jac(m, d, b1, p1, jt1, jr1);
+      om_jac(m, d, b2, p2, jt2, jr2);
+      for (int k = 0; k < 3; k++) {
+        for (int i = 0; i < nv; i++) J[i] = jt1[k][i] - jt2[k][i];
+        add_row(d, nv, J, p1[k] - p2[k], 0, OM_CNSTR_EQUALITY, e);
+      }
+      continue;
+    }
+    if (m->eq_type[e] == OM_EQ_JOINT) {
+      /* mjEQ_JOINT: q1 - q1_0 = polycoef(q2 - q2_0), one row; eq_body1/2 hold the JOINT ids */
+      const int q1a = m->jnt_qposadr[b1], q2a = m->jnt_qposadr[b2];
+      const double x1 = d->qpos[q1a] - m->qpos0[q1a], x2 = d->qpos[q2a] - m->qpos0[q2a];
+      const double poly = data[0] + x2 * (data[1] + x2 * (data[2] + x2 * (data[3] + x2 * data[4])));
+      const double deriv = data[1] + x2 * (2 * data[2] + x2 * (3 * data[3] + x2 * 4 * data[4]));
+      memset(J, 0, sizeof(double) * nv);
+      J[m->jnt_dofadr[b1]] = 1;
+      J[m->jnt_dofadr[b2]] = -deriv;
+      add_row(d, nv, J, x1 - poly, 0, OM_CNSTR_EQUALITY, e);
+      continue;
+    }
     double pos0[3], pos1[3], tmp[3], cpos[6];
     mulMatVec3(tmp, d->xmat[b1], data + 3);
     for (int k = 0; k < 3; k++) pos0[k] = d->xpos[b1][k] + tmp[k];
@@ -788,6 +824,11 @@ static void om_make_constraint(const om_model* m, om_data* d) {
     con->efc_address = d->nefc;
     if (con->dim == 1) {
       add_row(d, nv, Jc[0], con->dist, con->includemargin, OM_CNSTR_CONTACT_FRICTIONLESS, c);
+    } else if (m->cone == OM_CONE_ELLIPTIC) {
+      /* elliptic cone: the contact frame's own rows - normal, then tangents (torsion, rolling for condim 4, 6); only the normal
+       * row carries the distance and the margin */
+      add_row(d, nv, Jc[0], con->dist, con->includemargin, OM_CNSTR_CONTACT_ELLIPTIC, c);
+      for (int k = 1; k < con->dim; k++) add_row(d, nv, Jc[k], 0, 0, OM_CNSTR_CONTACT_ELLIPTIC, c);
     } else {
       for (int k = 1; k < con->dim; k++) {
         /* Jc row order: normal, tangent1, tangent2, torsion(=rot normal), roll1, roll2 */
@@ -827,7 +868,14 @@ static void om_make_impedance(const om_model* m, om_data* d) {
   /* diagApprox from body/dof inverse weights at qpos0 */
   for (int i = 0; i < d->nefc; i++) {
     int id = d->efc_id[i];
-    if (d->efc_type[i] == OM_CNSTR_EQUALITY) {
+    if (d->efc_type[i] == OM_CNSTR_EQUALITY && m->eq_type[id] == OM_EQ_JOINT) {
+      d->efc_diagApprox[i] = m->dof_invweight0[m->jnt_dofadr[m->eq_body1[id]]] + m->dof_invweight0[m->jnt_dofadr[m->eq_body2[id]]];
+    } else if (d->efc_type[i] == OM_CNSTR_EQUALITY && m->eq_type[id] == OM_EQ_CONNECT) {
+      int b1 = m->eq_body1[id], b2 = m->eq_body2[id];
+      double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
+      for (int k = 0; k < 3; k++) d->efc_diagApprox[i + k] = tran;
+      i += 2;
+    } else if (d->efc_type[i] == OM_CNSTR_EQUALITY) {
       int b1 = m->eq_body1[id], b2 = m->eq_body2[id];
       double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
       double rot = m->body_invweight0[b1][1] + m->body_invweight0[b2][1];
@@ -841,7 +889,11 @@ static void om_make_impedance(const om_model* m, om_data* d) {
       double tran = m->body_invweight0[b1][0] + m->body_invweight0[b2][0];
       double rot = m->body_invweight0[b1][1] + m->body_invweight0[b2][1];
       if (d->efc_type[i] == OM_CNSTR_CONTACT_FRICTIONLESS) d->efc_diagApprox[i] = tran;
-      else {
+      else if (d->efc_type[i] == OM_CNSTR_CONTACT_ELLIPTIC) {
+        /* only the normal row's value survives: the friction rows' R is derived from the normal row's below */
+        for (int j = 0; j < con->dim; j++) d->efc_diagApprox[i + j] = j < 3 ? tran : rot;
+        i += con->dim - 1;
+      } else {
         int nrow = 2 * (con->dim - 1);
         for (int j = 0; j < nrow; j++) {
           double fri = con->friction[j / 2];
@@ -859,9 +911,21 @@ static void om_make_impedance(const om_model* m, om_data* d) {
     if (d->efc_type[i] == OM_CNSTR_EQUALITY) {
       memcpy(solref, m->eq_solref[id], sizeof solref);
       memcpy(solimp, m->eq_solimp[id], sizeof solimp);
-      dim = 6; pos = 0;
-      for (int k = 0; k < 6; k++) pos += d->efc_pos[i + k] * d->efc_pos[i + k];
-      pos = sqrt(pos); /* getposdim: weld uses the norm of the 6-vector residual */
+      dim = m->eq_type[id] == OM_EQ_WELD ? 6 : m->eq_type[id] == OM_EQ_CONNECT ? 3 : 1;
+      if (dim > 1) { /* getposdim: weld / connect use the norm of the 6- / 3-vector residual */
+        pos = 0;
+        for (int k = 0; k < dim; k++) pos += d->efc_pos[i + k] * d->efc_pos[i + k];
+        pos = sqrt(pos);
+      }
+    } else if (d->efc_type[i] == OM_CNSTR_LIMIT_JOINT) {
+      memcpy(solref, m->jnt_solref[id], sizeof solref);
+      memcpy(solimp, m->jnt_solimp[id], sizeof solimp);
+    } else if (d->efc_type[i] == OM_CNSTR_CONTACT_ELLIPTIC) {
+      const om_contact* con = &d->contact[id];
+      memcpy(solref, con->solref, sizeof solref);
+      memcpy(solimp, con->solimp, sizeof solimp);
+      dim = con->dim;
+      pos = fabs(d->efc_pos[i]); /* norm of (dist, 0, ..): the impedance is even in pos - margin */
     } else if (d->efc_type[i] == OM_CNSTR_CONTACT_PYRAMIDAL) {
       const om_contact* con = &d->contact[id];
       memcpy(solref, con->solref, sizeof solref);
@@ -889,6 +953,14 @@ static void om_make_impedance(const om_model* m, om_data* d) {
       con->mu = con->friction[0] * sqrt(1 / m->impratio);
       double Rpy = 2 * con->mu * con->mu * d->efc_R[i];
       for (int j = 0; j < dim; j++) d->efc_R[i + j] = Rpy;
+    }
+    if (d->efc_type[i] == OM_CNSTR_CONTACT_ELLIPTIC) {
+      /* friction rows: R_tangent = R_normal / impratio, the other friction dimensions scaled so that the cone keeps its shape
+       * (R_j = R_tangent mu_1^2 / mu_j^2); the cone's slope in the solver's variables becomes mu = mu_1 sqrt(R_tangent / R_normal) */
+      om_contact* con = &d->contact[id];
+      d->efc_R[i + 1] = d->efc_R[i] / fmax(MJS_MINVAL, m->impratio);
+      for (int j = 2; j < dim; j++) d->efc_R[i + j] = d->efc_R[i + 1] * con->friction[0] * con->friction[0] / (con->friction[j - 1] * con->friction[j - 1]);
+      con->mu = con->friction[0] * sqrt(d->efc_R[i + 1] / d->efc_R[i]);
     }
     for (int j = 0; j < dim; j++) d->efc_D[i + j] = 1 / d->efc_R[i + j];
     i += dim;
@@ -955,6 +1027,10 @@ static void om_rne_bias(const om_model* m, om_data* d) {
  * here: damper force + gravity compensation (mj_gravcomp) */
 static void om_passive(const om_model* m, om_data* d) {
   for (int i = 0; i < m->nv; i++) d->qfrc_passive[i] = -m->dof_damping[i] * d->qvel[i];
+  /* joint springs (hinge / slide): -stiffness (q - springref) */
+  for (int j = 0; j < m->njnt; j++)
+    if (m->jnt_stiffness[j] != 0 && (m->jnt_type[j] == OM_JNT_HINGE || m->jnt_type[j] == OM_JNT_SLIDE))
+      d->qfrc_passive[m->jnt_dofadr[j]] -= m->jnt_stiffness[j] * (d->qpos[m->jnt_qposadr[j]] - m->qpos_spring[m->jnt_qposadr[j]]);
   for (int b = 1; b < m->nbody; b++) {
     if (m->body_gravcomp[b] == 0) continue;
     double F[3], jt[3][OM_MAXV], jr[3][OM_MAXV];
@@ -971,11 +1047,20 @@ static void om_actuation(const om_model* m, om_data* d) {
     int j = m->act_jnt[u];
     double ctrl = d->ctrl[u];
     if (m->act_ctrllimited[u]) ctrl = fmin(fmax(ctrl, m->act_ctrlrange[u][0]), m->act_ctrlrange[u][1]);
-    double len = d->qpos[m->jnt_qposadr[j]], vel = d->qvel[m->jnt_dofadr[j]];
+    double len, vel;
+    if (m->act_trntype[u] == OM_TRN_TENDON) {
+      /* fixed tendon (mj_tendon + mj_transmission): length = sum coef q, the moment arm is the coefficient vector */
+      len = 0; vel = 0;
+      for (int k = 0; k < m->nv; k++)
+        if (m->tendon_coef[j][k] != 0) { len += m->tendon_coef[j][k] * d->qpos[m->jnt_qposadr[m->dof_jnt[k]]]; vel += m->tendon_coef[j][k] * d->qvel[k]; }
+    } else { len = d->qpos[m->jnt_qposadr[j]]; vel = d->qvel[m->jnt_dofadr[j]]; }
     double f = m->act_gain[u] * ctrl + m->act_bias[u][0] + m->act_bias[u][1] * len + m->act_bias[u][2] * vel;
     if (m->act_forcelimited[u]) f = fmin(fmax(f, m->act_forcerange[u][0]), m->act_forcerange[u][1]);
     d->actuator_force[u] = f;
-    d->qfrc_actuator[m->jnt_dofadr[j]] += f;
+    if (m->act_trntype[u] == OM_TRN_TENDON) {
+      for (int k = 0; k < m->nv; k++) d->qfrc_actuator[k] += m->tendon_coef[j][k] * f;
+    } else
+      d->qfrc_actuator[m->jnt_dofadr[j]] += f;
   }
 }
 
@@ -984,9 +1069,41 @@ typedef struct {
   double cost, gauss;
 } cstate;
 
+/* elliptic cone of one contact in the solver's variables (PrimalUpdateConstraint): with z = jar of the contact's rows,
+ * U = (mu z_0, f_1 z_1, .., f_{dim-1} z_{dim-1}), N = U_0, T = |U_1..|, the row weights D_j = D_0 f_j^2 / mu^2 make the quadratic
+ * cost isotropic in U (weight D_0 / mu^2). Zones: top N >= mu T (no force), bottom mu N + T <= 0 (all rows quadratic), middle:
+ * squared distance to the cone N = mu T, cost = Dm (N - mu T)^2 / 2 with Dm = D_0 / (mu^2 (1 + mu^2)). */
+typedef struct { double N, T, mu, Dm, U[6]; int zone; } cone_state;
+static void cone_eval(const om_contact* con, const double* z, double D0, cone_state* c) {
+  c->mu = con->mu;
+  c->U[0] = z[0] * con->mu;
+  double tt = 0;
+  for (int j = 1; j < con->dim; j++) { c->U[j] = z[j] * con->friction[j - 1]; tt += c->U[j] * c->U[j]; }
+  c->N = c->U[0]; c->T = sqrt(tt);
+  c->Dm = D0 / (con->mu * con->mu * (1 + con->mu * con->mu));
+  c->zone = (c->N >= con->mu * c->T) ? 0 : (con->mu * c->N + c->T <= 0) ? 2 : 1;
+}
+
 static double constraint_update(const om_model* m, om_data* d, const double* jar, const double* qacc, const double* Ma, int* active, double* force) {
   double cost = 0;
   for (int i = 0; i < d->nefc; i++) {
+    if (d->efc_type[i] == OM_CNSTR_CONTACT_ELLIPTIC) {
+      om_contact* con = &d->contact[d->efc_id[i]];
+      cone_state c;
+      cone_eval(con, jar + i, d->efc_D[i], &c);
+      con->zone = c.zone;
+      for (int j = 0; j < con->dim; j++) { active[i + j] = (c.zone == 2); force[i + j] = 0; }
+      if (c.zone == 2) {
+        for (int j = 0; j < con->dim; j++) { force[i + j] = -d->efc_D[i + j] * jar[i + j]; cost += 0.5 * d->efc_D[i + j] * jar[i + j] * jar[i + j]; }
+      } else if (c.zone == 1) {
+        const double NT = c.N - c.mu * c.T;
+        cost += 0.5 * c.Dm * NT * NT;
+        force[i] = -c.Dm * NT * c.mu;
+        for (int j = 1; j < con->dim; j++) force[i + j] = -force[i] / c.T * c.U[j] * con->friction[j - 1];
+      }
+      i += con->dim - 1;
+      continue;
+    }
     int act = (d->efc_type[i] == OM_CNSTR_EQUALITY) ? 1 : (jar[i] < 0);
     active[i] = act;
     force[i] = act ? -d->efc_D[i] * jar[i] : 0;
@@ -1013,6 +1130,32 @@ static double line_search(const om_model* m, const om_data* d, const double* jar
     if (it + 1 > om_dbg_ls_max) om_dbg_ls_max = it + 1;
     double d1 = g1 + alpha * g2, d2 = g2;
     for (int i = 0; i < d->nefc; i++) {
+      if (d->efc_type[i] == OM_CNSTR_CONTACT_ELLIPTIC) {
+        /* the cone's cost along the ray (PrimalEval): N(alpha) linear, T(alpha)^2 quadratic in alpha */
+        const om_contact* con = &d->contact[d->efc_id[i]];
+        const int dim = con->dim;
+        const double mu = con->mu, U0 = jar[i] * mu, V0 = jv[i] * mu;
+        double UU = 0, UV = 0, VV = 0;
+        for (int j = 1; j < dim; j++) {
+          const double u = jar[i + j] * con->friction[j - 1], v = jv[i + j] * con->friction[j - 1];
+          UU += u * u; UV += u * v; VV += v * v;
+        }
+        const double N = U0 + alpha * V0, Tsq = UU + alpha * (2 * UV + alpha * VV), T = Tsq > 0 ? sqrt(Tsq) : 0;
+        if (N >= mu * T) { /* top zone: nothing */
+        } else if (mu * N + T <= 0) { /* bottom zone: every row quadratic */
+          for (int j = 0; j < dim; j++) {
+            const double x = jar[i + j] + alpha * jv[i + j];
+            d1 += d->efc_D[i + j] * x * jv[i + j]; d2 += d->efc_D[i + j] * jv[i + j] * jv[i + j];
+          }
+        } else { /* middle zone */
+          const double Dm = d->efc_D[i] / (mu * mu * (1 + mu * mu));
+          const double N1 = V0, T1 = (UV + alpha * VV) / T, T2 = VV / T - (UV + alpha * VV) * (UV + alpha * VV) / (T * T * T);
+          const double NT = N - mu * T, NT1 = N1 - mu * T1;
+          d1 += Dm * NT * NT1; d2 += Dm * (NT1 * NT1 - NT * mu * T2);
+        }
+        i += dim - 1;
+        continue;
+      }
       double x = jar[i] + alpha * jv[i];
       if (d->efc_type[i] == OM_CNSTR_EQUALITY || x < 0) { d1 += d->efc_D[i] * x * jv[i]; d2 += d->efc_D[i] * jv[i] * jv[i]; }
     }
@@ -1068,6 +1211,40 @@ static void om_solve_constraint(const om_model* m, om_data* d) {
           if (active[r]) h += d->efc_J[r][i] * d->efc_D[r] * d->efc_J[r][j];
         H[i][j] = H[j][i] = h;
       }
+    /* contacts on the cone surface (middle zone): H += Jc^T Hc Jc with the dim x dim Hessian of Dm (N - mu T)^2 / 2 in the
+     * contact's own rows (the role of HessianCone): with v = (mu, -mu f_j t_j / T), t_j = f_j z_j,
+     * Hc = Dm [ v v^T - mu (N - mu T) (diag(0, f_j^2) / T - (0, f_j t_j)(0, f_k t_k)^T / T^3) ] */
+    for (int r = 0; r < nefc; r++) {
+      if (d->efc_type[r] != OM_CNSTR_CONTACT_ELLIPTIC) continue;
+      const om_contact* con = &d->contact[d->efc_id[r]];
+      const int dim = con->dim;
+      if (con->zone == 1) {
+        cone_state c;
+        cone_eval(con, jar + r, d->efc_D[r], &c);
+        double v[6], w[6], Hc[6][6];
+        const double NT = c.N - c.mu * c.T;
+        v[0] = c.mu; w[0] = 0;
+        for (int j = 1; j < dim; j++) { w[j] = con->friction[j - 1] * c.U[j]; v[j] = -c.mu * w[j] / c.T; }
+        for (int a = 0; a < dim; a++)
+          for (int b = 0; b < dim; b++) {
+            double curv = -w[a] * w[b] / (c.T * c.T * c.T);
+            if (a == b && a > 0) curv += con->friction[a - 1] * con->friction[a - 1] / c.T;
+            Hc[a][b] = c.Dm * (v[a] * v[b] - c.mu * NT * curv);
+          }
+        for (int i = 0; i < nv; i++)
+          for (int j = 0; j <= i; j++) {
+            double h = 0;
+            for (int a = 0; a < dim; a++) {
+              double t = 0;
+              for (int b = 0; b < dim; b++) t += Hc[a][b] * d->efc_J[r + b][j];
+              h += d->efc_J[r + a][i] * t;
+            }
+            H[i][j] += h;
+            if (i != j) H[j][i] += h;
+          }
+      }
+      r += dim - 1;
+    }
     if (!chol_factor(nv, H, Lh)) break;
     for (int i = 0; i < nv; i++) search[i] = -grad[i];
     chol_solve(nv, Lh, search);
@@ -1174,9 +1351,9 @@ static void om_sensor_touch(const om_model* m, om_data* d) {
     for (int k = 0; k < 3; k++) rel[k] = con->pos[k] - d->site_xpos[s][k];
     for (int k = 0; k < 3; k++) loc[k] = d->site_xmat[s][k] * rel[0] + d->site_xmat[s][3 + k] * rel[1] + d->site_xmat[s][6 + k] * rel[2];
     if (loc[0] * loc[0] + loc[1] * loc[1] > m->touch_size[0] * m->touch_size[0] || fabs(loc[2]) > m->touch_size[1]) continue;
-    int nrow = con->dim == 1 ? 1 : 2 * (con->dim - 1);
+    int nrow = (con->dim == 1 || m->cone == OM_CONE_ELLIPTIC) ? 1 : 2 * (con->dim - 1);
     double fn = 0;
-    for (int r = 0; r < nrow; r++) fn += d->efc_force[con->efc_address + r]; /* pyramid: normal = sum of edges */
+    for (int r = 0; r < nrow; r++) fn += d->efc_force[con->efc_address + r]; /* pyramid: normal = sum of edges; elliptic: the normal row */
     d->touch_force += fn;
   }
 }
@@ -1201,6 +1378,14 @@ void om_step2(const om_model* m, om_data* d) {
     }
     for (int u = 0; u < m->nu; u++) {
       if (m->act_forcelimited[u] && (d->actuator_force[u] <= m->act_forcerange[u][0] || d->actuator_force[u] >= m->act_forcerange[u][1])) continue;
+      if (m->act_trntype[u] == OM_TRN_TENDON) { /* d qfrc / d qvel = moment^T bias_vel moment */
+        const double* co = m->tendon_coef[m->act_jnt[u]];
+        for (int a = 0; a < nv; a++)
+          if (co[a] != 0)
+            for (int b = 0; b < nv; b++)
+              if (co[b] != 0) A[a][b] -= m->dt * m->act_bias[u][2] * co[a] * co[b];
+        continue;
+      }
       int da = m->jnt_dofadr[m->act_jnt[u]];
       A[da][da] -= m->dt * m->act_bias[u][2];
     }
@@ -1263,6 +1448,15 @@ void om_set_const(om_model* m) {
     /* weld relpose from qpos0 when not specified (quat all zero): done by the scene builder */
   }
   om_kinematics(m, &d);
+  /* connect: the anchor is given in body1 (data[0:3]); the compiler stores the same world point at qpos0 in body2's frame (data[3:6]) */
+  for (int e = 0; e < m->neq; e++)
+    if (m->eq_type[e] == OM_EQ_CONNECT) {
+      const int b1 = m->eq_body1[e], b2 = m->eq_body2[e];
+      double p[3], tmp[3];
+      mulMatVec3(tmp, d.xmat[b1], m->eq_data[e]);
+      for (int k = 0; k < 3; k++) p[k] = d.xpos[b1][k] + tmp[k] - d.xpos[b2][k];
+      for (int k = 0; k < 3; k++) m->eq_data[e][3 + k] = d.xmat[b2][k] * p[0] + d.xmat[b2][3 + k] * p[1] + d.xmat[b2][6 + k] * p[2];
+    }
   om_subspaces(m, &d);
   om_crb(m, &d);
   int nv = m->nv;

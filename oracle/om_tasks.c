@@ -78,6 +78,8 @@ static int add_joint(om_model* m, int body, int type, const double* axis, int li
   m->jnt_qposadr[j] = m->nq; m->jnt_dofadr[j] = m->nv;
   if (axis) memcpy(m->jnt_axis[j], axis, sizeof(double) * 3);
   m->jnt_limited[j] = limited; m->jnt_range[j][0] = lo; m->jnt_range[j][1] = hi;
+  memcpy(m->jnt_solref[j], m->solref, sizeof m->solref); /* solreflimit / solimplimit default to the global defaults */
+  memcpy(m->jnt_solimp[j], m->solimp, sizeof m->solimp);
   int nd = type == OM_JNT_FREE ? 6 : 1, nqj = type == OM_JNT_FREE ? 7 : 1;
   for (int k = 0; k < nd; k++) {
     int dof = m->nv + k;
@@ -104,6 +106,8 @@ static int add_geom(om_model* m, int body, int type, const double* pos, const do
   m->geom_size[g][0] = s0; m->geom_size[g][1] = s1; m->geom_size[g][2] = s2;
   m->geom_contype[g] = 1; m->geom_conaffinity[g] = 1; m->geom_condim[g] = 3;
   m->geom_friction[g][0] = MJS_GEOM_FRICTION_SLIDE; m->geom_friction[g][1] = MJS_GEOM_FRICTION_SPIN; m->geom_friction[g][2] = MJS_GEOM_FRICTION_ROLL;
+  memcpy(m->geom_solref[g], m->solref, sizeof m->solref);
+  memcpy(m->geom_solimp[g], m->solimp, sizeof m->solimp);
   return g;
 }
 
@@ -136,6 +140,7 @@ static void build_pointmass(om_model* m) {
   add_geom(m, pm, OM_GEOM_SPHERE, zero3, ident, MJS_PM_RADIUS, 0, 0);
   /* weld mocap <-> pointmass (point_reach.py:84-89); relpose from qpos0 */
   m->neq = 1;
+  m->eq_type[0] = OM_EQ_WELD;
   m->eq_body1[0] = mocap; m->eq_body2[0] = pm;
   double* data = m->eq_data[0];
   memset(data, 0, sizeof(double) * 11);
@@ -228,6 +233,7 @@ static void gripper_integrate(om_env* e) {
 }
 /* one Physics.step() of the Button-Push scene: mj_step2 (arm + gripper), finger tips re-placed, mj_step1 */
 static void button_physics_step(om_env* e) {
+  if (e->cfg.gripper_model == OM_GRIPPER_ARTICULATED) { om_physics_step(&e->m, &e->d); return; } /* the fingers are part of the model */
   om_step2(&e->m, &e->d);
   gripper_integrate(e);
   gripper_place_tips(e);
@@ -237,14 +243,87 @@ static void button_physics_step(om_env* e) {
 /* Button-Push scene (robot_push_button.py:66-108): UR5e + lumped gripper (+ the reduced 2F-85's two finger-tip
  * spheres) + wrist-camera geoms' mass + static switch (box, button cylinder, touch
  * site). The switch body position is a MODEL field rewritten at every reset (Entity.set_pose). */
-static void build_button(om_model* m) {
-  build_robot(m, 1);
+/* The articulated Robotiq 2F-85 on the flange (gripper.py:36-98 loads the menagerie MJCF; robot.py:84-107 attaches it; SURVEY 8
+ * f-1): 12 bodies / 8 hinges from include/mjs_scene_spec.h (MJS_G85_*), the two `connect` equalities that close the finger
+ * linkages, the `joint` equality that couples the drivers, the fixed tendon "split" with `fingers_actuator` on it, the pad
+ * boxes, and the MJCF's <option cone="elliptic" impratio="10"/>, which dm_control's attach merges into the scene's options.
+ * Returns the index of the first gripper joint. */
+static int add_articulated_gripper(om_model* m, int wrist3) {
+  const double ident[4] = {1, 0, 0, 0};
+  int frame = add_body(m, wrist3, MJS_UR_FLANGE_POS, MJS_UR_FLANGE_QUAT, 0, NULL, NULL, NULL, 0.0);
+  int body[MJS_G85_NBODY], jnt0 = m->njnt;
+  for (int b = 0; b < MJS_G85_NBODY; b++) {
+    int parent = MJS_G85_PARENT[b] < 0 ? frame : body[MJS_G85_PARENT[b]];
+    body[b] = add_body(m, parent, MJS_G85_POS[b], MJS_G85_QUAT[b], MJS_G85_MASS[b], MJS_G85_IPOS[b], MJS_G85_IQUAT[b], MJS_G85_DIAGINERTIA[b], 0.0);
+    int c = MJS_G85_JCLASS[b];
+    if (c < 0) continue;
+    const double ax[3] = {1, 0, 0};
+    int j = add_joint(m, body[b], OM_JNT_HINGE, ax, 1, MJS_G85_JRANGE[c][0], MJS_G85_JRANGE[c][1], MJS_G85_JARMATURE[c]);
+    memcpy(m->jnt_pos[j], MJS_G85_JPOS[c], sizeof(double) * 3);
+    m->dof_damping[m->jnt_dofadr[j]] = MJS_G85_JDAMPING[c];
+    m->jnt_stiffness[j] = MJS_G85_JSTIFFNESS[c];
+    m->qpos_spring[m->jnt_qposadr[j]] = MJS_G85_JSPRINGREF[c];
+    if (MJS_G85_JSTIFFLIMIT[c]) {
+      memcpy(m->jnt_solref[j], MJS_G85_SOLREF, sizeof MJS_G85_SOLREF);
+      memcpy(m->jnt_solimp[j], MJS_G85_SOLIMP, sizeof MJS_G85_SOLIMP);
+    }
+  }
+  /* pad boxes: right pad first (MJCF order), box1 then box2 */
+  const int pads[2] = {body[MJS_G85_B_RIGHT_PAD], body[MJS_G85_B_LEFT_PAD]};
+  for (int s = 0; s < 2; s++)
+    for (int k = 0; k < 2; k++) {
+      int g = add_geom(m, pads[s], OM_GEOM_BOX, MJS_G85_PAD_POS[k], ident, MJS_G85_PAD_SIZE[0], MJS_G85_PAD_SIZE[1], MJS_G85_PAD_SIZE[2]);
+      m->geom_priority[g] = 1;
+      m->geom_friction[g][0] = MJS_G85_PAD_FRICTION[k];
+      memcpy(m->geom_solref[g], MJS_G85_PAD_SOLREF, sizeof MJS_G85_PAD_SOLREF);
+      memcpy(m->geom_solimp[g], MJS_G85_PAD_SOLIMP, sizeof MJS_G85_PAD_SOLIMP);
+    }
+  /* equality: connect(right follower, right coupler), connect(left follower, left coupler), anchor = the follower's origin;
+   * joint(right driver = left driver, polycoef 0 1 0 0 0) */
+  const int fol[2] = {body[MJS_G85_B_RIGHT_FOLLOWER], body[MJS_G85_B_LEFT_FOLLOWER]}, cou[2] = {body[MJS_G85_B_RIGHT_COUPLER], body[MJS_G85_B_LEFT_COUPLER]};
+  for (int s = 0; s < 2; s++) {
+    int e = m->neq++;
+    m->eq_type[e] = OM_EQ_CONNECT; m->eq_body1[e] = fol[s]; m->eq_body2[e] = cou[s];
+    memset(m->eq_data[e], 0, sizeof m->eq_data[e]); /* anchor 0 0 0 in body1; body2's anchor from qpos0 (om_set_const) */
+    memcpy(m->eq_solref[e], MJS_G85_SOLREF, sizeof MJS_G85_SOLREF);
+    memcpy(m->eq_solimp[e], MJS_G85_SOLIMP, sizeof MJS_G85_SOLIMP);
+  }
+  {
+    int e = m->neq++;
+    m->eq_type[e] = OM_EQ_JOINT; m->eq_body1[e] = jnt0 + MJS_G85_J_RIGHT_DRIVER; m->eq_body2[e] = jnt0 + MJS_G85_J_LEFT_DRIVER;
+    memset(m->eq_data[e], 0, sizeof m->eq_data[e]);
+    m->eq_data[e][1] = 1;
+    memcpy(m->eq_solref[e], MJS_G85_SOLREF, sizeof MJS_G85_SOLREF);
+    memcpy(m->eq_solimp[e], MJS_G85_SOLIMP, sizeof MJS_G85_SOLIMP);
+  }
+  /* tendon "split" + fingers_actuator (general, gaintype fixed, biastype affine) */
+  m->ntendon = 1;
+  memset(m->tendon_coef[0], 0, sizeof m->tendon_coef[0]);
+  m->tendon_coef[0][m->jnt_dofadr[jnt0 + MJS_G85_J_RIGHT_DRIVER]] = MJS_G85_TENDON_COEF;
+  m->tendon_coef[0][m->jnt_dofadr[jnt0 + MJS_G85_J_LEFT_DRIVER]] = MJS_G85_TENDON_COEF;
+  int u = m->nu++;
+  m->act_trntype[u] = OM_TRN_TENDON; m->act_jnt[u] = 0;
+  m->act_gain[u] = MJS_G2F85_ACT_GAIN;
+  m->act_bias[u][0] = 0; m->act_bias[u][1] = -MJS_G2F85_ACT_KP; m->act_bias[u][2] = -MJS_G2F85_ACT_KV;
+  m->act_ctrllimited[u] = 1; m->act_forcelimited[u] = 1;
+  m->act_ctrlrange[u][0] = 0; m->act_ctrlrange[u][1] = MJS_G2F85_CTRL_MAX;
+  m->act_forcerange[u][0] = -MJS_G2F85_ACT_FORCE; m->act_forcerange[u][1] = MJS_G2F85_ACT_FORCE;
+  m->cone = OM_CONE_ELLIPTIC;
+  m->impratio = MJS_G85_IMPRATIO;
+  return jnt0;
+}
+
+static void build_button(om_model* m, int gripper_model) {
+  build_robot(m, gripper_model == OM_GRIPPER_ARTICULATED ? 0 : 1);
   const double zero3[3] = {0, 0, 0}, ident[4] = {1, 0, 0, 0};
-  int payload = m->nbody - 1, wrist3 = m->body_parent[payload];
+  int payload = m->nbody - 1, wrist3 = gripper_model == OM_GRIPPER_ARTICULATED ? payload : m->body_parent[payload];
+  if (gripper_model == OM_GRIPPER_ARTICULATED) add_articulated_gripper(m, wrist3);
+  else {
   /* finger-tip spheres on the gripper body (tips at the TCP plane), placed from the driver angle by gripper_place_tips */
   const double ppos[3] = {0, 0, MJS_G2F85_TCP_Z - MJS_G2F85_PROXY_RADIUS};
   m->gr_geom[0] = add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
   m->gr_geom[1] = add_geom(m, payload, OM_GEOM_SPHERE, ppos, ident, MJS_G2F85_PROXY_RADIUS, 0, 0);
+  }
   /* wrist camera body: box + sphere of default density, concentric at MJS_WCAM_POS (mass only) */
   double bx = MJS_CAM_BOX_HALF[0], by = MJS_CAM_BOX_HALF[1], bz = MJS_CAM_BOX_HALF[2], rs = MJS_CAM_SPHERE_RADIUS;
   double mb = MJS_GEOM_DENSITY * 8 * bx * by * bz, ms = MJS_GEOM_DENSITY * 4.0 / 3.0 * 3.14159265358979323846 * rs * rs * rs;
@@ -353,7 +432,7 @@ void om_env_init(om_env* e, const om_task_config* cfg, uint32_t seed) {
   memset(e, 0, sizeof *e);
   e->cfg = *cfg;
   if (cfg->task == OM_TASK_POINTMASS) { build_pointmass(&e->m); e->n_sub = (int)round(MJS_PM_CONTROL_DT / MJS_PM_PHYSICS_DT); }
-  else if (cfg->task == OM_TASK_BUTTON_PUSH) { build_button(&e->m); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
+  else if (cfg->task == OM_TASK_BUTTON_PUSH) { build_button(&e->m, cfg->gripper_model); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   else if (cfg->task == OM_TASK_PLANAR_PUSH) { build_push(&e->m, cfg->n_objects); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   else { build_robot(&e->m, 1); e->n_sub = (int)round(MJS_RR_CONTROL_DT / MJS_RR_PHYSICS_DT); }
   e->distance_to_target = 1.0;          /* point_reach.py:112-113 */
@@ -477,7 +556,7 @@ static void episode_init(om_env* e) {
     for (int k = 0; k < 3; k++) e->switch_pos[k] = om_rng_uniform(&e->rng, MJS_BP_SWITCH_SPACE_LO[k], MJS_BP_SWITCH_SPACE_HI[k]);
     memcpy(m->body_pos[m->site_body[m->touch_site]], e->switch_pos, sizeof e->switch_pos);
     e->gr_theta = e->gr_vel = e->gr_ctrl = 0; /* mj_resetData: gripper joints at qpos0 (open), ctrl 0 */
-    gripper_place_tips(e);
+    if (e->cfg.gripper_model != OM_GRIPPER_ARTICULATED) gripper_place_tips(e);
     om_forward(m, d);
     /* Switch.initialize_episode (switch.py:62-65) */
     e->switch_num_pressed = 0;
@@ -549,6 +628,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
   } else if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.action_type == OM_ACTION_ABS_JOINT) {
     /* robot_push_button.py:151-157: gripper.move(a[6]) sets the finger actuator's ctrl; servoJ(a[:6]) -> robot.py:227-259 */
     e->gr_ctrl = gripper_ctrl_of_opening(action[6]);
+    if (e->cfg.gripper_model == OM_GRIPPER_ARTICULATED) d->ctrl[6] = e->gr_ctrl; /* physics.bind(self.actuator).ctrl (gripper.py:84) */
     memcpy(e->traj_q0, d->qpos, sizeof e->traj_q0);
     memcpy(e->traj_q1, action, sizeof e->traj_q1);
     e->traj_t0 = d->time;
@@ -557,6 +637,7 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
   } else {
     /* robot_reach.py:159-169 / robot_push_button.py:143-149 -> robot.py:218-259 */
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) e->gr_ctrl = gripper_ctrl_of_opening(action[3]); /* gripper.move(a[3]), :147 */
+    if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.gripper_model == OM_GRIPPER_ARTICULATED) d->ctrl[6] = e->gr_ctrl;
     double q_now[6], q_ik[6];
     memcpy(q_now, d->qpos, sizeof q_now);
     if (!tcp_pose_to_joints(action, MJS_TOP_DOWN_QUAT_XYZW, MJS_G2F85_TCP_Z, q_now, q_ik)) {
@@ -680,7 +761,7 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
   static __thread om_model m;
   static __thread om_data d;
   static __thread int built = 0;
-  if (!built) { build_button(&m); built = 1; }
+  if (!built) { build_button(&m, OM_GRIPPER_REDUCED); built = 1; }
   om_reset_data(&m, &d);
   memcpy(d.qpos, q, sizeof(double) * 6);
   memcpy(d.qvel, v, sizeof(double) * 6);
@@ -699,7 +780,7 @@ void om_debug_button_dynamics(const double* q, const double* v, double* M_out, d
  * (what mj_makeImpedance uses as diagApprox for a contact of one of the arm's collision geoms with the static floor) */
 void om_debug_link_invweights(int task, double* out7) {
   static __thread om_model m;
-  if (task == OM_TASK_BUTTON_PUSH) build_button(&m);
+  if (task == OM_TASK_BUTTON_PUSH) build_button(&m, OM_GRIPPER_REDUCED);
   else if (task == OM_TASK_PLANAR_PUSH) build_push(&m, 2);
   else build_robot(&m, 1);
   for (int k = 0; k < 7; k++) out7[k] = m.body_invweight0[1 + k][0];
@@ -737,12 +818,39 @@ void om_debug_set_state(om_env* e, const double* qpos, const double* qvel) {
   memcpy(e->d.qpos, qpos, sizeof(double) * e->m.nq);
   memcpy(e->d.qvel, qvel, sizeof(double) * e->m.nv);
   memset(e->d.qacc_warmstart, 0, sizeof e->d.qacc_warmstart);
-  for (int j = 0; j < e->m.nu; j++) e->d.ctrl[j] = qpos[j];
+  for (int j = 0; j < e->m.nu && j < 6; j++) e->d.ctrl[j] = qpos[j]; /* the arm's servos hold the given joints; a finger actuator keeps its ctrl */
   e->traj_active = 0;
   e->reset_pending = 0;
   om_forward(&e->m, &e->d);
 }
-void om_debug_get_gripper(const om_env* e, double* theta_vel) { theta_vel[0] = e->gr_theta; theta_vel[1] = e->gr_vel; }
+void om_debug_get_gripper(const om_env* e, double* theta_vel) {
+  if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.gripper_model == OM_GRIPPER_ARTICULATED) { theta_vel[0] = e->d.qpos[6]; theta_vel[1] = e->d.qvel[6]; return; } /* right driver */
+  theta_vel[0] = e->gr_theta; theta_vel[1] = e->gr_vel;
+}
+/* debug hooks for the articulated-gripper tests: model sizes; the constraint rows of the current state (mj_forward's); a geom's
+ * world pose; an actuator's ctrl */
+void om_debug_model_dims(const om_env* e, int* out /*8*/) {
+  out[0] = e->m.nq; out[1] = e->m.nv; out[2] = e->m.nbody; out[3] = e->m.ngeom; out[4] = e->m.neq; out[5] = e->m.nu; out[6] = e->m.njnt; out[7] = e->m.cone;
+}
+int om_debug_efc(const om_env* e, int maxrows, double* pos, double* J /*[maxrows][nv]*/, int* type, double* force, double* aref, double* D) {
+  const int n = e->d.nefc < maxrows ? e->d.nefc : maxrows;
+  for (int r = 0; r < n; r++) {
+    pos[r] = e->d.efc_pos[r]; type[r] = e->d.efc_type[r]; force[r] = e->d.efc_force[r]; aref[r] = e->d.efc_aref[r]; D[r] = e->d.efc_D[r];
+    memcpy(J + (size_t)r * e->m.nv, e->d.efc_J[r], sizeof(double) * e->m.nv);
+  }
+  return e->d.nefc;
+}
+void om_debug_geom_pose(const om_env* e, int g, double* pos3, double* mat9) {
+  memcpy(pos3, e->d.geom_xpos[g], sizeof(double) * 3);
+  memcpy(mat9, e->d.geom_xmat[g], sizeof(double) * 9);
+}
+void om_debug_set_ctrl(om_env* e, int u, double value) { e->d.ctrl[u] = value; }
+void om_debug_get_dynamics(const om_env* e, double* M /*[nv][nv]*/, double* qfrc_smooth, double* qacc) {
+  for (int i = 0; i < e->m.nv; i++) {
+    for (int j = 0; j < e->m.nv; j++) M[(size_t)i * e->m.nv + j] = e->d.M[i][j];
+    qfrc_smooth[i] = e->d.qfrc_smooth[i]; qacc[i] = e->d.qacc[i];
+  }
+}
 void om_debug_set_gripper(om_env* e, double theta, double vel) {
   e->gr_theta = theta; e->gr_vel = vel;
   if (e->cfg.task == OM_TASK_BUTTON_PUSH) { gripper_place_tips(e); om_forward(&e->m, &e->d); }

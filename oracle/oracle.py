@@ -31,6 +31,7 @@ class TaskConfig(C.Structure):
         ("n_objects", C.c_int),
         ("max_episode_steps", C.c_int),
         ("block_shape", C.c_int),
+        ("gripper_model", C.c_int),
     ]
 
 
@@ -189,7 +190,7 @@ class OracleBatch:
                  autoreset: int = AUTORESET_NEXT_STEP, time_limit: float | None = None,
                  terminate_on_success: bool = False, nthreads: int = 1, action_type: int | None = None,
                  button_disturbances: bool = False, n_objects: int | None = None, max_episode_steps: int | None = None,
-                 block_shape: int | None = None):
+                 block_shape: int | None = None, gripper_model: int = 0):
         L = lib()
         cfg = TaskConfig()
         L.om_default_config(task, C.byref(cfg))
@@ -208,6 +209,7 @@ class OracleBatch:
             cfg.max_episode_steps = max_episode_steps
         if block_shape is not None:
             cfg.block_shape = block_shape
+        cfg.gripper_model = int(gripper_model)
         self.cfg, self.task, self.n, self.nthreads = cfg, task, n, nthreads
         L.om_obs_dim_for.argtypes = [C.c_void_p]
         self.obs_dim, self.action_dim = L.om_obs_dim_for(C.byref(cfg)), L.om_action_dim(task)
@@ -295,8 +297,49 @@ class OracleBatch:
         nq = 0
         for i in range(self.n):
             nq = L.om_debug_get_state(L.om_batch_env(self._h, i), qp[i].ctypes.data, qv[i].ctypes.data, tm[i:].ctypes.data)
-        nv = nq - (nq - 6) // 7 if nq > 6 else nq
+        nv = self.model_dims()["nv"]
         return qp[:, :nq].copy(), qv[:, :nv].copy(), tm
+
+    # ---- debug hooks of the articulated-gripper tests
+    def model_dims(self):
+        L = lib()
+        L.om_debug_model_dims.argtypes = [C.c_void_p, C.c_void_p]
+        out = np.zeros(8, np.int32)
+        L.om_debug_model_dims(L.om_batch_env(self._h, 0), out.ctypes.data)
+        return dict(zip(("nq", "nv", "nbody", "ngeom", "neq", "nu", "njnt", "cone"), out.tolist()))
+
+    def efc(self, i: int, maxrows: int = 128):
+        """constraint rows of env i's current state: dict(pos, J [nefc, nv], type, force, aref, D)"""
+        L = lib()
+        L.om_debug_efc.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 6
+        nv = self.model_dims()["nv"]
+        pos, J, typ = np.zeros(maxrows), np.zeros((maxrows, nv)), np.zeros(maxrows, np.int32)
+        force, aref, D = np.zeros(maxrows), np.zeros(maxrows), np.zeros(maxrows)
+        n = L.om_debug_efc(L.om_batch_env(self._h, i), maxrows, pos.ctypes.data, J.ctypes.data, typ.ctypes.data, force.ctypes.data, aref.ctypes.data, D.ctypes.data)
+        n = min(n, maxrows)
+        return {"pos": pos[:n], "J": J[:n], "type": typ[:n], "force": force[:n], "aref": aref[:n], "D": D[:n]}
+
+    def geom_pose(self, i: int, g: int):
+        L = lib()
+        L.om_debug_geom_pose.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        pos, mat = np.zeros(3), np.zeros(9)
+        L.om_debug_geom_pose(L.om_batch_env(self._h, i), g, pos.ctypes.data, mat.ctypes.data)
+        return pos, mat.reshape(3, 3)
+
+    def set_ctrl(self, u: int, values):
+        L = lib()
+        L.om_debug_set_ctrl.argtypes = [C.c_void_p, C.c_int, C.c_double]
+        v = np.broadcast_to(np.asarray(values, dtype=np.float64), (self.n,))
+        for i in range(self.n):
+            L.om_debug_set_ctrl(L.om_batch_env(self._h, i), u, float(v[i]))
+
+    def dynamics(self, i: int):
+        L = lib()
+        L.om_debug_get_dynamics.argtypes = [C.c_void_p] * 4
+        nv = self.model_dims()["nv"]
+        M, f, a = np.zeros((nv, nv)), np.zeros(nv), np.zeros(nv)
+        L.om_debug_get_dynamics(L.om_batch_env(self._h, i), M.ctypes.data, f.ctypes.data, a.ctypes.data)
+        return M, f, a
 
     def get_gripper(self):
         """Button-Push: (driver angle, driver velocity) of the reduced 2F-85 per env, [N, 2]."""

@@ -608,6 +608,105 @@ def test_robot_reach_episodes_ending_at_different_times(oracle_mod, autoreset, k
     venv.close()
 
 
+def _seek_actions(rs, obs, N):
+    a = rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (N, 3))
+    seek = np.arange(N) % 4 != 0
+    a[seek] = obs[seek, 9:12] + rs.normal(0, 0.002, (int(seek.sum()), 3))
+    return a
+
+
+def test_reset_groups_beyond_the_resident_grid_matches_the_default_kernel():
+    """MJS_VARIANT_RESET_GROUPS at 16384 envs: 2 x 256 workgroups of three wavefronts do not fit the chip at once, so
+    the reset workgroups (the grid's second half) start only as stepping workgroups retire. A new "reset pending" therefore carries
+    the launch's parity and is acted on by the NEXT launch's reset workgroups only; before that fix a late reset workgroup reset
+    an env in the launch that ended its episode (LAST outputs overwritten by FIRST ones, one launch early). Variant 3 against
+    variant 0 (a workgroup resets its own envs), every output bitwise, 100 steps of success-terminated episodes."""
+    import mujoco_sim_amd as m
+
+    N, T = 16384, 100
+    a_env = m.HipVectorEnv("robot_reach", N, seed=31, terminate_on_success=True, kernel_variant=0)
+    b_env = m.HipVectorEnv("robot_reach", N, seed=31, terminate_on_success=True, kernel_variant=3)
+    a_env.reset()
+    b_env.reset()
+    rs = np.random.RandomState(4)
+    obs = _gpu_result(a_env)["obs"]
+    n_last = 0
+    for t in range(T):
+        act = torch.from_numpy(_seek_actions(rs, obs, N))
+        a_env.step(act)
+        b_env.step(act)
+        ga, gb = _gpu_result(a_env), _gpu_result(b_env)
+        for k in ("obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon", "fault"):
+            assert np.array_equal(ga[k], gb[k]), (k, t)
+        obs = ga["obs"]
+        n_last += int((ga["step_type"] == 2).sum())
+    assert n_last > 3 * N, n_last
+    assert torch.equal(a_env.get_state()[:-1], b_env.get_state()[:-1])
+    a_env.close()
+    b_env.close()
+
+
+@pytest.mark.parametrize("task", ["robot_reach", "robot_push_button"])
+def test_reset_groups_checkpoint_resumes_in_any_handle(task):
+    """mjs_get_state / mjs_set_state under MJS_VARIANT_RESET_GROUPS: the flag byte's launch-parity bits
+    (FLAG_FRESH / FLAG_EPOCH) are not part of a checkpoint. A state saved after an ODD number of steps - with envs that were
+    just reset by a reset workgroup and envs that wait for their reset - resumes bit for bit in the same handle, in a fresh
+    handle (launch parity 0) and in a handle of the default variant; no env skips a step."""
+    import mujoco_sim_amd as m
+
+    N = 256
+    kw = dict(terminate_on_success=True) if task == "robot_reach" else dict(action_type="absolute_eef_action")
+
+    def actions(rs, obs):
+        if task == "robot_reach":
+            return _seek_actions(rs, obs, N)
+        a = rs.uniform([-0.2, -0.6, 0.02, 0.0], [0.2, -0.3, 0.3, 0.085], (N, 4))
+        return a
+
+    src = m.HipVectorEnv(task, N, seed=13, kernel_variant=3, **kw)
+    if task == "robot_push_button":  # episodes that end at different times: shift the envs' clocks
+        src.reset()
+        st = src.get_state()
+        st[12] += torch.from_numpy(np.random.RandomState(0).randint(60, 99, N) * 0.1).to(st.device)
+        src.set_state(st)
+    else:
+        src.reset()
+    rs = np.random.RandomState(8)
+    obs = _gpu_result(src)["obs"]
+    saved = None
+    for t in range(41):  # odd number of launches; stop at a step where some env ended and some env was just reset
+        src.step(torch.from_numpy(actions(rs, obs)))
+        g = _gpu_result(src)
+        obs = g["obs"]
+        if t >= 20 and t % 2 == 0 and (g["step_type"] == 2).any() and (g["step_type"] == 0).any():
+            saved = (src.get_state().clone(), src.get_rng_state(), t)
+            break
+    assert saved is not None
+    state, rng, t0 = saved
+    assert int(state[-1].max().item()) < 64  # neither parity bit is exported
+    tail = [actions(rs, obs) for _ in range(1)]
+    ref = []
+    for k in range(12):
+        src.step(torch.from_numpy(tail[-1]))
+        g = _gpu_result(src)
+        ref.append(g)
+        tail.append(actions(rs, g["obs"]))
+    for variant, presteps in ((3, 0), (3, 1), (0, 0)):
+        dst = m.HipVectorEnv(task, N, seed=99, kernel_variant=variant, **kw)
+        dst.reset()
+        for _ in range(presteps):  # the handle's launch parity differs from a fresh one's
+            dst.step(torch.from_numpy(tail[0]))
+        dst.set_state(state)
+        dst.set_rng_state(rng)
+        for k in range(12):
+            dst.step(torch.from_numpy(tail[k]))
+            g = _gpu_result(dst)
+            for key in ("obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon"):
+                assert np.array_equal(g[key], ref[k][key]), (key, k, variant, presteps)
+        dst.close()
+    src.close()
+
+
 def _top_down_ik_is_a_tie(oracle_mod, tcp, guess, tcp_z=0.174, eps=1e-9):
     """inverse_kinematics_closest picks, per solution and joint, the 2*pi-shifted angle when it is STRICTLY closer to the guess,
     then the solution with the smallest distance. Where two candidates are equally far to the last bit (the wrist_2 joint rests
