@@ -57,11 +57,12 @@ def demo_actions(obs):
     return np.concatenate([tcp + diff, np.zeros((len(obs), 1))], axis=1)
 
 
-def run_button(N, T, base_seed):
+def run_button(N, T, base_seed, gripper_model=0):
     # closed loop on the oracle; the recorded actions make the fixture open-loop for the GPU test.
     # Covers: approach, press (contact rows, touch sensor, rising-edge toggle), success termination
     # (discount 0), next-step auto-reset with device-side re-draws, second episodes.
-    b = oracle.OracleBatch(oracle.TASK_BUTTON_PUSH, N, base_seed, action_type=oracle.ACTION_ABS_EEF)
+    # gripper_model = 1: the articulated 2F-85 (nv = 14, elliptic cones)
+    b = oracle.OracleBatch(oracle.TASK_BUTTON_PUSH, N, base_seed, action_type=oracle.ACTION_ABS_EEF, gripper_model=gripper_model)
     r = b.reset()
     keys = ["obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon"]
     traj = {k: [] for k in keys}
@@ -69,6 +70,32 @@ def run_button(N, T, base_seed):
     reset_obs = r["obs"]
     for t in range(T):
         a = demo_actions(r["obs"])
+        acts.append(a)
+        r = b.step(a)
+        for k in keys:
+            traj[k].append(r[k])
+    return dict(actions=np.stack(acts), reset_obs=reset_obs, **{k: np.stack(v) for k, v in traj.items()})
+
+
+def run_button_joint(N, T, base_seed, gripper_model=1):
+    """Button-Push, absolute joint actions (robot_push_button.py:151-157) with the articulated gripper: joint targets around the
+    reset pose that sweep the pads into the floor / the switch now and then, random gripper openings (the fingers move all the
+    time: tendon actuator, equalities, joint stops), 60 steps with a 40-step time limit so that truncations and resets are inside."""
+    b = oracle.OracleBatch(oracle.TASK_BUTTON_PUSH, N, base_seed, action_type=oracle.ACTION_ABS_JOINT, gripper_model=gripper_model, time_limit=4.0)
+    r = b.reset()
+    keys = ["obs", "reward", "discount", "step_type", "terminated", "truncated", "is_success", "ncon"]
+    traj = {k: [] for k in keys}
+    acts = []
+    reset_obs = r["obs"]
+    rs = np.random.RandomState(321)
+    home = r["obs"][:, :6].copy()
+    for t in range(T):
+        fresh = np.asarray(r["step_type"]) == 0
+        home[fresh] = r["obs"][fresh, :6]
+        if t % 6 == 0:  # a joint target is held for six control steps (the servo lags a 0.1 s set-point by about that much)
+            off = rs.uniform(-0.25, 0.25, (N, 6))
+            off[:, 1] = rs.uniform(0.0, 0.5, N)  # shoulder lift: reach down, the pads meet the floor / the switch in many envs
+        a = np.concatenate([home + off, rs.uniform(0.0, 0.085, (N, 1))], axis=1)
         acts.append(a)
         r = b.step(a)
         for k in keys:
@@ -133,6 +160,8 @@ if __name__ == "__main__":
             print("planar push (mesh blocks) fixture: base seed", seed, "contacts beyond the floor:", int((fx["ncon"] > 8).sum()), "episode ends:", int((fx["step_type"] == 2).sum()))
             break
     np.savez_compressed(OUT / "button_push_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025))
+    np.savez_compressed(OUT / "button_push_art_eef_n8_t80_seed2025.npz", **run_button(8, 80, 2025, gripper_model=1))
+    np.savez_compressed(OUT / "button_push_art_joint_n8_t60_seed2025.npz", **run_button_joint(8, 60, 2025))
     np.savez_compressed(OUT / "pointmass_n8_t70_seed2025.npz", **run(oracle.TASK_POINTMASS, 8, 70, 2025, oracle.AUTORESET_NEXT_STEP))
     np.savez_compressed(OUT / "robot_reach_n8_t110_seed2025.npz", **run(oracle.TASK_ROBOT_REACH, 8, 110, 2025, oracle.AUTORESET_NEXT_STEP))
     print("golden fixtures written to", OUT)
