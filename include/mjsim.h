@@ -25,7 +25,7 @@ extern "C" {
 /* 2 (round 3): mjs_config starts with struct_size (validated by mjs_create: a caller built against another header is refused
  * instead of being read past its end); Robot-Reach / Button-Push state blocks grew 18 rows (qacc_warmstart, carried cos / sin):
  * checkpoints of abi 1 do not fit mjs_set_state any more (mjs_state_dim reports the new widths). */
-#define MJS_ABI_VERSION 2
+#define MJS_ABI_VERSION 3
 
 /* tasks (environments/tasks/*.py) */
 enum {
@@ -105,8 +105,14 @@ typedef struct {
   int32_t block_shape;          /* Planar-Push only: MJS_BLOCKS_MESH (0, the reference: GoogleBlockProp.sample_random_object per episode,
                                  * google_block.py:55-68, category / colour / scale from the env's seeded stream) or MJS_BLOCKS_BOX (round 1's box
                                  * stand-in of the cube mesh's bounding box, scale 1: a documented fast variant) */
+  int32_t gripper_model;        /* Button-Push only (abi 3): MJS_GRIPPER_REDUCED (0: the one-coordinate 2F-85 of DESIGN.md D-1b on the 6-dof arm, the
+                                 * fast default) or MJS_GRIPPER_ARTICULATED (1: the Robotiq 2F-85 as entities/eef/gripper.py:36-98 attaches it -
+                                 * eight hinges, two connect equalities, the driver coupling, the fixed-tendon fingers_actuator, pad boxes,
+                                 * elliptic cones with impratio 10: nv = 14; mjs_env_state_dim() reports its wider state) */
+  int32_t reserved0;            /* 0 */
 } mjs_config;
 enum { MJS_BLOCKS_MESH = 0, MJS_BLOCKS_BOX = 1 };
+enum { MJS_GRIPPER_REDUCED = 0, MJS_GRIPPER_ARTICULATED = 1 };
 
 /* Per-step outputs. Device pointers, caller-owned, any may be NULL.
  * Replaces the (obs, reward, terminated, truncated, info) tuple of

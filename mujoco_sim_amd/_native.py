@@ -30,6 +30,7 @@ STEP_FIRST, STEP_MID, STEP_LAST = 0, 1, 2
 AUTORESET_NEXT_STEP, AUTORESET_SAME_STEP, AUTORESET_DISABLED = 0, 1, 2
 FAULT_BAD_STATE, FAULT_IK_FAILED, FAULT_LIMIT_COLDSTART, FAULT_UNSUPPORTED_CONTACT, FAULT_FASTPATH_VIOLATED = 1, 2, 4, 8, 16
 BLOCKS_MESH, BLOCKS_BOX = 0, 1
+GRIPPER_REDUCED, GRIPPER_ARTICULATED = 0, 1
 VARIANT_DEFAULT, VARIANT_SINGLE_WAVE, VARIANT_TWO_ROLES, VARIANT_RESET_GROUPS = 0, 1, 2, 3
 UR_STATE = 34
 UR_CMD_NONE, UR_CMD_MOVEJ, UR_CMD_MOVEJ_IK, UR_CMD_SERVOL, UR_CMD_SERVOJ = 0, 1, 2, 3, 4
@@ -47,9 +48,10 @@ class MjsConfig(C.Structure):
         ("struct_size", C.c_uint32), ("task", C.c_int32), ("num_envs", C.c_int32), ("device", C.c_int32), ("reward_type", C.c_int32),
         ("autoreset", C.c_int32), ("terminate_on_success", C.c_int32), ("env_index_offset", C.c_int32),
         ("kernel_variant", C.c_int32), ("time_limit", C.c_double), ("action_type", C.c_int32), ("button_disturbances", C.c_int32), ("n_objects", C.c_int32), ("max_episode_steps", C.c_int32), ("block_shape", C.c_int32),
+        ("gripper_model", C.c_int32), ("reserved0", C.c_int32),
     ]
 
-    def __init__(self, *args, **kw):  # struct_size = sizeof(mjs_config) of THIS binding: mjs_create refuses a mismatch (abi 2)
+    def __init__(self, *args, **kw):  # struct_size = sizeof(mjs_config) of THIS binding: mjs_create refuses a mismatch (abi 2+)
         super().__init__(*args, **kw)
         if "struct_size" not in kw:
             self.struct_size = C.sizeof(MjsConfig)

@@ -11,6 +11,7 @@
 #include "mjs_pointmass.h"
 #include "mjs_reach.h"
 #include "mjs_button.h"
+#include "mjs_gripper14.h"
 #include "mjs_push.h"
 #include "mjs_render.h"
 #include <cmath>
@@ -34,6 +35,7 @@ struct mjs_handle {
   float* cams;                 // [N][12] wrist-camera poses (Button-Push)
   double* ws = nullptr;        // [rr::WS_ROWS][N] contact workspace of the general constraint stage (Robot-Reach, Button-Push)
   int epoch = 0;               // parity of the next step launch (FLAG_EPOCH)
+  double* ws14 = nullptr;      // [bg::WS_DOUBLES][N] constraint rows of the articulated-gripper kernel (mjs_gripper14.h)
   std::string err;
 };
 
@@ -158,7 +160,9 @@ __global__ void tcp_to_joints_kernel(const double* pos, const double* guess, dou
   ok[i] = found;
 }
 
+bool articulated(const mjs_handle* h) { return h->cfg.task == MJS_TASK_BUTTON_PUSH && h->cfg.gripper_model == MJS_GRIPPER_ARTICULATED; }
 bool uses_reset_groups(const mjs_handle* h) {
+  if (articulated(h)) return false;  // one kernel shape: a workgroup resets its own envs
   return (h->cfg.task == MJS_TASK_ROBOT_REACH || h->cfg.task == MJS_TASK_BUTTON_PUSH) && h->cfg.kernel_variant == MJS_VARIANT_RESET_GROUPS &&
          h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP;
 }
@@ -191,6 +195,10 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   return p;
 }
 
+// envs per workgroup of the articulated-gripper kernel: 4 until every SIMD of a 256-CU chip has a wavefront (4096 envs), then
+// doubling with the batch (the LDS holds 16 envs of 9.6 KB)
+int bg_epw_for(int n) { return n <= 4096 ? 4 : n <= 8192 ? 8 : 16; }
+
 constexpr int BLOCK = 64;  // one wavefront per workgroup: N/64 workgroups spread over the CUs
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
 
@@ -202,6 +210,10 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, pp::LDS_BYTES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)  // 3..5 blocks: the 5-slot instance, its cooperative workspace needs the large-LDS opt-in (mjs_create)
     pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
+  else if (articulated(h)) {
+    const int epw = bg_epw_for(p.N);
+    bg::kernel<IS_RESET><<<dim3((unsigned)((p.N + epw - 1) / epw)), BLOCK, (size_t)epw * sizeof(bg::Env), s>>>(p, h->ws14, epw);
+  }
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
     else if (p.reset_groups) {  // MJS_VARIANT_RESET_GROUPS: the second half of the grid resets the envs whose episode ended
@@ -283,6 +295,9 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (cfg->task != MJS_TASK_POINTMASS_REACH && cfg->task != MJS_TASK_ROBOT_REACH && cfg->task != MJS_TASK_BUTTON_PUSH && cfg->task != MJS_TASK_PLANAR_PUSH)
     return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: unknown task id");
   if (mjs_action_dim_for(cfg->task, cfg->action_type) < 0) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad action_type");
+  if (cfg->gripper_model != MJS_GRIPPER_REDUCED && cfg->gripper_model != MJS_GRIPPER_ARTICULATED) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad gripper_model");
+  if (cfg->gripper_model == MJS_GRIPPER_ARTICULATED && cfg->task != MJS_TASK_BUTTON_PUSH)
+    return fail(nullptr, MJS_ERR_UNSUPPORTED, "mjs_create: the articulated 2F-85 is built for Button-Push only (Robot-Reach keeps the rigid payload, BASELINE config 3 \"UR5e 6-DoF\")");
   if (cfg->task == MJS_TASK_PLANAR_PUSH && cfg->n_objects > MJS_PP_MAX_OBJECTS) return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: n_objects exceeds MJS_PP_MAX_OBJECTS");
   if (cfg->task == MJS_TASK_PLANAR_PUSH && cfg->block_shape != MJS_BLOCKS_MESH && cfg->block_shape != MJS_BLOCKS_BOX)
     return fail(nullptr, MJS_ERR_INVALID_ARG, "mjs_create: bad block_shape");
@@ -303,6 +318,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);
   if (cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) { h->state_dim = pp5::STATE_DIM; h->obs_dim = pp5::OBS_DIM; }
+  if (cfg->task == MJS_TASK_BUTTON_PUSH && h->cfg.gripper_model == MJS_GRIPPER_ARTICULATED) h->state_dim = bg::STATE_DIM;
   h->act_dim = mjs_action_dim_for(cfg->task, cfg->action_type);
   h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr; h->cams = nullptr;
   const size_t N = (size_t)cfg->num_envs;
@@ -332,6 +348,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::BP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_PLANAR_PUSH) e = hipMalloc(&h->prims, sizeof(float) * rend::PRIM_FLOATS * rend::PP_NPRIM * N);
   if (e == hipSuccess && cfg->task == MJS_TASK_BUTTON_PUSH) e = hipMalloc(&h->cams, sizeof(float) * 12 * N);
+  if (e == hipSuccess && articulated(h)) e = hipMalloc(&h->ws14, sizeof(double) * (size_t)bg::WS_DOUBLES * N);  // 15 KB per env: every row of every env
   if (e == hipSuccess && cfg->task != MJS_TASK_POINTMASS_REACH)  // 3.4 KB per env, touched only by lanes with an arm geom in the floor
     e = hipMalloc(&h->ws, sizeof(double) * rr::WS_ROWS * N);
 #ifdef MJS_STAMPS
@@ -342,6 +359,25 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
     int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
     mjs_destroy(h);
     return rc;
+  }
+  if (articulated(h)) {  // > 64 KB of dynamic LDS per workgroup is an opt-in (16 envs per workgroup at large batches)
+    static_assert(16 * sizeof(bg::Env) <= 160 * 1024, "16 envs per workgroup fit the CU's LDS");
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bg::kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * sizeof(bg::Env)));
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&bg::kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(16 * sizeof(bg::Env)));
+    if (e != hipSuccess) {
+      int rc = hip_fail(nullptr, e, "mjs_create: LDS opt-in");
+      mjs_destroy(h);
+      return rc;
+    }
+  }
+  if (articulated(h)) {  // the compiled 14-body model: a __device__ global of this device, the same constants for every handle
+    static const bg::Model host_model = [] { bg::Model m; std::memset(&m, 0, sizeof m); bg::build_model(m); return m; }();
+    e = hipMemcpyToSymbol(HIP_SYMBOL(bg::g_model), &host_model, sizeof host_model);
+    if (e != hipSuccess) {
+      int rc = hip_fail(nullptr, e, "mjs_create: model upload");
+      mjs_destroy(h);
+      return rc;
+    }
   }
   init_kernel<<<grid_for((int)N), BLOCK>>>(h->state, h->flags, (int)N, cfg->task, host_pending_byte(h));
   seed_kernel<<<grid_for((int)N), BLOCK>>>(DevRng{h->rng_mt, h->rng_pos, (int)N}, 0u, cfg->env_index_offset);
@@ -402,6 +438,7 @@ void mjs_destroy(mjs_handle* h) {
   if (h->bg_rgb) (void)hipFree(h->bg_rgb);
   if (h->cams) (void)hipFree(h->cams);
   if (h->ws) (void)hipFree(h->ws);
+  if (h->ws14) (void)hipFree(h->ws14);
   delete h;
 }
 

@@ -104,7 +104,8 @@ class HipVectorEnv:
                  terminate_on_success: bool = False, env_index_offset: int = 0, kernel_variant: int | None = None,
                  observation_type: str = STATE_OBS, image_resolution: int = 64, action_type: str | None = None,
                  button_disturbances: bool = False, use_wrist_camera: bool = True, n_objects: int | None = None,
-                 max_episode_steps: int | None = None, block_shape: str = "mesh", global_num_envs: int | None = None):
+                 max_episode_steps: int | None = None, block_shape: str = "mesh", global_num_envs: int | None = None,
+                 gripper_model: str = "reduced"):
         if task not in TASKS:
             raise ValueError(f"unknown task {task!r}; available: {sorted(TASKS)}")
         self.spec = TASKS[task]
@@ -122,6 +123,11 @@ class HipVectorEnv:
         if block_shape not in ("mesh", "box"):
             raise ValueError("block_shape must be 'mesh' (the reference's GoogleBlockProp meshes) or 'box' (round 1's stand-in)")
         self.block_shape = block_shape
+        if gripper_model not in ("reduced", "articulated"):
+            raise ValueError("gripper_model must be 'reduced' (DESIGN.md D-1b, nv = 6) or 'articulated' (the 2F-85 of gripper.py:36-98, nv = 14)")
+        if gripper_model == "articulated" and task != "robot_push_button":
+            raise ValueError("the articulated 2F-85 is built for robot_push_button only")
+        self.gripper_model = gripper_model
         self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
         if self.device.type != "cuda" or not torch.cuda.is_available():
             raise nat.MjsError("HipVectorEnv needs a HIP device (torch device 'cuda:N'); there is no CPU path")
@@ -152,7 +158,8 @@ class HipVectorEnv:
                             time_limit=float(time_limit) if time_limit is not None else -1.0,
                             action_type=_ACTION_IDS.get(action_type, 0), button_disturbances=int(bool(button_disturbances)),
                             n_objects=int(n_objects or 0), max_episode_steps=int(max_episode_steps or 0),
-                            block_shape=nat.BLOCKS_BOX if block_shape == "box" else nat.BLOCKS_MESH)
+                            block_shape=nat.BLOCKS_BOX if block_shape == "box" else nat.BLOCKS_MESH,
+                            gripper_model=nat.GRIPPER_ARTICULATED if gripper_model == "articulated" else nat.GRIPPER_REDUCED)
         h = C.c_void_p()
         nat.check(self._lib.mjs_create(C.byref(cfg), C.byref(h)))
         self._h = h

@@ -79,7 +79,7 @@ def test_create_rejects_bad_arguments(native):
     # abi 2: a caller built against another header (different mjs_config) is refused before any field is read
     cfg = native.MjsConfig(task=1, num_envs=4, device=0, reward_type=-1, autoreset=0, struct_size=C.sizeof(native.MjsConfig) - 4)
     assert L.mjs_create(C.byref(cfg), C.byref(h)) == -1 and b"struct_size" in L.mjs_last_error(None)
-    assert b"abi 2" in L.mjs_version()
+    assert b"abi 3" in L.mjs_version()
 
 
 def test_no_cpu_fallback_without_gpu(native):

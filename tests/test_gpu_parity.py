@@ -2010,3 +2010,162 @@ def test_robot_reach_large_batch_matches_oracle(oracle_mod):
         o = ob.step(acts[t])
         _compare(t, _gpu_result(venv), o)
     venv.close()
+
+
+# ------------------------------------------------------------------------------------ the articulated Robotiq 2F-85 (nv = 14)
+ART_ATOL = 1e-8
+
+
+def _art_pair(oracle_mod, N, seed, action_type, autoreset="next_step", **okw):
+    import mujoco_sim_amd as m
+
+    at = {0: "absolute_joint_action", 1: "absolute_eef_action"}[action_type]
+    venv = m.HipVectorEnv("robot_push_button", N, seed=seed, autoreset=autoreset, action_type=at, gripper_model="articulated", **{k: v for k, v in okw.items() if k == "time_limit"})
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, seed, autoreset={"next_step": 0, "same_step": 1, "disabled": 2}[autoreset], nthreads=8,
+                                action_type=action_type, gripper_model=1, **okw)
+    return venv, ob
+
+
+def _art_compare(t, g, o, atol=ART_ATOL):
+    np.testing.assert_allclose(g["obs"], o["obs"], rtol=0, atol=atol, err_msg=f"obs step {t}")
+    np.testing.assert_allclose(g["reward"], o["reward"], rtol=0, atol=atol, err_msg=f"reward step {t}")
+    for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+        assert np.array_equal(np.asarray(g[k]).astype(np.int64), np.asarray(o[k]).astype(np.int64)), (k, t, np.where(np.asarray(g[k]).astype(np.int64) != np.asarray(o[k]).astype(np.int64)))
+
+
+def _art_state(venv):
+    st = venv.get_state().cpu().numpy()
+    q = np.concatenate([st[0:6], st[36:44]]).T
+    v = np.concatenate([st[6:12], st[44:52]]).T
+    return q, v
+
+
+@pytest.mark.parametrize("action_type", [1, 0])
+def test_articulated_gripper_matches_golden(action_type):
+    """the nv = 14 Button-Push kernel (mjs_gripper14.h) on the committed fixtures of the articulated oracle: EEF actions = the
+    reference's scripted policy (press, success, auto-reset, second episodes); joint actions = held joint targets that bring pads
+    and links to the floor, random gripper commands, truncation at 40 steps"""
+    import mujoco_sim_amd as m
+
+    name = {0: "button_push_art_joint_n8_t60_seed2025.npz", 1: "button_push_art_eef_n8_t80_seed2025.npz"}[action_type]
+    fx = np.load(GOLDEN / name)
+    N = fx["actions"].shape[1]
+    kw = {"time_limit": 4.0} if action_type == 0 else {}
+    venv = m.HipVectorEnv("robot_push_button", N, seed=2025, action_type={0: "absolute_joint_action", 1: "absolute_eef_action"}[action_type], gripper_model="articulated", **kw)
+    venv.reset()
+    np.testing.assert_allclose(_gpu_result(venv)["obs"], fx["reset_obs"], rtol=0, atol=ART_ATOL)
+    for t in range(fx["actions"].shape[0]):
+        venv.step(torch.from_numpy(fx["actions"][t]))
+        _art_compare(t, _gpu_result(venv), {k: fx[k][t] for k in ("obs", "reward", "step_type", "terminated", "truncated", "is_success", "ncon")})
+    venv.close()
+
+
+@pytest.mark.parametrize("autoreset", ["next_step", "same_step"])
+def test_articulated_gripper_scripted_policy_vs_oracle(oracle_mod, autoreset):
+    """closed loop: the reference's demonstration policy (robot_push_button.py:231-300, gripper "always closed") computed from
+    the DEVICE observations, the same actions on both sides: 64 envs x 120 steps, every output of every env; the episodes succeed
+    (the closed pads' ends are the TCP), end at different times and restart under both auto-reset modes"""
+    import mujoco_sim_amd as m
+
+    N, T = 64, 120
+    task = m.RobotPushButtonTask(observation_type="state_observations", action_type="absolute_eef_action")
+    venv, ob = _art_pair(oracle_mod, N, 77, 1, autoreset)
+    venv.reset()
+    ob.reset()
+    wins = 0
+    for t in range(T):
+        a = task.demonstration_actions(venv).cpu().numpy()
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        g = _gpu_result(venv)
+        _art_compare(t, g, o)
+        if autoreset == "same_step":
+            np.testing.assert_allclose(g["terminal_obs"][o["step_type"] == 2], o["terminal_obs"][o["step_type"] == 2], rtol=0, atol=ART_ATOL)
+        wins += int(np.asarray(o["is_success"]).sum())
+    assert wins >= N, wins
+    q, v = _art_state(venv)
+    oq, ov, _ = ob.get_state()
+    np.testing.assert_allclose(q, oq, rtol=0, atol=ART_ATOL)
+    np.testing.assert_allclose(v, ov, rtol=0, atol=1e-6)
+    venv.close()
+
+
+def test_articulated_gripper_joint_actions_vs_oracle(oracle_mod):
+    """absolute joint actions (robot_push_button.py:151-157): joint targets held for six steps that reach down (pads and arm links
+    on the floor, on the switch), a new gripper opening every step (tendon actuator, equalities, joint stops at work all the time):
+    128 envs x 90 steps against the oracle. Rigid contact amplifies rounding (a pad that bounces on the floor: the kernel sums in
+    another order than the oracle), so every env is held to max(1e-8, 100 x its own sensitivity), the sensitivity being what a SECOND
+    oracle whose joint targets are shifted by 1e-13 rad does to that env; flags and contact counts are exact for every env that has
+    stayed calm (sensitivity < 1e-10), at least 80 % of them to the end, where all 14 joint positions are compared as well."""
+    N, T = 128, 90
+    venv, ob = _art_pair(oracle_mod, N, 5, 0, time_limit=5.0)
+    ob2 = oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 5, nthreads=8, action_type=0, gripper_model=1, time_limit=5.0)
+    venv.reset()
+    r = ob.reset()
+    ob2.reset()
+    rs = np.random.RandomState(3)
+    home = r["obs"][:, :6].copy()
+    contact_steps = 0
+    sens = np.zeros(N)
+    for t in range(T):
+        fresh = np.asarray(r["step_type"]) == 0
+        home[fresh] = r["obs"][fresh, :6]
+        sens[fresh] = 0.0  # a new episode starts from exact reset draws
+        if t % 6 == 0:
+            off = rs.uniform(-0.25, 0.25, (N, 6))
+            off[:, 1] = rs.uniform(0.0, 0.5, N)
+        a = np.concatenate([home + off, rs.uniform(0.0, 0.085, (N, 1))], axis=1)
+        venv.step(torch.from_numpy(a))
+        r = ob.step(a)
+        a2 = a.copy()
+        a2[:, :6] += 1e-13
+        r2 = ob2.step(a2)
+        g = _gpu_result(venv)
+        sens = np.maximum(sens, np.abs(r["obs"] - r2["obs"]).max(axis=1))
+        err = np.abs(g["obs"] - r["obs"]).max(axis=1)
+        assert (err <= np.maximum(ART_ATOL, 100 * sens)).all(), (t, np.where(err > np.maximum(ART_ATOL, 100 * sens)), err.max())
+        calm = sens < 1e-10
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            assert np.array_equal(np.asarray(g[k]).astype(np.int64)[calm], np.asarray(r[k]).astype(np.int64)[calm]), (k, t)
+        assert not (np.asarray(g["fault"]) & 1).any()
+        contact_steps += int((np.asarray(r["ncon"]) > 0).sum())
+    assert contact_steps > 300, contact_steps
+    calm = sens < 1e-10
+    assert calm.mean() >= 0.8, calm.mean()
+    q, v = _art_state(venv)
+    oq, ov, _ = ob.get_state()
+    np.testing.assert_allclose(q[calm], oq[calm], rtol=0, atol=ART_ATOL)
+    venv.close()
+
+
+def test_articulated_gripper_follows_move_and_shards(oracle_mod):
+    """(1) Robotiq2f85.move (gripper.py:79-84): with the arm held, the commanded opening is reached - state rows 16-17 (right
+    driver angle / velocity) equal the oracle's, the reference's read-back get_finger_opening (gripper.py:76-77) = the command
+    to 1 mm at rest. (2) envs are independent: env i of one 64-env handle = env i of four 16-env handles (global seeds), bitwise."""
+    import mujoco_sim_amd as m
+
+    N = 64
+    venv, ob = _art_pair(oracle_mod, N, 41, 0, "disabled")
+    venv.reset()
+    r = ob.reset()
+    hold = r["obs"][:, :6].copy()
+    w = np.linspace(0.0, 0.085, N)
+    shards = [m.HipVectorEnv("robot_push_button", 16, seed=41, autoreset="disabled", gripper_model="articulated", env_index_offset=16 * k) for k in range(4)]
+    for sh in shards:
+        sh.reset()
+    for t in range(25):
+        a = np.concatenate([hold, w[:, None]], axis=1)
+        venv.step(torch.from_numpy(a))
+        r = ob.step(a)
+        _art_compare(t, _gpu_result(venv), r)
+        for k, sh in enumerate(shards):
+            sh.step(torch.from_numpy(a[16 * k:16 * k + 16]))
+    g = venv.get_state().cpu().numpy()
+    np.testing.assert_allclose(g[16:18].T, ob.get_gripper(), rtol=0, atol=ART_ATOL)
+    opening = 0.085 * (1 - np.sin(g[16]) / np.sin(0.8))
+    np.testing.assert_allclose(opening, w, atol=1e-3)
+    whole = venv.get_state()
+    for k, sh in enumerate(shards):
+        assert torch.equal(sh.get_state()[:-1], whole[:-1, 16 * k:16 * k + 16]), k
+        sh.close()
+    venv.close()
