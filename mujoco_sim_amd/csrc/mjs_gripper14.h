@@ -78,7 +78,7 @@ struct Model {
   double pad_com[2][3];                    // pad body's own COM in the follower's frame
   double site_pos[3], site_rot[9];         // flange site in wrist_3's frame
 };
-__device__ Model g_model;
+__constant__ Model g_model;  // constant address space: a wave-uniform index makes the load a scalar one
 
 MJS_HD void quat_to_mat(const double* q_in, double* m) {  // normalises; row-major
   double n = sqrt(q_in[0] * q_in[0] + q_in[1] * q_in[1] + q_in[2] * q_in[2] + q_in[3] * q_in[3]);
@@ -136,6 +136,9 @@ struct Env {
   // scratch of the stage that is running (composite inertias | spatial velocities, accelerations, forces | Hessian and its factor |
   // the integrator's matrix and its factor): kept with the env so that it lives in LDS like the rest
   double tmp[256];
+#ifdef MJS_BG_PROFILE
+  double dbg[4];  // Newton iterations, line-search iterations, solves, MPR calls
+#endif
 };
 MJS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
 struct Rows {
@@ -220,12 +223,13 @@ MJS_DEV void cross_force6(const double* v, const double* f, double* r) {
   for (int k = 0; k < 3; k++) { r[k] = a[k] + b[k]; r[3 + k] = c[k]; }
 }
 
-// dense Cholesky A = L L^T on packed lower triangles, false when not positive definite
-MJS_HD bool chol_factor(const double* A, double* L) {
+// dense Cholesky A = L L^T on packed lower triangles, false when not positive definite. Host (model compiler): plain loops.
+// Device: the 105 entries are loaded into registers, factorised by fully unrolled code (no indexed memory: the loop version's
+// dependent LDS reads cost ~450 cycles per multiply-add on a wavefront that has the SIMD to itself, 125 us per factorisation)
+// and stored back; out of line, one copy for the five call sites.
+inline bool chol_factor_host(const double* A, double* L) {
   bool ok = true;
-#pragma unroll 1
   for (int i = 0; i < NV; i++)
-#pragma unroll 1
     for (int j = 0; j <= i; j++) {
       double s = A[tri(i, j)];
       for (int k = 0; k < j; k++) s -= L[tri(i, k)] * L[tri(j, k)];
@@ -237,22 +241,83 @@ MJS_HD bool chol_factor(const double* A, double* L) {
     }
   return ok;
 }
-MJS_HD void chol_solve(const double* L, double* x) {
-#pragma unroll 1
+inline void chol_solve_host(const double* L, double* x) {
   for (int i = 0; i < NV; i++) {
     double s = x[i];
     for (int k = 0; k < i; k++) s -= L[tri(i, k)] * x[k];
     x[i] = s / L[tri(i, i)];
   }
-#pragma unroll 1
   for (int i = NV - 1; i >= 0; i--) {
     double s = x[i];
     for (int k = i + 1; k < NV; k++) s -= L[tri(k, i)] * x[k];
     x[i] = s / L[tri(i, i)];
   }
 }
-
-// mj_crb + armature -> dense M, then its Cholesky factor
+__device__ __noinline__ bool chol_factor_dev(const double* A, double* L) {
+  double a[NTRI];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) a[k] = A[k];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double d = a[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= a[tri(j, k)] * a[tri(j, k)];
+    if (!(d >= MJS_MINVAL)) { ok = false; d = MJS_MINVAL; }
+    const double ljj = sqrt(d);
+    a[tri(j, j)] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < NV; i++) {
+      double s = a[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) s -= a[tri(i, k)] * a[tri(j, k)];
+      a[tri(i, j)] = s / ljj;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) L[k] = a[k];
+  return ok;
+}
+// x <- (L L^T)^-1 x, L and x in registers
+__device__ __noinline__ void chol_solve_dev(const double* L, double* x) {
+  double a[NTRI], y[NV];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) a[k] = L[k];
+#pragma unroll
+  for (int k = 0; k < NV; k++) y[k] = x[k];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double s = y[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= a[tri(i, k)] * y[k];
+    y[i] = s / a[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; i--) {
+    double s = y[i];
+#pragma unroll
+    for (int k = i + 1; k < NV; k++) s -= a[tri(k, i)] * y[k];
+    y[i] = s / a[tri(i, i)];
+  }
+#pragma unroll
+  for (int k = 0; k < NV; k++) x[k] = y[k];
+}
+// y = M x with the packed symmetric M in registers
+__device__ __noinline__ void sym_mul_dev(const double* M, const double* x, double* y) {
+  double a[NTRI], xx[NV];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) a[k] = M[k];
+#pragma unroll
+  for (int k = 0; k < NV; k++) xx[k] = x[k];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double s = 0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) s += a[k <= i ? tri(i, k) : tri(k, i)] * xx[k];
+    y[i] = s;
+  }
+}
+// mj_crb + armature -> M (packed); the caller factorises it (chol_factor_dev / chol_factor_host)
 MJS_HD void crb(const Model& m, Env& e) {
   SIn* c = reinterpret_cast<SIn*>(e.tmp);
   static_assert(sizeof(SIn) * NV <= sizeof(double) * 256, "composite inertias fit the stage scratch");
@@ -279,7 +344,6 @@ MJS_HD void crb(const Model& m, Env& e) {
     }
     e.M[tri(i, i)] += m.armature[i];
   }
-  chol_factor(e.M, e.L);
 }
 
 // translational Jacobian of the world point p attached to moving body b: jt[k][j] (zero for dofs that do not move b)
@@ -634,16 +698,28 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
 // observation of the env (kinematics, crb + factor, collision, rows, velocity stage, forces + solver, integration)
 #ifdef MJS_BG_PROFILE
 #define BG_T(k, stmt) do { const long long t0_ = clock64(); stmt; prof[k] += (double)(clock64() - t0_); } while (0)
+#define BG_COUNT(e, k) ((e).dbg[k] += 1.0)
 #else
 #define BG_T(k, stmt) do { stmt; } while (0)
+#define BG_COUNT(e, k) ((void)0)
 #endif
+// The stages are OUT OF LINE, one copy each, and find their env in LDS themselves (an Env& argument would make every access a
+// FLAT one): a control step runs them 20 times, resets run them too, and inlined into the four call contexts the kernel was
+// 62 k instructions - far beyond the instruction cache, which the substep loop streams through once per substep.
+extern __shared__ double lds_envs[];
+MJS_DEV Env& my_env() { return reinterpret_cast<Env*>(lds_envs)[threadIdx.x]; }
+__device__ __noinline__ void st_kinematics() { kinematics(g_model, my_env()); }
+__device__ __noinline__ void st_crb() { Env& e = my_env(); crb(g_model, e); chol_factor_dev(e.M, e.L); }
+__device__ __noinline__ void st_collision() { collision(g_model, my_env()); }
+__device__ __noinline__ void st_rows(double* ws_lane, size_t N) { make_rows(g_model, my_env(), Rows{ws_lane, N}); }
+__device__ __noinline__ void st_velocity() { velocity_stage(g_model, my_env()); }
 // mj_step1: position + velocity stages
 MJS_DEV void step1(const Model& m, Env& e, const Rows& w, double* prof) {
-  BG_T(0, kinematics(m, e));
-  BG_T(1, crb(m, e));
-  BG_T(2, collision(m, e));
-  BG_T(3, make_rows(m, e, w));
-  BG_T(4, velocity_stage(m, e));
+  BG_T(0, st_kinematics());
+  BG_T(1, st_crb());
+  BG_T(2, st_collision());
+  BG_T(3, st_rows(w.base, w.N));
+  BG_T(4, st_velocity());
 }
 
 // ------------------------------------------------------------------------------------------------ forces and the solver
@@ -710,15 +786,7 @@ MJS_DEV double constraint_update(Env& e, const Rows& w, const double* qacc, cons
   for (int i = 0; i < NV; i++) gauss += (Ma[i] - e.qfrc_smooth[i]) * (qacc[i] - e.qacc_smooth[i]);
   return cost + 0.5 * gauss;
 }
-MJS_DEV void mul_M(const Env& e, const double* x, double* y) {
-#pragma unroll 1
-  for (int i = 0; i < NV; i++) {
-    double s = 0;
-    for (int k = 0; k <= i; k++) s += e.M[tri(i, k)] * x[k];
-    for (int k = i + 1; k < NV; k++) s += e.M[tri(k, i)] * x[k];
-    y[i] = s;
-  }
-}
+MJS_DEV void mul_M(const Env& e, const double* x, double* y) { sym_mul_dev(e.M, x, y); }
 MJS_DEV void set_jar(const Env& e, const Rows& w, const double* qacc) {  // jar = J qacc - aref
 #pragma unroll 1
   for (int r = 0; r < e.nefc; r++) {
@@ -728,10 +796,11 @@ MJS_DEV void set_jar(const Env& e, const Rows& w, const double* qacc) {  // jar 
   }
 }
 // exact 1-D minimiser of the cost along the search direction (1-D Newton with bracketing, MuJoCo's gradient stopping rule)
-MJS_DEV double line_search(const Env& e, const Rows& w, double g1, double g2, double gtol) {
+MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
 #pragma unroll 1
   for (int it = 0; it < 50; it++) {
+    BG_COUNT(e, 1);
     double d1 = g1 + alpha * g2, d2 = g2;
 #pragma unroll 1
     for (int r = 0; r < e.nefc; r++) {
@@ -809,8 +878,10 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
   double* const H = e.tmp;
   double* const Lh = e.tmp + NTRI;
   static_assert(2 * NTRI <= 256, "Hessian and factor fit the stage scratch");
+  BG_COUNT(e, 2);
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
+    BG_COUNT(e, 0);
     gradient(e, w, Ma, grad);
     // Hessian: M + sum over quadratic rows D J^T J + cone blocks
 #pragma unroll 1
@@ -857,9 +928,9 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
         for (int j = 0; j <= i; j++) H[tri(i, j)] += dj * Jr[j];
       }
     }
-    if (!chol_factor(H, Lh)) break;
+    if (!chol_factor_dev(H, Lh)) break;
     for (int i = 0; i < NV; i++) search[i] = -grad[i];
-    chol_solve(Lh, search);
+    chol_solve_dev(Lh, search);
     mul_M(e, search, Mv);
     double g1 = 0, g2 = 0, snorm = 0;
     for (int i = 0; i < NV; i++) { g1 += search[i] * (Ma[i] - e.qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
@@ -907,7 +978,7 @@ MJS_DEV void forces(const Model& m, Env& e, const Rows& w) {
   double act[NV];
   actuation(m, e, act);
   for (int i = 0; i < NV; i++) { e.qfrc_smooth[i] = e.passive[i] - e.bias[i] + act[i]; e.qacc_smooth[i] = e.qfrc_smooth[i]; }
-  chol_solve(e.L, e.qacc_smooth);
+  chol_solve_dev(e.L, e.qacc_smooth);
   solve(m, e, w);
   touch_sensor(e, w);
 }
@@ -932,8 +1003,8 @@ MJS_DEV bool integrate(const Model& m, Env& e) {
     const double kk = MJS_RR_PHYSICS_DT * MJS_G2F85_ACT_KV * MJS_G85_TENDON_COEF * MJS_G85_TENDON_COEF;
     A[tri(B_RDRIVER, B_RDRIVER)] += kk; A[tri(B_LDRIVER, B_LDRIVER)] += kk; A[tri(B_LDRIVER, B_RDRIVER)] += kk;
   }
-  chol_factor(A, L);
-  chol_solve(L, qa);
+  chol_factor_dev(A, L);
+  chol_solve_dev(L, qa);
   for (int i = 0; i < NV; i++) {
     e.v[i] += MJS_RR_PHYSICS_DT * qa[i];
     e.q[i] += MJS_RR_PHYSICS_DT * e.v[i];
@@ -942,6 +1013,9 @@ MJS_DEV bool integrate(const Model& m, Env& e) {
   e.time += MJS_RR_PHYSICS_DT;
   return bad;
 }
+
+__device__ __noinline__ void st_forces(double* ws_lane, size_t N) { forces(g_model, my_env(), Rows{ws_lane, N}); }
+__device__ __noinline__ bool st_integrate() { return integrate(g_model, my_env()); }
 
 // ------------------------------------------------------------------------------------------------ model compilation (host)
 // The role of MuJoCo's model compiler + mj_setConst for this scene: runs on the host at mjs_create, the result is copied into
@@ -1077,6 +1151,7 @@ inline void build_model(Model& m) {
   for (int i = 0; i < NV; i++) { e.q[i] = 0; e.v[i] = 0; }
   kinematics(m, e);
   crb(m, e);
+  chol_factor_host(e.M, e.L);
   for (int s = 0; s < 2; s++) {
     const int b1 = s == 0 ? B_RFOLLOWER : B_LFOLLOWER, b2 = s == 0 ? B_RCOUPLER : B_LCOUPLER;
     double d[3];
@@ -1089,7 +1164,7 @@ inline void build_model(Model& m) {
   for (int i = 0; i < NV; i++) {
     double x[NV];
     for (int k = 0; k < NV; k++) x[k] = k == i ? 1.0 : 0.0;
-    chol_solve(e.L, x);
+    chol_solve_host(e.L, x);
     m.dof_invweight0[i] = x[i];
   }
   auto invweight_tran = [&](int b, const double* local) {
@@ -1101,7 +1176,7 @@ inline void build_model(Model& m) {
     for (int k = 0; k < 3; k++) {
       double x[NV];
       for (int j = 0; j < NV; j++) x[j] = jt[k][j];
-      chol_solve(e.L, x);
+      chol_solve_host(e.L, x);
       for (int j = 0; j < NV; j++) s += jt[k][j] * x[j];
     }
     return fmax(MJS_MINVAL, s / 3);
@@ -1163,7 +1238,7 @@ MJS_DEV uint8_t episode_init(const Model& m, const KernelParams& p, int i, Env& 
   e.overflow = false;
   double prof[8];
   step1(m, e, w, prof);
-  forces(m, e, w);
+  st_forces(w.base, w.N);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   bp::switch_update(e.touch, f);
   return f;
@@ -1181,8 +1256,11 @@ MJS_DEV void reset_env(const Model& m, const KernelParams& p, int i, Env& e, con
 // until every SIMD of the chip has a wavefront the envs are spread as thin as the LDS allows (4 per workgroup: 4 workgroups of
 // 4 x 9.6 KB per CU = one wavefront per SIMD at 4096 envs); larger batches take 8, 16, .. envs per workgroup (host: epw_for).
 extern __shared__ double lds_envs[];
+#ifndef MJS_BG_WAVES
+#define MJS_BG_WAVES 1  // wavefronts per SIMD the register budget is cut for (tools/ab experiments: -DMJS_BG_WAVES=2 / 4)
+#endif
 template <bool IS_RESET>
-__global__ __launch_bounds__(64) void kernel(KernelParams p, double* ws_base, int epw) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES, MJS_BG_WAVES))) void kernel(KernelParams p, double* ws_base, int epw) {
   const int lane = threadIdx.x;
   if (lane >= epw) return;
   const int i = blockIdx.x * epw + lane;
@@ -1217,13 +1295,16 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p, double* ws_base, in
   const double t0 = e.time, t1 = e.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
   bool bad = false, rows_active = false;
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#ifdef MJS_BG_PROFILE
+  for (int k = 0; k < 4; k++) e.dbg[k] = 0;
+#endif
   step1(m, e, w, prof);  // the previous Physics.step()'s mj_step1 (a function of the state)
 #pragma unroll 1
   for (int s = 0; s < MJS_RR_NSUB; s++) {
     const double t = fmin(fmax(e.time, t0), t1);
     for (int j = 0; j < NA; j++) e.ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;  // robot.py:261-263
-    BG_T(5, forces(m, e, w));              // mj_step2 ...
-    BG_T(6, bad = integrate(m, e) || bad);
+    BG_T(5, st_forces(w.base, w.N));       // mj_step2 ...
+    BG_T(6, bad = st_integrate() || bad);
     rows_active = rows_active || e.nefc > NEQ_ROWS;
     step1(m, e, w, prof);                  // ... mj_step1 (dm_control's legacy order)
     bp::switch_update(e.touch, flags);     // Switch.after_substep (switch.py:71-72)
@@ -1233,6 +1314,7 @@ __global__ __launch_bounds__(64) void kernel(KernelParams p, double* ws_base, in
   make_obs(m, e, flags, obs);
 #ifdef MJS_BG_PROFILE
   for (int k = 0; k < 7; k++) obs[k] = prof[k];
+  for (int k = 0; k < 4; k++) obs[7 + k] = e.dbg[k];
 #endif
   const double dx = obs[6] - MJS_BP_ROBOT_END_POS[0], dy = obs[7] - MJS_BP_ROBOT_END_POS[1], dz = obs[8] - MJS_BP_ROBOT_END_POS[2];
   const bool success = (flags & FLAG_SWITCH_ACTIVE) && sqrt(dx * dx + dy * dy + dz * dz) < MJS_BP_GOAL_THRESHOLD;

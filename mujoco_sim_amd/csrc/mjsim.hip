@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -197,7 +198,10 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
 
 // envs per workgroup of the articulated-gripper kernel: 4 until every SIMD of a 256-CU chip has a wavefront (4096 envs), then
 // doubling with the batch (the LDS holds 16 envs of 9.6 KB)
-int bg_epw_for(int n) { return n <= 4096 ? 4 : n <= 8192 ? 8 : 16; }
+int bg_epw_for(int n) {
+  if (const char* ev = std::getenv("MJS_BG_EPW")) { const int v = std::atoi(ev); if (v >= 1 && v <= 16) return v; }  // A/B experiments
+  return n <= 4096 ? 4 : n <= 8192 ? 8 : 16;
+}
 
 constexpr int BLOCK = 64;  // one wavefront per workgroup: N/64 workgroups spread over the CUs
 inline dim3 grid_for(int n) { return dim3((unsigned)((n + BLOCK - 1) / BLOCK)); }
