@@ -18,6 +18,14 @@ from pathlib import Path
 import numpy as np
 
 
+# The reference's LeRobot configs (scripts/lerobot/configs/act_robot_button_push.yaml:24,47, dp_robot_button_push.yaml:24,148) name the
+# wrist camera's column `ur5e_WristCamera_rgb_image`; the reference's code at HEAD produces `ur5e/Camera/rgb_image` (the Camera
+# entity keeps CameraConfig.name = "Camera", robot_push_button.py:92-96), i.e. `ur5e_Camera_rgb_image` after the recorder's
+# '/' -> '_' mapping. The recorder emits the CODE's key; `key_aliases` (or this table) renames columns for a consumer that
+# was configured from the YAMLs.
+REFERENCE_YAML_KEY_ALIASES = {"observation.images.ur5e_Camera_rgb_image": "observation.images.ur5e_WristCamera_rgb_image"}
+
+
 def _to_numpy(x):
     if hasattr(x, "detach"):
         x = x.detach().cpu().numpy()
@@ -32,7 +40,7 @@ class LeRobotDatasetRecorder:
         "timestamp": {"dtype": "float32", "shape": (1,), "names": None},
     }
 
-    def __init__(self, env, root_dataset_dir, dataset_name: str, fps: int, use_videos: bool = False, task: str = ""):
+    def __init__(self, env, root_dataset_dir, dataset_name: str, fps: int, use_videos: bool = False, task: str = "", key_aliases: dict | None = None):
         if use_videos:
             raise NotImplementedError("no video encoder in this environment: images are stored as raw uint8 columns (use_videos=False)")
         self.root_dataset_dir = Path(root_dataset_dir)
@@ -57,6 +65,9 @@ class LeRobotDatasetRecorder:
             features[self.key_mapping_dict[key]] = {"dtype": "float32", "shape": tuple(spaces[key].shape), "names": None}
         features["observation.state"] = {"dtype": "float32", "shape": (sum(int(np.prod(spaces[k].shape)) for k in self.state_keys),), "names": None}
         features["action"] = {"dtype": "float32", "shape": tuple(action_space.shape), "names": None}
+        if key_aliases:  # e.g. REFERENCE_YAML_KEY_ALIASES: write the columns under the names a YAML-configured consumer expects
+            self.key_mapping_dict = {k: key_aliases.get(v, v) for k, v in self.key_mapping_dict.items()}
+            features = {key_aliases.get(k, k): v for k, v in features.items()}
         self.features = features
         (self.root_dataset_dir / "meta").mkdir(parents=True, exist_ok=True)
         (self.root_dataset_dir / "data" / "chunk-000").mkdir(parents=True, exist_ok=True)

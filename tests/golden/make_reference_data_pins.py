@@ -133,8 +133,31 @@ def literal_pins():
     return out
 
 
+def lerobot_config_pins():
+    """scripts/lerobot/configs/*.yaml (the reference's LeRobot training configs): what they say about the env's interface - task id,
+    fps, episode length, state / action widths, image size, the observation column names and their shapes. Numbers and key names only."""
+    import yaml
+
+    out = {}
+    for path in sorted((REF.parents[1] / "scripts" / "lerobot" / "configs").glob("*.yaml")):
+        cfg = yaml.safe_load(path.read_text())
+        env = cfg["env"]
+        shapes = cfg["policy"]["input_shapes"]
+        out[path.name] = {
+            "file": f"scripts/lerobot/configs/{path.name}",
+            "fps": cfg["fps"], "task": env["task"], "image_size": env["image_size"], "state_dim": env["state_dim"], "action_dim": env["action_dim"],
+            "episode_length": env["episode_length"],
+            "image_keys": {k: v for k, v in shapes.items() if k.startswith("observation.images.")},
+            "state_key": [k for k in shapes if k == "observation.state"],
+            "action_key": list(cfg["policy"]["output_shapes"].keys()),
+            "stats_keys": sorted(cfg.get("override_dataset_stats", {}).keys()),
+        }
+    return out
+
+
 if __name__ == "__main__":
     d = main()
+    d["lerobot_configs"] = lerobot_config_pins()
     d["literals"] = literal_pins()
     OUT.write_text(json.dumps(d, indent=1) + "\n")
     print("wrote", OUT, "with", len(d["literals"]), "source literals")
