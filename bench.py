@@ -56,6 +56,8 @@ def parse():
                          "(north_star's '4096 parallel Robot-Reach envs at 1/2/4/8 MI355X' read literally)")
     ap.add_argument("--n-objects", type=int, default=2, help="Planar-Push blocks: 2 = BASELINE config 4, 5 = the reference's dataclass default")
     ap.add_argument("--block-shape", default="mesh", choices=["mesh", "box"], help="Planar-Push blocks: the reference's meshes (default) or round 1's box stand-in")
+    ap.add_argument("--gripper-model", default="reduced", choices=["reduced", "articulated"],
+                    help="Button-Push: the one-coordinate 2F-85 of DESIGN.md D-1b (BASELINE config 5's kernel) or the articulated 2F-85 (SURVEY 8 f-1, nv = 14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", type=int, default=0, help="kernel variant for A/B profiling (0 = default)")
     ap.add_argument("--visual", type=int, default=0, metavar="RES",
@@ -97,13 +99,16 @@ def host_cores():
     return max(1, min(n, int(os.environ.get("MJS_BENCH_CORES", "16"))))
 
 
-def cpu_baseline(task, n_envs, seconds, n_objects=2, block_shape="mesh"):
+def cpu_baseline(task, n_envs, seconds, n_objects=2, block_shape="mesh", gripper_model="reduced"):
     import oracle
 
     tid = {"robot_reach": oracle.TASK_ROBOT_REACH, "point_mass_reach": oracle.TASK_POINTMASS, "robot_push_button": oracle.TASK_BUTTON_PUSH,
            "robot_planar_push": oracle.TASK_PLANAR_PUSH}[task]
     cores = host_cores()
-    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores, **({"n_objects": n_objects, "block_shape": oracle.BLOCKS_BOX if block_shape == "box" else oracle.BLOCKS_MESH} if task == "robot_planar_push" else {}))
+    kw = {"n_objects": n_objects, "block_shape": oracle.BLOCKS_BOX if block_shape == "box" else oracle.BLOCKS_MESH} if task == "robot_planar_push" else {}
+    if task == "robot_push_button" and gripper_model == "articulated":
+        kw["gripper_model"] = 1
+    b = oracle.OracleBatch(tid, n_envs, 2025, nthreads=cores, **kw)
     b.reset()
     acts = make_actions(task, 8, n_envs, "cpu", 12345).numpy()
     b.step(acts[0])  # warm
@@ -311,6 +316,8 @@ def main():
         import mujoco_sim_amd as m
 
         extra = {"n_objects": args.n_objects, "block_shape": args.block_shape} if args.task == "robot_planar_push" else {}
+        if args.task == "robot_push_button" and args.gripper_model == "articulated":
+            extra["gripper_model"] = "articulated"
         # global seeds: env i of the whole job <- RandomState(2025 + i) whatever the rank count (reach_sac.py:84 seeds sub-env rank with seed + rank)
         venv = m.HipVectorEnv(args.task, n_local, device=device, seed=2025, env_index_offset=rank * n_local, kernel_variant=args.variant, **extra)
         sync = lambda: torch.cuda.synchronize(device)  # noqa: E731
@@ -395,12 +402,13 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{args.task}: {n_local} envs per GPU, {substeps} substeps/step, "
                                    f"{'state obs' if not cams else 'visual obs'}, {'joint targets q_home +- U(0.2) + gripper opening U(0, 0.085)' if args.task == 'robot_push_button' else 'uniform workspace actions'}, next-step auto-reset"
-                                   + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else ""),
+                                   + (f", + {len(cams)} camera image(s) {args.visual}x{args.visual} per step" if cams else "")
+                                   + (", articulated Robotiq 2F-85 (nv = 14)" if (args.task == "robot_push_button" and args.gripper_model == "articulated") else ""),
                        "envs_per_gpu": n_local, "envs_total": n_global, "parallelism": f"env-sharded x{world}, no collective in the step",
                        "scaling_mode": ("weak: envs_per_gpu fixed, envs_total grows with the GPU count" if args.scaling == "weak" else
                                         "strong: envs_total fixed, envs_per_gpu = envs_total / n_gpus (a launch is latency-bound below ~16k envs per GPU: expect ~1x)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else measured_traffic(args.task, n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else (None if (args.task == "robot_push_button" and args.gripper_model == "articulated") else measured_traffic(args.task, n_local)), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }
@@ -425,7 +433,7 @@ def main():
             except Exception:  # noqa: BLE001
                 pass
         if world == 1 and not args.no_cpu_baseline and not args.stub:
-            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects, args.block_shape)
+            line["cpu_baseline"] = cpu_baseline(args.task, n_local, args.cpu_seconds, args.n_objects, args.block_shape, args.gripper_model)
             line["cpu_baseline"].update(mujoco_probe())  # "mujoco_on_box": asked on every run, acted on only when true
             if args.task == "robot_reach":
                 line["config1_single_env"] = single_env_figures(device)

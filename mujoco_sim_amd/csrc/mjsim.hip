@@ -196,11 +196,12 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   return p;
 }
 
-// envs per workgroup of the articulated-gripper kernel: 4 until every SIMD of a 256-CU chip has a wavefront (4096 envs), then
-// doubling with the batch (the LDS holds 16 envs of 9.6 KB)
+// envs per workgroup of the articulated-gripper kernel. The kernel is bound by instruction DELIVERY (its substep streams ~150 KB of
+// code through the instruction cache), so fewer, fuller wavefronts win as soon as every CU has one: 16 envs per workgroup (what
+// the LDS holds: 16 x 9.8 KB) from 4096 envs on - 11.7 ms per launch against 14.9 with 4 (profiles/r04_b_*)
 int bg_epw_for(int n) {
   if (const char* ev = std::getenv("MJS_BG_EPW")) { const int v = std::atoi(ev); if (v >= 1 && v <= 16) return v; }  // A/B experiments
-  return n <= 4096 ? 4 : n <= 8192 ? 8 : 16;
+  return n < 1024 ? 4 : n < 4096 ? 8 : 16;
 }
 
 constexpr int BLOCK = 64;  // one wavefront per workgroup: N/64 workgroups spread over the CUs

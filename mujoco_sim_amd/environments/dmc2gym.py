@@ -13,6 +13,7 @@ from collections import OrderedDict
 from typing import NamedTuple
 
 import numpy as np
+import torch
 
 from .. import _native as nat
 from ..spaces import Box, Dict
@@ -65,6 +66,15 @@ class HipEnvironment:
                                   observation_type=getattr(task, "observation_type", STATE_OBS),
                                   image_resolution=getattr(task, "image_resolution", 64), **kwargs)
         self._random_state = None
+        # one pinned host mirror of the env's output arena and one pinned action buffer (the SB3 adapter's scheme): a step costs
+        # ONE host->device copy (the action) and ONE device->host copy (every output field) instead of a sync per scalar
+        v = self._venv
+        self._host_arena = torch.empty(v._arena.shape, dtype=torch.uint8, pin_memory=True)
+        self._host = {name: self._host_arena[o:o + nb].view(dt).view(shape).numpy() for name, dt, shape, o, nb in v._arena_layout}
+        self._act_host = torch.empty(1, v.action_dim, dtype=torch.float64, pin_memory=True)
+        self._act_dev = torch.empty(1, v.action_dim, dtype=torch.float64, device=v.device)
+        self._visual = v._img is not None
+        self._layout = [e for e in v.spec.obs_layout if e[0] in v._visual_keys] if self._visual else list(v._state_layout)
         if random_state is not None:
             self.seed(random_state)
 
@@ -88,12 +98,26 @@ class HipEnvironment:
         return spec
 
     def _timestep(self) -> TimeStep:
-        b = self._venv._buf
-        st = int(b["step_type"][0].item())
-        obs = OrderedDict((k, v[0].cpu().numpy().copy()) for k, v in self._venv._obs_dict(b["obs"]).items())
+        v = self._venv
+        images = None
+        if self._visual:  # renders the camera image(s) on the env's stream; they are copied on their own
+            images = [(k, t) for k, t in v._obs_dict(v._buf["obs"]).items() if t.dtype == torch.uint8]
+        self._host_arena.copy_(v._arena, non_blocking=True)
+        if images is not None:
+            images = [(k, t[0].cpu().numpy().copy()) for k, t in images]
+        torch.cuda.current_stream(v.device).synchronize()
+        h = self._host
+        st = int(h["step_type"][0])
+        flat = h["obs"][0]
+        obs = OrderedDict((k, flat[s:s + n].copy()) for k, s, n in self._layout)
+        if images is not None:
+            for k, img in images:
+                obs[k] = img
+            obs = OrderedDict((k, obs[k]) for k in v.single_observation_space.keys())  # the reference's dict order
+        self._is_success = bool(h["is_success"][0])
         if st == nat.STEP_FIRST:
             return TimeStep(st, None, None, obs)
-        return TimeStep(st, float(b["reward"][0].item()), float(b["discount"][0].item()), obs)
+        return TimeStep(st, float(h["reward"][0]), float(h["discount"][0]), obs)
 
     def reset(self) -> TimeStep:
         self._venv.reset()
@@ -102,12 +126,14 @@ class HipEnvironment:
     def step(self, action) -> TimeStep:
         a = np.asarray(action)
         assert a.shape == (self._venv.action_dim,)  # point_reach.py:158 / robot_reach.py:167
-        self._venv.step(a.astype(np.float64)[None])
+        self._act_host.numpy()[0] = a
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        self._venv.step_flat(self._act_dev)
         return self._timestep()
 
     @property
     def is_success(self) -> bool:
-        return bool(self._venv._buf["is_success"][0].item())
+        return self._is_success
 
     def close(self):
         self._venv.close()

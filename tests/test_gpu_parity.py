@@ -2169,3 +2169,35 @@ def test_articulated_gripper_follows_move_and_shards(oracle_mod):
         assert torch.equal(sh.get_state()[:-1], whole[:-1, 16 * k:16 * k + 16]), k
         sh.close()
     venv.close()
+
+
+def test_rccl_backend_initialises_and_gathers_a_rollout_block():
+    """SCALE was skipped three rounds running, so the first multi-GPU run must not be the first time `nccl` (= RCCL) initialises:
+    a fresh child process inits the backend with world size 1 on the one GPU gpurun gives, runs dist.all_gather_into_tensor on a
+    device rollout block directly (mujoco_sim_amd.distributed.gather_rollout returns early at world size 1), the max-over-ranks
+    all_reduce and a barrier; then `bench.py --gpus 1` runs under torch.distributed.run --nproc-per-node 1, the driver's launch
+    shape for N > 1. No scaling claim follows from this."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    root = Path(__file__).resolve().parents[1]
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    res = subprocess.run([sys.executable, str(root / "tests" / "_rccl_child.py"), str(port)], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line == {"backend": "nccl", "world": 1, "gather_identical": True, "bytes": 256 * 8 * 12 * 8}
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port + 1),
+                          str(root / "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    bl = json.loads(lines[0])
+    assert bl["n_gpus"] == 1 and bl["steps"] == 5 and bl["value"] > 1e6
