@@ -95,10 +95,9 @@ struct World {
   Block b[NB];
 };
 
-MJS_DEV World load_world(const KernelParams& p, int i) {
+MJS_DEV World load_world_at(const double* base, size_t N, int i) {
   World s;
-  const size_t N = p.N;
-  const double* st = p.state + i;
+  const double* st = base + i;
 #pragma unroll
   for (int j = 0; j < NJ; j++) { s.q[j] = st[(S_Q + j) * N]; s.v[j] = st[(S_V + j) * N]; }
   s.time = st[S_TIME * N];
@@ -117,9 +116,9 @@ MJS_DEV World load_world(const KernelParams& p, int i) {
   }
   return s;
 }
-MJS_DEV void store_world(const KernelParams& p, int i, const World& s) {
-  const size_t N = p.N;
-  double* st = p.state + i;
+MJS_DEV World load_world(const KernelParams& p, int i) { return load_world_at(p.state, (size_t)p.N, i); }
+MJS_DEV void store_world_at(double* base, size_t N, int i, const World& s) {
+  double* st = base + i;
 #pragma unroll
   for (int j = 0; j < NJ; j++) { st[(S_Q + j) * N] = s.q[j]; st[(S_V + j) * N] = s.v[j]; }
   st[S_TIME * N] = s.time;
@@ -137,6 +136,22 @@ MJS_DEV void store_world(const KernelParams& p, int i, const World& s) {
     bs[13 * N] = s.b[b].shape; bs[14 * N] = s.b[b].scale;
   }
 }
+MJS_DEV void store_world(const KernelParams& p, int i, const World& s) { store_world_at(p.state, (size_t)p.N, i, s); }
+// The handle's state buffer has a SECOND SLOT per env: rows [STATE_DIM, 2 STATE_DIM) hold the env's NEXT episode while it is being
+// prepared (the draws of initialize_episode + as many of its 150 settle steps as have run), row 2 STATE_DIM how far that has got:
+// -1 nothing drawn yet, 0 .. 149 settle steps done, 150 ready. An env's reset is a function of its own RNG stream only, so it can be
+// worked out ahead of time: in launches with p.prefetch the grid's second half are prefetch workgroups that advance the next-episode
+// slot of the envs of their group by PREFETCH_CHUNK substeps per launch, on CUs the stepping workgroups leave idle; when an
+// episode ends, the next launch swaps the slots (no settle steps inside a step launch). Ownership is decided by what both roles
+// read at launch start: an env whose reset is pending belongs to the stepping workgroup (which finishes whatever is missing
+// inline: the old path, bit for bit the same arithmetic), every other env's second slot to the prefetch workgroup. mjs_seed
+// empties the slot; mjs_get_state / mjs_set_state carry it (a checkpoint resumes with the prepared episode).
+// Rows PROG_ROW + 1 .. + 6: the prepared episode's reset joints = the servo set-point of its settle steps (robot.py:185-189); the
+// next 12: the carried cos / sin of its joint angles (the substep loop updates them incrementally: with them in the slot a settle
+// phase that is cut into chunks is bit for bit the uninterrupted one, so WHEN the chunks ran - which depends on the order in
+// which a launch's workgroups start - cannot show in any result).
+constexpr int NEXT_ROW0 = STATE_DIM, PROG_ROW = 2 * STATE_DIM, CTRL_ROW0 = PROG_ROW + 1, CS_ROW0 = CTRL_ROW0 + NJ, FULL_STATE_DIM = CS_ROW0 + 2 * NJ;
+constexpr int PREFETCH_CHUNK = 10;
 
 MJS_DEV M3 quat_to_m3(const double* q) {  // unit quaternion -> rotation (columns = body axes in the world)
   const double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -2155,22 +2170,40 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     for (int k = threadIdx.x; k < HULL_LDS_DOUBLES; k += 64 * WAVES) dst[k] = src[k];
     __syncthreads();
   }
-  const int gi = (blockIdx.x * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
+  const int groups = (int)gridDim.x >> ((!IS_RESET && p.prefetch) ? 1 : 0);
+  const bool prefetcher = !IS_RESET && p.prefetch && (int)blockIdx.x >= groups;
+  const int wg = prefetcher ? (int)blockIdx.x - groups : (int)blockIdx.x;
+  const int gi = (wg * WAVES + (threadIdx.x >> 6)) * EPW + (threadIdx.x & 63);
   const bool valid = (threadIdx.x & 63) < EPW && gi < p.N;
   const int i = valid ? gi : 0;  // helper / padding lanes shadow env 0 and never write
   const int nb = p.n_objects;
   uint8_t flags = p.flags[i];
   double obs[OBS_DIM], cs[NJ], sn[NJ], ctrl0[NJ], q0[NJ], q1[NJ];
   World s;
+  double* const next_base = p.state + (size_t)NEXT_ROW0 * p.N;
+  double* const prog_row = p.state + (size_t)PROG_ROW * p.N;
+  int prog = valid ? (int)prog_row[i] : -1;  // how far the env's next episode has been prepared (see NEXT_ROW0)
   const bool masked_out = IS_RESET && p.reset_mask && !p.reset_mask[i];
-  const bool resetting = valid && !masked_out && (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP));
-  const bool stepping = valid && !IS_RESET && !resetting;
+  const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
+  const bool resetting = valid && !prefetcher && !masked_out && (IS_RESET || pending);
+  const bool stepping = valid && !prefetcher && !IS_RESET && !resetting;
+  const bool filling = valid && prefetcher && !pending && prog < MJS_PP_SETTLE_STEPS;
+  if (prefetcher && !__syncthreads_or(filling)) return;  // nothing to prepare in this group
   double t0 = 0, t1 = 1, inv_span = 1;
   int nsub = 0;
-  if (resetting) {
-    episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
-    nsub = MJS_PP_SETTLE_STEPS;
-    for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189)
+  bool carried = false;  // the slot holds the cos / sin rows of a settle phase that is under way
+  if (resetting || filling) {
+    if (prog >= 0) {  // drawn earlier (and settled for `prog` steps)
+      s = load_world_at(next_base, (size_t)p.N, i);
+      for (int j = 0; j < NJ; j++) ctrl0[j] = p.state[(size_t)(CTRL_ROW0 + j) * p.N + i];
+      carried = prog > 0;
+    } else {
+      episode_draws(p.rng, i, nb, s, valid, p.block_shape == MJS_BLOCKS_MESH);
+      prog = 0;
+      for (int j = 0; j < NJ; j++) ctrl0[j] = s.q[j];  // Robot.set_joint_positions leaves ctrl = the reset joints (robot.py:185-189)
+    }
+    nsub = MJS_PP_SETTLE_STEPS - prog;  // 0 when the episode was ready: a reset is then a swap of the slots
+    if (filling && nsub > PREFETCH_CHUNK) nsub = PREFETCH_CHUNK;
   } else if (stepping) {
     s = load_world(p, i);
     // before_step (base.py:31-32, robot_planar_push.py:185-201)
@@ -2187,6 +2220,8 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     s = load_world(p, i);
   }
   for (int j = 0; j < NJ; j++) sincos(s.q[j], &sn[j], &cs[j]);
+  if (carried)
+    for (int j = 0; j < NJ; j++) { cs[j] = p.state[(size_t)(CS_ROW0 + j) * p.N + i]; sn[j] = p.state[(size_t)(CS_ROW0 + NJ + j) * p.N + i]; }
   if (!valid) nsub = 0;  // helper lanes only take part in the cooperative solves
   StepInfo info{false, false, false, 0};
 #ifdef MJS_STAMPS
@@ -2236,6 +2271,18 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     for (int j = 0; j < NJ; j++) { cs[j] = env.cs[j]; sn[j] = env.sn[j]; }
     info = env.info;
     // ncon of the state just reached (mj_step1 of the last substep): by the env groups where the detection results live in LDS
+    if (prefetcher) {  // the prepared episode goes back to its slot; nothing is reported
+      if (filling) {
+        store_world_at(next_base, (size_t)p.N, i, s);
+        prog_row[i] = (double)(prog + nsub);
+        for (int j = 0; j < NJ; j++) {
+          p.state[(size_t)(CTRL_ROW0 + j) * p.N + i] = ctrl0[j];
+          p.state[(size_t)(CS_ROW0 + j) * p.N + i] = cs[j];
+          p.state[(size_t)(CS_ROW0 + NJ + j) * p.N + i] = sn[j];
+        }
+      }
+      return;
+    }
     const int ncon_now = count_contacts_group(nb, valid && (pass == 0 ? (resetting || stepping) : again));
     if (pass == 1) {
       if (again) {
@@ -2258,8 +2305,11 @@ __global__ __launch_bounds__(64 * WAVES) void kernel(KernelParams p) {
     bad = info.bad;
     if (resetting) {
       const int ncon = ncon_now;
+      for (int j = 0; j < NJ; j++) bad = bad || bad_value(s.q[j]) || bad_value(s.v[j]);  // (a prepared episode's settle ran in earlier launches)
+      for (int b = 0; b < nb; b++) bad = bad || bad_value(s.b[b].p.x) || bad_value(s.b[b].p.y) || bad_value(s.b[b].p.z);
       if (valid) {
         store_world(p, i, s);
+        prog_row[i] = -1.0;  // the next-episode slot is consumed
         p.flags[i] = 0;
         make_obs(s, cs, sn, nb, obs);
         write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, bad ? MJS_FAULT_BAD_STATE : 0, ncon);

@@ -92,6 +92,10 @@ __global__ __launch_bounds__(64) void seed_kernel(DevRng rng, uint32_t base_seed
 // Pointmass bookkeeping starts at 1.0 at construction (point_reach.py:112-113); flags = reset pending
 // host_pending: the byte of an env that waits for its next-step reset, as the host writes it (reset-groups handles: with the
 // parity OPPOSITE to the next step launch's, i.e. "ended in an earlier launch", mjs_kernel_common.h)
+__global__ void fill_row_kernel(double* row, int N, double value) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) row[i] = value;
+}
 __global__ void init_kernel(double* state, uint8_t* flags, int N, int task, uint8_t host_pending) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
@@ -161,6 +165,7 @@ __global__ void tcp_to_joints_kernel(const double* pos, const double* guess, dou
   ok[i] = found;
 }
 
+int push_prog_row(const mjs_handle* h) { return h->cfg.n_objects > MJS_PP_FAST_OBJECTS ? pp5::PROG_ROW : pp::PROG_ROW; }
 bool articulated(const mjs_handle* h) { return h->cfg.task == MJS_TASK_BUTTON_PUSH && h->cfg.gripper_model == MJS_GRIPPER_ARTICULATED; }
 bool uses_reset_groups(const mjs_handle* h) {
   if (articulated(h)) return false;  // one kernel shape: a workgroup resets its own envs
@@ -184,6 +189,9 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.block_shape = h->cfg.block_shape;
   p.epoch = h->epoch;
   p.reset_groups = uses_reset_groups(h);
+  // Planar-Push: next episodes are prepared ahead of time by prefetch workgroups (mjs_push_impl.h NEXT_ROW0); variant 1 keeps
+  // round 3's behaviour (the settle steps of a reset run inside the step launch) for A/B measurements
+  p.prefetch = h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP && h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
   p.time_limit = h->cfg.time_limit;
   p.state = h->state;
   p.flags = h->flags;
@@ -212,9 +220,9 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
   bool flip_epoch = false;
   if (h->cfg.task == MJS_TASK_POINTMASS_REACH) pm::kernel<IS_RESET><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects <= MJS_PP_FAST_OBJECTS)
-    pp::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES))), BLOCK * pp::WAVES, pp::LDS_BYTES, s>>>(p);
+    pp::kernel<IS_RESET><<<dim3((unsigned)(((!IS_RESET && p.prefetch) ? 2 : 1) * ((p.N + pp::EPW * pp::WAVES - 1) / (pp::EPW * pp::WAVES)))), BLOCK * pp::WAVES, pp::LDS_BYTES, s>>>(p);
   else if (h->cfg.task == MJS_TASK_PLANAR_PUSH)  // 3..5 blocks: the 5-slot instance, its cooperative workspace needs the large-LDS opt-in (mjs_create)
-    pp5::kernel<IS_RESET><<<dim3((unsigned)((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
+    pp5::kernel<IS_RESET><<<dim3((unsigned)(((!IS_RESET && p.prefetch) ? 2 : 1) * ((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES)))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
   else if (articulated(h)) {
     const int epw = bg_epw_for(p.N);
     bg::kernel<IS_RESET><<<dim3((unsigned)((p.N + epw - 1) / epw)), BLOCK, (size_t)epw * sizeof(bg::Env), s>>>(p, h->ws14, epw);
@@ -268,7 +276,7 @@ int mjs_action_dim_for(int task, int action_type) {
 }
 int mjs_action_dim(int task) { return mjs_action_dim_for(task, MJS_ACTION_ABS_JOINT); }
 int mjs_state_dim(int task) {
-  return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : task == MJS_TASK_BUTTON_PUSH ? bp::STATE_DIM + 1 : task == MJS_TASK_PLANAR_PUSH ? pp::STATE_DIM + 1 : -1;
+  return task == MJS_TASK_POINTMASS_REACH ? pm::STATE_DIM + 1 : task == MJS_TASK_ROBOT_REACH ? rr::STATE_DIM + 1 : task == MJS_TASK_BUTTON_PUSH ? bp::STATE_DIM + 1 : task == MJS_TASK_PLANAR_PUSH ? pp::FULL_STATE_DIM + 1 : -1;
 }
 int mjs_env_obs_dim(const mjs_handle* h) { return h ? h->obs_dim : -1; }
 int mjs_env_state_dim(const mjs_handle* h) { return h ? h->state_dim + 1 : -1; }
@@ -322,7 +330,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
   if (!(h->cfg.time_limit > 0)) h->cfg.time_limit = default_time_limit(cfg->task);
   h->state_dim = mjs_state_dim(cfg->task) - 1;
   h->obs_dim = mjs_obs_dim(cfg->task);
-  if (cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) { h->state_dim = pp5::STATE_DIM; h->obs_dim = pp5::OBS_DIM; }
+  if (cfg->task == MJS_TASK_PLANAR_PUSH && h->cfg.n_objects > MJS_PP_FAST_OBJECTS) { h->state_dim = pp5::FULL_STATE_DIM; h->obs_dim = pp5::OBS_DIM; }
   if (cfg->task == MJS_TASK_BUTTON_PUSH && h->cfg.gripper_model == MJS_GRIPPER_ARTICULATED) h->state_dim = bg::STATE_DIM;
   h->act_dim = mjs_action_dim_for(cfg->task, cfg->action_type);
   h->state = nullptr; h->flags = nullptr; h->rng_mt = nullptr; h->rng_pos = nullptr; h->stamps = nullptr; h->prims = nullptr; h->cams = nullptr;
@@ -385,6 +393,7 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
     }
   }
   init_kernel<<<grid_for((int)N), BLOCK>>>(h->state, h->flags, (int)N, cfg->task, host_pending_byte(h));
+  if (cfg->task == MJS_TASK_PLANAR_PUSH) fill_row_kernel<<<grid_for((int)N), BLOCK>>>(h->state + (size_t)push_prog_row(h) * N, (int)N, -1.0);  // no next episode prepared
   seed_kernel<<<grid_for((int)N), BLOCK>>>(DevRng{h->rng_mt, h->rng_pos, (int)N}, 0u, cfg->env_index_offset);
   e = hipDeviceSynchronize();
   if (e != hipSuccess) {
@@ -453,6 +462,8 @@ int mjs_seed(mjs_handle* h, uint32_t base_seed, void* stream) {
   HIP_TRY(h, dev_.err);
   seed_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(DevRng{h->rng_mt, h->rng_pos, h->cfg.num_envs}, base_seed,
                                                                            h->cfg.env_index_offset);
+  if (h->cfg.task == MJS_TASK_PLANAR_PUSH)  // episodes prepared from the old streams are void
+    fill_row_kernel<<<grid_for(h->cfg.num_envs), BLOCK, 0, (hipStream_t)stream>>>(h->state + (size_t)push_prog_row(h) * h->cfg.num_envs, h->cfg.num_envs, -1.0);
   HIP_TRY(h, hipGetLastError());
   return MJS_OK;
 }

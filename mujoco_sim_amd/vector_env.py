@@ -188,7 +188,10 @@ class HipVectorEnv:
         self.action_dim = self._lib.mjs_action_dim_for(self.spec.task_id, _ACTION_IDS.get(action_type, 0))
         self.state_dim = self._lib.mjs_env_state_dim(h)
         self.algorithmic_bytes_per_env_step = self._lib.mjs_algorithmic_bytes_per_env_step(self.spec.task_id)
-        if self.state_dim != self._lib.mjs_state_dim(self.spec.task_id):  # Planar-Push, 5 block slots: same formula, wider rows
+        if task == "robot_planar_push" and self.state_dim != self._lib.mjs_state_dim(self.spec.task_id):  # 5 block slots: same formula, wider rows
+            S = (self.state_dim - 2 - 18) // 2  # rows of ONE world (the state also carries the next-episode slot, its progress row and its servo set-point)
+            self.algorithmic_bytes_per_env_step = 8 * S + 8 * (S - 3) + 2 + 8 * self.action_dim + 8 * self.obs_dim + 25
+        elif self.state_dim != self._lib.mjs_state_dim(self.spec.task_id):  # Button-Push with the articulated gripper: wider state
             S = self.state_dim - 1
             self.algorithmic_bytes_per_env_step = 8 * S + 8 * (S - 3) + 2 + 8 * self.action_dim + 8 * self.obs_dim + 25
         N, dev = self.num_envs, self.device

@@ -48,7 +48,7 @@ def test_static_queries(native):
     assert L.mjs_version().startswith(b"mjsim-hip")
     assert (L.mjs_obs_dim(0), L.mjs_action_dim(0), L.mjs_substeps(0)) == (4, 2, 5)
     assert (L.mjs_obs_dim(1), L.mjs_action_dim(1), L.mjs_substeps(1)) == (12, 3, 20)
-    assert (L.mjs_obs_dim(2), L.mjs_action_dim(2), L.mjs_substeps(2), L.mjs_state_dim(2)) == (9, 2, 20, 48)   # Planar-Push, 2 block slots
+    assert (L.mjs_obs_dim(2), L.mjs_action_dim(2), L.mjs_substeps(2), L.mjs_state_dim(2)) == (9, 2, 20, 2 * 47 + 1 + 6 + 12 + 1)   # Planar-Push, 2 block slots: current world + prepared next episode (+ progress, set-point, cos / sin) + flags
     assert (L.mjs_obs_dim(3), L.mjs_action_dim(3), L.mjs_substeps(3)) == (13, 7, 20)                            # Button-Push
     assert (L.mjs_action_dim_for(3, 0), L.mjs_action_dim_for(3, 1), L.mjs_action_dim_for(3, 2), L.mjs_action_dim_for(1, 5)) == (7, 4, -1, 3)
     assert L.mjs_obs_dim(99) == -1

@@ -15,7 +15,8 @@ from bench import make_actions  # noqa: E402
 N = 4096
 TIME_ROW = 12  # S_TIME of the three robot scenes
 for task in sys.argv[1:] or ["robot_reach", "robot_push_button", "robot_planar_push"]:
-    for desync, variant in ((False, 0), (True, 0)) + (((False, 3), (True, 3)) if task in ("robot_reach", "robot_push_button") else ()):
+    # variants: Robot-Reach / Button-Push 3 = reset workgroups; Planar-Push 1 = round 3's behaviour (settle steps inside the step launch), 0 = prefetched episodes
+    for desync, variant in ((False, 0), (True, 0)) + (((False, 3), (True, 3)) if task in ("robot_reach", "robot_push_button") else ((False, 1), (True, 1))):
         kw = {"max_episode_steps": 100} if task == "robot_planar_push" else {}
         venv = m.HipVectorEnv(task, N, seed=0, kernel_variant=variant, **kw)
         acts = make_actions(task, 64, N, "cuda", 1)

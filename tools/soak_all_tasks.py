@@ -76,7 +76,7 @@ def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_
 
 
 rs = np.random.RandomState(123 + SEED_SHIFT)
-which = sys.argv[1:] or ["reach_box", "reach_success", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "pointmass"]  # (Planar-Push: its own tests carry the conditioning mask that contact-rich free bodies need)
+which = sys.argv[1:] or ["reach_box", "reach_success", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "planar_push", "pointmass"]
 if "reach_box" in which:
     run("Robot-Reach, workspace actions, 3 episodes", "robot_reach", oracle.TASK_ROBOT_REACH, 4096, 250, lambda t: rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (4096, 3)), 11)
 if "reach_success" in which:
@@ -107,6 +107,65 @@ if "button_joint_nominal" in which:
     nominal = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04])
     run("Button-Push, joint actions around the nominal pose", "robot_push_button", oracle.TASK_BUTTON_PUSH, 2048, 220,
         lambda t: nominal + rs.uniform(-1, 1, (2048, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04]), 15)
+def run_push(name, shape, N=2048, LIMIT=40, T=85, seed=31):
+    """Planar-Push with the conditioning rule of tests/test_gpu_parity.py::_check_ill_conditioned_envs: a second oracle whose resets are perturbed by
+    1e-13 m measures every env's sensitivity; calm envs (< 1e-10) are held to 1e-6 (worst value reported) and exact flags / contact counts, the others to the episode
+    bookkeeping exactly, no bad state, and an error of at most max(1e-6, 100 x their own sensitivity)."""
+    global bad_total
+    import ctypes as C
+    t0 = time.time()
+    knob = C.c_double.in_dll(oracle.lib(), "om_dbg_perturb")
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=seed + SEED_SHIFT, max_episode_steps=LIMIT, block_shape=shape)
+    okw = dict(nthreads=16, max_episode_steps=LIMIT, block_shape=1 if shape == "box" else 0)
+    ob, ob2 = oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, seed + SEED_SHIFT, **okw), oracle.OracleBatch(oracle.TASK_PLANAR_PUSH, N, seed + SEED_SHIFT, **okw)
+    venv.reset()
+    o = ob.reset()
+    knob.value = 1e-13
+    o2 = ob2.reset()
+    knob.value = 0.0
+    sens = np.abs(o["obs"] - o2["obs"]).max(axis=1) > 1e-10
+    prs = np.random.RandomState(9 + SEED_SHIFT)
+    n_div = n_last = 0
+    worst_calm = 0.0
+    frac = []
+    for t in range(T):
+        tcp, blk = o["obs"][:, :2], o["obs"][:, 5:7]
+        a = tcp + np.clip(blk - tcp, -0.02, 0.02) + prs.uniform(-0.004, 0.004, (N, 2))
+        venv.step(torch.from_numpy(a))
+        o = ob.step(a)
+        knob.value = 1e-13
+        o2 = ob2.step(a)
+        knob.value = 0.0
+        dev = np.abs(o["obs"] - o2["obs"]).max(axis=1)
+        fresh = (o["step_type"] != 1) & (o2["step_type"] != 1)
+        sens = np.where(fresh, dev > 1e-12, sens | (dev > 1e-10))
+        g = _gpu_result(venv)
+        err = np.abs(g["obs"] - o["obs"]).max(axis=1)
+        calm_bad = ~sens & (err > 1e-6)  # (the solvers stop at MuJoCo's tolerance 1e-8 on the scaled gradient: calm envs differ by up to 1e-7)
+        for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
+            calm_bad |= ~sens & (np.asarray(g[k]).astype(np.int64) != np.asarray(o[k]).astype(np.int64))
+        same = np.asarray(o["step_type"]) == np.asarray(o2["step_type"])
+        wild_bad = sens & same & (err > np.maximum(1e-6, 100 * dev))
+        for k in ("step_type", "terminated", "truncated"):
+            wild_bad |= sens & (np.asarray(g[k]).astype(np.int64) != np.asarray(o[k]).astype(np.int64))
+        wild_bad |= sens & ((np.asarray(g["fault"]).astype(np.int64) & 1) > 0)
+        if calm_bad.any() or wild_bad.any():
+            print(f"  {name} step {t}: calm envs off {np.nonzero(calm_bad)[0][:8]} (|d obs| {err[calm_bad][:8]}, own sensitivity {dev[calm_bad][:8]}), "
+                  f"ill-conditioned envs beyond their bound {np.nonzero(wild_bad)[0][:8]}")
+        n_div += int(calm_bad.sum() + wild_bad.sum())
+        worst_calm = max(worst_calm, float(err[calm_bad].max(initial=0.0)))
+        sens = sens | calm_bad  # reported once: the env sits out the rest of its episode like an ill-conditioned one
+        n_last += int((np.asarray(g["step_type"]) == 2).sum())
+        frac.append(sens.mean())
+    venv.close()
+    bad_total += n_div
+    print(f"{name}: {N} envs x {T} steps, env-episodes off their bound {n_div} (worst |d obs| of a calm env {worst_calm:.2e}), ill-conditioned fraction mean {np.mean(frac):.4f} "
+          f"max {np.max(frac):.4f}, episode ends {n_last}, {time.time() - t0:.0f} s", flush=True)
+
+
+if "planar_push" in which:
+    run_push("Planar-Push, mesh blocks, 2 episodes", "mesh")
+    run_push("Planar-Push, box blocks, 2 episodes", "box", seed=33)
 if "pointmass" in which:
     run("Pointmass-Reach, 4 episodes", "point_mass_reach", oracle.TASK_POINTMASS, 4096, 420, lambda t: rs.uniform(-0.1, 0.1, (4096, 2)).astype(np.float32).astype(np.float64), 16, atol=1e-9)
 print("soak:", "OK" if bad_total == 0 else f"{bad_total} divergence(s)")
