@@ -20,8 +20,13 @@ import re
 import sys
 
 COPY_LIKE = re.compile(r"v_accvgpr_(write|read)_b32|v_mov_b(32|64)_e32 v\S+, v|(scratch|buffer)_(store|load)\S* .*Folded (Spill|Reload)")
-SCALAR_OK = re.compile(r"s_(mov|waitcnt|nop|add|sub|and|or|andn2|xor|lshl|lshr|cselect|cmp)\S*\s|v_(readlane|writelane)_b32")
-EXEC_RESTORE = re.compile(r"s_or_b64 exec, exec, ")
+# Round 4: the scan no longer stops at the first scalar instruction it does not know: ANY scalar instruction that is not a
+# branch and does not write exec may sit between the label and the restore (an s_load, an s_waitcnt, address arithmetic ...), and the
+# restore itself may be spelled `s_or_b64 exec, exec, sX`, `s_mov_b64 exec, sX` or `s_or_saveexec_b64` (the `else` entry).
+SCALAR_OK = re.compile(r"s_(?!cbranch|branch|endpgm|setpc|swappc|call|barrier|trap|sleep)\w+\s|v_(readlane|writelane|readfirstlane)_b32")
+# (`s_or_saveexec_b64 sX, -1` is the whole-wave prologue / epilogue of an out-of-line function - callee-saved VGPR spills of ALL lanes -
+# not a join: only the register form counts)
+EXEC_RESTORE = re.compile(r"s_or_b64 exec, exec, |s_mov_b64 exec, s|s_or_saveexec_b64 s\[\d+:\d+\], s")
 
 
 def lint(lines):
@@ -42,7 +47,7 @@ def lint(lines):
                 if copies:
                     findings.append((fn, l.split(":")[0], copies, t))
                 break
-            if "exec" in t.split(";")[0]:
+            if "exec" in t.split(";")[0]:  # any other reader / writer of the mask ends the block prologue
                 break
             if COPY_LIKE.match(t):
                 copies.append(t.split(";")[0].strip())

@@ -51,3 +51,27 @@ def test_copy_ahead_of_the_exec_restore_is_found():
 def test_sound_joins_pass():
     # a copy ahead of a saveexec (the `then` block of a nested if), a copy after the restore, real work ahead of a restore
     assert lint(SOUND.split("\n")) == []
+
+
+WIDER = """
+_ZN2bg9st_forcesEPdm:
+.LBB7_12:
+\ts_load_dwordx2 s[4:5], s[0:1], 0x10
+\ts_waitcnt lgkmcnt(0)
+\ts_mul_i32 s6, s6, s7
+\tscratch_load_dwordx2 v[76:77], off, s6 ; 8-byte Folded Reload
+\ts_mov_b64 exec, s[8:9]
+.LBB7_13:
+\ts_bfe_u32 s2, s3, 0x10008
+\tv_accvgpr_read_b32 v5, a9
+\ts_or_saveexec_b64 s[10:11], s[12:13]
+.Lfunc_end7:
+"""
+
+
+def test_round4_widening_scalar_loads_and_other_restore_forms():
+    """a split copy placed after a scalar instruction the old table did not list (an s_load, an s_mul), and restores
+    written as `s_mov_b64 exec` / `s_or_saveexec_b64`, are findings too."""
+    found = lint(WIDER.split("\n"))
+    assert [f[1] for f in found] == [".LBB7_12", ".LBB7_13"]
+    assert found[0][3].startswith("s_mov_b64 exec") and found[1][3].startswith("s_or_saveexec_b64")
