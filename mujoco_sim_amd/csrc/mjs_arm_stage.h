@@ -95,7 +95,7 @@ MJS_DEV void plane_cylinder_contacts(V3 gp, V3 axis, V3 xaxis, double rad, doubl
   if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
   V3 vec = prjaxis * axis - v3(0, 0, 1);
   const double len = sqrt(dot(vec, vec));
-  if (len < 1e-12) vec = rad * xaxis;
+  if (len < MJS_MINVAL) vec = rad * xaxis;
   else vec = (rad / len) * vec;
   const double prjvec = vec.z;
   axis = half * axis;
@@ -107,12 +107,12 @@ MJS_DEV void plane_cylinder_contacts(V3 gp, V3 axis, V3 xaxis, double rad, doubl
   if (dd <= 0) emit(v3(gp.x + vec.x - axis.x, gp.y + vec.y - axis.y, gp.z + vec.z - axis.z - dd * 0.5), dd);
   V3 side = cross(vec, axis);
   const double sl = sqrt(dot(side, side));
-  if (sl > 1e-12) {
+  if (sl > MJS_MINVAL) {
     side = (rad * sqrt(3.0) * 0.5 / sl) * side;
     dd = dist0 + prjaxis - 0.5 * prjvec;
     if (dd <= 0) {
 #pragma unroll
-      for (int s = -1; s <= 1; s += 2)
+      for (int s = 1; s >= -1; s -= 2)  // point A = +side first, then B = -side (mjc_PlaneCylinder's order)
         emit(v3(gp.x + s * side.x + axis.x - 0.5 * vec.x, gp.y + s * side.y + axis.y - 0.5 * vec.y, gp.z + s * side.z + axis.z - 0.5 * vec.z - dd * 0.5), dd);
     }
   }

@@ -500,7 +500,7 @@ MJS_DEV void collision(const Model& m, Env& e) {
       double vec[3], pos[3];
       for (int k = 0; k < 3; k++) vec[k] = ax[k] * prjaxis - up[k];
       const double len = sqrt(dot3(vec, vec));
-      if (len < 1e-12) {  // disk parallel to the plane: the geom's x axis scaled by the radius
+      if (len < MJS_MINVAL) {  // disk parallel to the plane: the geom's x axis scaled by the radius
         double col0[3];
         mat_vec(e.xmat[b], m.col_xaxis[g], col0);
         for (int k = 0; k < 3; k++) vec[k] = col0[k] * rad;
@@ -522,11 +522,11 @@ MJS_DEV void collision(const Model& m, Env& e) {
       double side[3];
       cross3(vec, ax, side);
       const double sl = sqrt(dot3(side, side));
-      if (sl > 1e-12) {
+      if (sl > MJS_MINVAL) {
         for (int k = 0; k < 3; k++) side[k] *= rad * sqrt(3.0) * 0.5 / sl;
         dd = dist0 + prjaxis - 0.5 * prjvec;
         if (dd <= 0)
-          for (int s = -1; s <= 1; s += 2) {
+          for (int s = 1; s >= -1; s -= 2) {  // point A = +side first, then B = -side
             for (int k = 0; k < 3; k++) pos[k] = gp[k] + s * side[k] + ax[k] - 0.5 * vec[k] - up[k] * dd * 0.5;
             add_contact(e, dd, pos, up, -1, b, default_pair(), tran, false);
           }

@@ -971,7 +971,7 @@ MJS_DEV int count_floor_contacts(const Chain& c) {
       if (prjaxis > 0) { axis = -axis; prjaxis = -prjaxis; }
       V3 vec = prjaxis * axis - nrm;
       double len = sqrt(dot(vec, vec));
-      if (len < 1e-12) vec = rad * R.cx;
+      if (len < MJS_MINVAL) vec = rad * R.cx;
       else vec = (rad / len) * vec;
       double prjvec = vec.z;
       axis = half * axis;
@@ -980,7 +980,7 @@ MJS_DEV int count_floor_contacts(const Chain& c) {
       n += 1;
       n += (dist0 - prjaxis + prjvec <= 0);
       V3 side = cross(vec, axis);
-      if (sqrt(dot(side, side)) > 1e-12 && dist0 + prjaxis - 0.5 * prjvec <= 0) n += 2;
+      if (sqrt(dot(side, side)) > MJS_MINVAL && dist0 + prjaxis - 0.5 * prjvec <= 0) n += 2;
     }
   }
   return n;

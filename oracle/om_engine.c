@@ -353,7 +353,8 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
       add_contact(m, d, g1, g2, dist, pos, n);
     }
   } else if (m->geom_type[g2] == OM_GEOM_CYLINDER) {
-    /* mjc_PlaneCylinder: deepest rim point, then up to two more rim points and the opposite one */
+    /* mjc_PlaneCylinder: deepest rim point, the opposite end of that generator, then two more points of the lower disk: A = +side first,
+     * then B = -side (engine_collision_primitive.c as recalled); degenerate tests against mjMINVAL */
     double axis[3] = {gm[2], gm[5], gm[8]};
     for (int k = 0; k < 3; k++) tmp[k] = gp[k] - pp[k];
     double dist0 = dot3(tmp, n);
@@ -362,7 +363,7 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
     double vec[3];
     for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
     double len = norm3(vec);
-    if (len < 1e-12) {
+    if (len < MJS_MINVAL) {
       /* disk parallel to plane: pick x-axis of the cylinder scaled by radius */
       for (int k = 0; k < 3; k++) vec[k] = gm[3 * k] * sz[0];
     } else {
@@ -387,11 +388,11 @@ static void collide_plane(const om_model* m, om_data* d, int g1, int g2) {
     double side[3];
     cross3(side, vec, axis);
     double sl = norm3(side);
-    if (sl > 1e-12) {
+    if (sl > MJS_MINVAL) {
       for (int k = 0; k < 3; k++) side[k] *= sz[0] * sqrt(3.0) * 0.5 / sl;
       dd = dist0 + prjaxis - 0.5 * prjvec;
       if (dd <= margin) {
-        for (int s = -1; s <= 1; s += 2) {
+        for (int s = 1; s >= -1; s -= 2) {
           for (int k = 0; k < 3; k++) pos[k] = gp[k] + s * side[k] + axis[k] - 0.5 * vec[k] - n[k] * dd * 0.5;
           cnt += add_contact(m, d, g1, g2, dd, pos, n);
         }
