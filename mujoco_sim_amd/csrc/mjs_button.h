@@ -1117,11 +1117,14 @@ __global__ __launch_bounds__(64 * ROLES) void kernel(KernelParams p) {
   const int role = (ROLES == 2) ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
   // MJS_VARIANT_RESET_GROUPS (p.reset_groups; rr::kernel3 explains the protocol): the grid's second half are reset workgroups,
   // workgroup G + g resets the envs of group g whose episode ended while workgroup g steps the others on another CU
-  const int groups = (p.N + 63) >> 6;
+  // Envs per workgroup: p.epg lanes of each wavefront carry an env (64; smaller groups are an A/B knob that lost:
+  // profiles/r04_d_button_group_size.txt). The path decision below is per workgroup; results are a function of the env's group.
+  const int epg = p.epg;
+  const int groups = (p.N + epg - 1) / epg;
   const bool resetter = !IS_RESET && ROLES == 2 && (int)blockIdx.x >= groups;
-  const int i = (resetter ? (int)blockIdx.x - groups : (int)blockIdx.x) * 64 + lane;
+  const int i = (resetter ? (int)blockIdx.x - groups : (int)blockIdx.x) * epg + lane;
   __shared__ double xch[ROLES == 2 ? 12 : 1][64];  // rows 0-5: qfrc_smooth (role 1 -> 0), 6-11: qacc (role 0 -> 1)
-  if (i >= p.N) return;
+  if (lane >= epg || i >= p.N) return;
   uint8_t flags = p.flags[i];
   const bool pending = (flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP;
   const rr::Ws ws{p.ws, p.N, i};

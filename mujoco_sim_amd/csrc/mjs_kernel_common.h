@@ -34,6 +34,7 @@ struct KernelParams {
   int block_shape;        // Planar-Push: MJS_BLOCKS_MESH / MJS_BLOCKS_BOX
   int epoch;              // parity of this step launch (0 / 1, toggled per launch): see FLAG_EPOCH
   int reset_groups;       // Robot-Reach kernel3: 1 = the grid's second half are reset workgroups, 0 = a workgroup resets its own envs
+  int epg;                // Button-Push: envs per workgroup (lanes >= epg leave at once): 64, or 16 while the chip has CUs to spare (mjsim.hip)
   int prefetch;           // Planar-Push: 1 = the grid's second half are PREFETCH workgroups that prepare every env's next episode
                           // (draws + settle steps, a few substeps per launch) in the state's second slot (mjs_push_impl.h)
   double time_limit;

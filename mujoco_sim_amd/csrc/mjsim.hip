@@ -165,6 +165,14 @@ __global__ void tcp_to_joints_kernel(const double* pos, const double* guess, dou
   ok[i] = found;
 }
 
+// Button-Push: envs per workgroup = 64. Smaller groups were measured (MJS_BP_EPG, profiles/r04_d_button_group_size.txt) and LOSE: with
+// 16 envs per group the steady state goes 53 -> 84 us per launch and the desynchronised case stays at 260 us - four times the
+// wavefronts share SIMDs (the dispatcher packs workgroups onto CUs), which costs more than the smaller groups save.
+int button_epg(const mjs_handle* h) {
+  if (h->cfg.task != MJS_TASK_BUTTON_PUSH) return 64;
+  if (const char* ev = std::getenv("MJS_BP_EPG")) { const int v = std::atoi(ev); if (v == 8 || v == 16 || v == 32 || v == 64) return v; }
+  return 64;
+}
 int push_prog_row(const mjs_handle* h) { return h->cfg.n_objects > MJS_PP_FAST_OBJECTS ? pp5::PROG_ROW : pp::PROG_ROW; }
 bool articulated(const mjs_handle* h) { return h->cfg.task == MJS_TASK_BUTTON_PUSH && h->cfg.gripper_model == MJS_GRIPPER_ARTICULATED; }
 bool uses_reset_groups(const mjs_handle* h) {
@@ -189,6 +197,7 @@ KernelParams make_params(const mjs_handle* h, const double* actions, const uint8
   p.block_shape = h->cfg.block_shape;
   p.epoch = h->epoch;
   p.reset_groups = uses_reset_groups(h);
+  p.epg = button_epg(h);
   // Planar-Push: next episodes are prepared ahead of time by prefetch workgroups (mjs_push_impl.h NEXT_ROW0); variant 1 keeps
   // round 3's behaviour (the settle steps of a reset run inside the step launch) for A/B measurements
   p.prefetch = h->cfg.task == MJS_TASK_PLANAR_PUSH && h->cfg.autoreset == MJS_AUTORESET_NEXT_STEP && h->cfg.kernel_variant != MJS_VARIANT_SINGLE_WAVE;
@@ -228,12 +237,13 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     bg::kernel<IS_RESET><<<dim3((unsigned)((p.N + epw - 1) / epw)), BLOCK, (size_t)epw * sizeof(bg::Env), s>>>(p, h->ws14, epw);
   }
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
-    if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
+    const dim3 bgrid((unsigned)((p.N + p.epg - 1) / p.epg));
+    if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) bp::kernel<IS_RESET, 1><<<bgrid, BLOCK, 0, s>>>(p);
     else if (p.reset_groups) {  // MJS_VARIANT_RESET_GROUPS: the second half of the grid resets the envs whose episode ended
-      bp::kernel<false, 2><<<dim3(2 * grid_for(p.N).x), 2 * BLOCK, 0, s>>>(p);
+      bp::kernel<false, 2><<<dim3(2 * bgrid.x), 2 * BLOCK, 0, s>>>(p);
       flip_epoch = true;
     }
-    else bp::kernel<false, 2><<<grid_for(p.N), 2 * BLOCK, 0, s>>>(p);
+    else bp::kernel<false, 2><<<bgrid, 2 * BLOCK, 0, s>>>(p);
   }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   // Two shapes of the same step (results equal to rounding): an IK wave + two role-specialised dynamics waves per 64 envs

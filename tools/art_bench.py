@@ -1,7 +1,7 @@
 """Launch time of the articulated-gripper Button-Push kernel (mjs_gripper14.h) at a few batch sizes (holding pose, gripper half open)."""
 import sys, time
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import mujoco_sim_amd as m
 
 for n in [int(x) for x in (sys.argv[1:] or ["4096"])]:
