@@ -34,7 +34,7 @@ def measured_traffic(task, n_local):
     """HBM bytes per launch from the committed PMC passes (profiles/r03_traffic_all_tasks.json: rocprofv3 --pmc
     FETCH_SIZE / WRITE_SIZE in separate runs of this very command, FETCH corrected per the gfx950 calibration of
     profiles/r01_traffic.json). Only valid for the configuration it was measured on; otherwise None."""
-    for name in ("r03_traffic_all_tasks.json",):  # measured on the kernels of THIS round (tools/profile_round.sh + collate_profiles.py)
+    for name in ("r04_traffic_all_tasks.json", "r03_traffic_all_tasks.json"):  # measured on the kernels of THIS round (tools/profile_round.sh + collate_profiles.py)
         try:
             d = json.load(open(ROOT / "profiles" / name))["tasks"][task]
             if n_local == d["envs"]:
@@ -427,7 +427,7 @@ def main():
             line["roofline"]["valu_fp64"] = {"flops_per_env_step": flops, "achieved_tflops": tf, "peak_tflops": 78.6, "frac": tf / 78.6,
                                              "simds_occupied_frac": min(1.0, (2 if args.variant == 2 else 1 if args.variant == 1 else 3) * (n_local / 64) / 1024)}
             try:  # PMC view of this very launch shape (profiles/r03_reach_valu.json): VALU busy share of a wavefront's lifetime
-                v = json.load(open(ROOT / "profiles" / "r03_reach_valu.json"))
+                v = json.load(open(ROOT / "profiles" / ("r04_reach_valu.json" if (ROOT / "profiles" / "r04_reach_valu.json").exists() else "r03_reach_valu.json")))
                 if v["envs"] == n_local:
                     line["roofline"]["valu_fp64"]["valu_busy_frac_on_occupied_simds_pmc"] = v["valu_busy_frac_of_wave_lifetime"]
             except Exception:  # noqa: BLE001

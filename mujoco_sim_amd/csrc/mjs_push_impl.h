@@ -141,7 +141,7 @@ MJS_DEV void store_world(const KernelParams& p, int i, const World& s) { store_w
 // prepared (the draws of initialize_episode + as many of its 150 settle steps as have run), row 2 STATE_DIM how far that has got:
 // -1 nothing drawn yet, 0 .. 149 settle steps done, 150 ready. An env's reset is a function of its own RNG stream only, so it can be
 // worked out ahead of time: in launches with p.prefetch the grid's second half are prefetch workgroups that advance the next-episode
-// slot of the envs of their group by PREFETCH_CHUNK substeps per launch, on CUs the stepping workgroups leave idle; when an
+// slot of the envs of their group by PREFETCH_CHUNK (10) substeps per launch, on CUs the stepping workgroups leave idle; when an
 // episode ends, the next launch swaps the slots (no settle steps inside a step launch). Ownership is decided by what both roles
 // read at launch start: an env whose reset is pending belongs to the stepping workgroup (which finishes whatever is missing
 // inline: the old path, bit for bit the same arithmetic), every other env's second slot to the prefetch workgroup. mjs_seed

@@ -165,6 +165,13 @@ __global__ void tcp_to_joints_kernel(const double* pos, const double* guess, dou
   ok[i] = found;
 }
 
+// A/B knob (MJS_LDS_PAD = bytes of unused dynamic LDS per workgroup of the Robot-Reach / Button-Push step kernels): a pad above half of the
+// CU's 160 KB leaves room for ONE workgroup per CU, which tells whether the dispatcher packs the few workgroups of a 4096-env launch onto
+// shared CUs (profiles/r04_e_workgroup_placement.txt).
+size_t lds_pad() {
+  static const size_t pad = [] { const char* ev = std::getenv("MJS_LDS_PAD"); return ev ? (size_t)std::atol(ev) : (size_t)0; }();
+  return pad;
+}
 // Button-Push: envs per workgroup = 64. Smaller groups were measured (MJS_BP_EPG, profiles/r04_d_button_group_size.txt) and LOSE: with
 // 16 envs per group the steady state goes 53 -> 84 us per launch and the desynchronised case stays at 260 us - four times the
 // wavefronts share SIMDs (the dispatcher packs workgroups onto CUs), which costs more than the smaller groups save.
@@ -243,7 +250,7 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
       bp::kernel<false, 2><<<dim3(2 * bgrid.x), 2 * BLOCK, 0, s>>>(p);
       flip_epoch = true;
     }
-    else bp::kernel<false, 2><<<bgrid, 2 * BLOCK, 0, s>>>(p);
+    else bp::kernel<false, 2><<<bgrid, 2 * BLOCK, lds_pad(), s>>>(p);
   }
   else if (IS_RESET || h->cfg.kernel_variant == MJS_VARIANT_SINGLE_WAVE) rr::kernel<IS_RESET, 1><<<grid_for(p.N), BLOCK, 0, s>>>(p);
   // Two shapes of the same step (results equal to rounding): an IK wave + two role-specialised dynamics waves per 64 envs
@@ -260,7 +267,7 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     rr::kernel3<0><<<dim3(2 * grid_for(p.N).x), 3 * BLOCK, 0, s>>>(p);
     flip_epoch = true;
   }
-  else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, 0, s>>>(p);
+  else rr::kernel3<0><<<grid_for(p.N), 3 * BLOCK, lds_pad(), s>>>(p);
   HIP_TRY(h, hipGetLastError());
   if (flip_epoch) h->epoch ^= 1;  // only a launch that was accepted consumed its parity
   return MJS_OK;
@@ -382,6 +389,10 @@ int mjs_create(const mjs_config* cfg, mjs_handle** out) {
     int rc = hip_fail(nullptr, e, "mjs_create: device allocation");
     mjs_destroy(h);
     return rc;
+  }
+  if (lds_pad() > 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&rr::kernel3<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad());
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bp::kernel<false, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad());
   }
   if (articulated(h)) {  // > 64 KB of dynamic LDS per workgroup is an opt-in (16 envs per workgroup at large batches)
     static_assert(16 * sizeof(bg::Env) <= 160 * 1024, "16 envs per workgroup fit the CU's LDS");

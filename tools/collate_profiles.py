@@ -4,7 +4,7 @@ JSON files bench.py reads: profiles/<round>_traffic_all_tasks.json (HBM bytes pe
 WRITE_SIZE passes, FETCH_SIZE corrected by the gfx950 calibration 0.5039 of profiles/r01_traffic.json) and
 profiles/<round>_reach_valu.json (VALU busy share of a wavefront's lifetime for the default Robot-Reach launch).
 
-usage: python tools/collate_profiles.py r3p r03
+usage: python tools/collate_profiles.py r4p r04
 """
 import csv
 import json
