@@ -20,8 +20,7 @@
 //     mj_makeConstraint's order (connect x2, joint coupling, joint limits, elliptic condim-3 contacts), impedance / reference
 //     acceleration, the primal Newton solver with elliptic cones (cost, gradient, cone Hessian, exact line search) warm-started
 //     like mj_fwdConstraint, the touch sensor, implicitfast integration with the tendon actuator's velocity derivative;
-//   * rows live in a per-handle HBM workspace ws[slot][N] (struct of arrays: a wavefront's access to one slot is one coalesced
-//     transaction); everything else is lane-private;
+//   * rows live in a per-handle HBM workspace ws[env][row][entry] (env-major: see struct Rows); the per-env state is in LDS;
 //   * convex pairs (pad - pad, pad - switch box, button - pad, wrist cylinder - switch box) go through the own MPR of
 //     mjs_push_impl.h, one contact per pair (DESIGN.md D-9's rule); pad boxes on the floor: mjc_PlaneBox's corner rule.
 // The oracle (oracle/om_engine.c + om_tasks.c build_button(.., OM_GRIPPER_ARTICULATED)) states the same model on MuJoCo's
@@ -137,14 +136,18 @@ struct Env {
   // the integrator's matrix and its factor): kept with the env so that it lives in LDS like the rest
   double tmp[256];
 #ifdef MJS_BG_PROFILE
-  double dbg[4];  // Newton iterations, line-search iterations, solves, MPR calls
+  double dbg[6];  // clocks inside the solver: warm-start trials + first update | gradient + Hessian | factor + direction | J search + line search | update | (spare)
 #endif
 };
 MJS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
+// Row workspace of one env: rows are CONTIGUOUS per env (ws[env][row][entry]): with 16 of a wavefront's 64 lanes carrying an env a
+// struct-of-arrays layout buys no coalescing (a wave touches 2 cache lines per entry either way), while the env-major layout makes
+// every entry of a row a constant offset from one row pointer (no 64-bit multiply per access: address arithmetic was as large as the
+// FP64 work in the solver's row passes) and lets neighbouring entries travel in one 16-byte load.
 struct Rows {
   double* base;
-  size_t N;
-  MJS_DEV double& at(int r, int k) const { return base[(size_t)(r * ROW_STRIDE + k) * N]; }
+  size_t N;  // (kept for the launch interface; unused by the env-major layout)
+  MJS_DEV double& at(int r, int k) const { return base[r * ROW_STRIDE + k]; }
 };
 
 // ------------------------------------------------------------------------------------------------ tree passes
@@ -698,10 +701,12 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
 // observation of the env (kinematics, crb + factor, collision, rows, velocity stage, forces + solver, integration)
 #ifdef MJS_BG_PROFILE
 #define BG_T(k, stmt) do { const long long t0_ = clock64(); stmt; prof[k] += (double)(clock64() - t0_); } while (0)
-#define BG_COUNT(e, k) ((e).dbg[k] += 1.0)
+#define BG_COUNT(e, k) ((void)0)
+#define BG_S(e, k, stmt) do { const long long t0_ = clock64(); stmt; (e).dbg[k] += (double)(clock64() - t0_); } while (0)
 #else
 #define BG_T(k, stmt) do { stmt; } while (0)
 #define BG_COUNT(e, k) ((void)0)
+#define BG_S(e, k, stmt) do { stmt; } while (0)
 #endif
 // The stages are OUT OF LINE, one copy each, and find their env in LDS themselves (an Env& argument would make every access a
 // FLAT one): a control step runs them 20 times, resets run them too, and inlined into the four call contexts the kernel was
@@ -748,53 +753,65 @@ MJS_DEV void actuation(const Model& m, Env& e, double* qfrc_act) {
   }
 }
 
-// cost, forces and cone zones at jar (PrimalUpdateConstraint); returns the constraint cost + the Gauss term
-MJS_DEV double constraint_update(Env& e, const Rows& w, const double* qacc, const double* Ma) {
+// ONE pass over the rows (PrimalUpdateConstraint + the gradient): jar (fresh: J qacc - aref; update: += alpha jv), forces, cone zones, the
+// constraint cost, and grad = Ma - qfrc_smooth - J^T f; returns the cost incl. the Gauss term. The oracle walks the rows once per
+// quantity; fused here because every pass over the HBM row workspace is a chain of dependent loads on a wavefront that has its
+// SIMD to itself.
+MJS_DEV double rows_pass(Env& e, const Rows& w, const double* qacc, const double* Ma, bool fresh, double alpha, double* grad) {
   double cost = 0;
+  for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
 #pragma unroll 1
   for (int r = 0; r < e.nefc; r++) {
     const int t = e.rtype[r];
+    const int nr = t == 2 ? 3 : 1;
+    double Jr[3][NV], z[3], f[3] = {0, 0, 0};
+    for (int a = 0; a < 3; a++) {
+      if (a >= nr) continue;
+      for (int k = 0; k < NV; k++) Jr[a][k] = w.at(r + a, ROW_J + k);
+      if (fresh) {
+        double sj = -w.at(r + a, ROW_AREF);
+        for (int k = 0; k < NV; k++) sj += Jr[a][k] * qacc[k];
+        z[a] = sj;
+      } else
+        z[a] = w.at(r + a, ROW_JAR) + alpha * w.at(r + a, ROW_JV);
+      w.at(r + a, ROW_JAR) = z[a];
+    }
     if (t == 2) {
       Contact& con = e.con[e.rcon[r]];
-      const double z0 = w.at(r, ROW_JAR), z1 = w.at(r + 1, ROW_JAR), z2 = w.at(r + 2, ROW_JAR);
       const double D0 = w.at(r, ROW_D), D1 = w.at(r + 1, ROW_D);
       const double mu = con.mu, fr = con.friction;
-      const double N = z0 * mu, U1 = z1 * fr, U2 = z2 * fr, T = sqrt(U1 * U1 + U2 * U2);
-      double f0 = 0, f1 = 0, f2 = 0;
+      const double N = z[0] * mu, U1 = z[1] * fr, U2 = z[2] * fr, T = sqrt(U1 * U1 + U2 * U2);
       if (N >= mu * T) con.zone = 0;
       else if (mu * N + T <= 0) {
         con.zone = 2;
-        f0 = -D0 * z0; f1 = -D1 * z1; f2 = -D1 * z2;
-        cost += 0.5 * (D0 * z0 * z0 + D1 * z1 * z1 + D1 * z2 * z2);
+        f[0] = -D0 * z[0]; f[1] = -D1 * z[1]; f[2] = -D1 * z[2];
+        cost += 0.5 * (D0 * z[0] * z[0] + D1 * z[1] * z[1] + D1 * z[2] * z[2]);
       } else {
         con.zone = 1;
         const double Dm = D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
         cost += 0.5 * Dm * NT * NT;
-        f0 = -Dm * NT * mu;
-        f1 = -f0 / T * U1 * fr; f2 = -f0 / T * U2 * fr;
+        f[0] = -Dm * NT * mu;
+        f[1] = -f[0] / T * U1 * fr; f[2] = -f[0] / T * U2 * fr;
       }
-      w.at(r, ROW_FORCE) = f0; w.at(r + 1, ROW_FORCE) = f1; w.at(r + 2, ROW_FORCE) = f2;
-      r += 2;
-      continue;
+    } else {
+      const double D = w.at(r, ROW_D);
+      const bool act = t == 0 || z[0] < 0;
+      f[0] = act ? -D * z[0] : 0.0;
+      if (act) cost += 0.5 * D * z[0] * z[0];
     }
-    const double jar = w.at(r, ROW_JAR), D = w.at(r, ROW_D);
-    const bool act = t == 0 || jar < 0;
-    w.at(r, ROW_FORCE) = act ? -D * jar : 0.0;
-    if (act) cost += 0.5 * D * jar * jar;
+    for (int a = 0; a < 3; a++) {
+      if (a >= nr) continue;
+      w.at(r + a, ROW_FORCE) = f[a];
+      if (f[a] != 0)
+        for (int k = 0; k < NV; k++) grad[k] -= Jr[a][k] * f[a];
+    }
+    r += nr - 1;
   }
   double gauss = 0;
   for (int i = 0; i < NV; i++) gauss += (Ma[i] - e.qfrc_smooth[i]) * (qacc[i] - e.qacc_smooth[i]);
   return cost + 0.5 * gauss;
 }
 MJS_DEV void mul_M(const Env& e, const double* x, double* y) { sym_mul_dev(e.M, x, y); }
-MJS_DEV void set_jar(const Env& e, const Rows& w, const double* qacc) {  // jar = J qacc - aref
-#pragma unroll 1
-  for (int r = 0; r < e.nefc; r++) {
-    double s = -w.at(r, ROW_AREF);
-    for (int k = 0; k < NV; k++) s += w.at(r, ROW_J + k) * qacc[k];
-    w.at(r, ROW_JAR) = s;
-  }
-}
 // exact 1-D minimiser of the cost along the search direction (1-D Newton with bracketing, MuJoCo's gradient stopping rule)
 MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
@@ -845,15 +862,111 @@ MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double g
   }
   return alpha;
 }
-// gradient = M a - qfrc_smooth - J^T f
-MJS_DEV void gradient(const Env& e, const Rows& w, const double* Ma, double* grad) {
-  for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
+// Newton direction, out of line and in REGISTERS: H = M + sum over the active rows D J^T J + the cone blocks is accumulated in 105
+// registers (rows in a run-time loop, the 14 x 14 triangle unrolled), factorised in place and back-substituted for search = -H^-1 grad
+// and J search is written to the rows' JV entries; nothing of H touches memory. Returns false when H is not positive definite.
+__device__ __noinline__ bool newton_direction(double* ws_env, const double* grad, double* search) {
+  Env& e = my_env();
+  const Rows w{ws_env, 0};
+  double h[NTRI];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) h[k] = e.M[k];
 #pragma unroll 1
   for (int r = 0; r < e.nefc; r++) {
-    const double f = w.at(r, ROW_FORCE);
-    if (f == 0) continue;
-    for (int i = 0; i < NV; i++) grad[i] -= w.at(r, ROW_J + i) * f;
+    const int t = e.rtype[r];
+    if (t == 2) {
+      const Contact& con = e.con[e.rcon[r]];
+      if (con.zone != 0) {
+        double J0[NV], J1[NV], J2[NV];
+#pragma unroll
+        for (int k = 0; k < NV; k++) { J0[k] = w.at(r, ROW_J + k); J1[k] = w.at(r + 1, ROW_J + k); J2[k] = w.at(r + 2, ROW_J + k); }
+        double Hc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        const double D0 = w.at(r, ROW_D), D1 = w.at(r + 1, ROW_D);
+        if (con.zone == 2) { Hc[0][0] = D0; Hc[1][1] = D1; Hc[2][2] = D1; }
+        else {
+          const double mu = con.mu, fr = con.friction;
+          const double N = w.at(r, ROW_JAR) * mu, U1 = w.at(r + 1, ROW_JAR) * fr, U2 = w.at(r + 2, ROW_JAR) * fr, T = sqrt(U1 * U1 + U2 * U2);
+          const double Dm = D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
+          const double wv[3] = {0, fr * U1, fr * U2}, vv[3] = {mu, -mu * wv[1] / T, -mu * wv[2] / T};
+#pragma unroll
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) {
+              double curv = -wv[a] * wv[b] / (T * T * T);
+              if (a == b && a > 0) curv += fr * fr / T;
+              Hc[a][b] = Dm * (vv[a] * vv[b] - mu * NT * curv);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+          const double t0 = Hc[0][0] * J0[i] + Hc[0][1] * J1[i] + Hc[0][2] * J2[i];
+          const double t1 = Hc[1][0] * J0[i] + Hc[1][1] * J1[i] + Hc[1][2] * J2[i];
+          const double t2 = Hc[2][0] * J0[i] + Hc[2][1] * J1[i] + Hc[2][2] * J2[i];
+#pragma unroll
+          for (int j = 0; j <= i; j++) h[tri(i, j)] += J0[j] * t0 + J1[j] * t1 + J2[j] * t2;
+        }
+      }
+      r += 2;
+      continue;
+    }
+    if (!(t == 0 || w.at(r, ROW_JAR) < 0)) continue;
+    const double D = w.at(r, ROW_D);
+    double Jr[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) Jr[k] = w.at(r, ROW_J + k);
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      const double dj = D * Jr[i];
+#pragma unroll
+      for (int j = 0; j <= i; j++) h[tri(i, j)] += dj * Jr[j];
+    }
   }
+  // Cholesky in place
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double d = h[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= h[tri(j, k)] * h[tri(j, k)];
+    if (!(d >= MJS_MINVAL)) { ok = false; d = MJS_MINVAL; }
+    const double ljj = sqrt(d);
+    h[tri(j, j)] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < NV; i++) {
+      double sij = h[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) sij -= h[tri(i, k)] * h[tri(j, k)];
+      h[tri(i, j)] = sij / ljj;
+    }
+  }
+  double y[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) y[i] = -grad[i];
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sy -= h[tri(i, k)] * y[k];
+    y[i] = sy / h[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; i--) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = i + 1; k < NV; k++) sy -= h[tri(k, i)] * y[k];
+    y[i] = sy / h[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) search[i] = y[i];
+  // J search for the line search
+#pragma unroll 1
+  for (int r = 0; r < e.nefc; r++) {
+    double sj = 0;
+#pragma unroll
+    for (int k = 0; k < NV; k++) sj += w.at(r, ROW_J + k) * y[k];
+    w.at(r, ROW_JV) = sj;
+  }
+  return ok;
 }
 // mj_fwdConstraint: primal Newton (mj_solPrimal) warm-started from the cheaper of qacc_warmstart and qacc_smooth
 MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
@@ -862,104 +975,44 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
     return;
   }
   double qacc[NV], Ma[NV], grad[NV], search[NV], Mv[NV];
-  double best = INFINITY;
-  for (int trial = 0; trial < 2; trial++) {
-    const double* q0 = trial == 0 ? e.warm : e.qacc_smooth;
-    double ma[NV];
-    mul_M(e, q0, ma);
-    set_jar(e, w, q0);
-    const double c = constraint_update(e, w, q0, ma);
-    if (c < best) { best = c; for (int i = 0; i < NV; i++) qacc[i] = q0[i]; }
+  // warm start: qacc_warmstart unless qacc_smooth is strictly cheaper (mj_fwdConstraint). The smooth candidate goes first so that
+  // the rows hold the warm candidate's jar / forces when it wins (the common case); M qacc_smooth = qfrc_smooth by definition.
+  double cost;
+  {
+    double ma_s[NV], ma_w[NV], grad_s[NV];
+    for (int i = 0; i < NV; i++) ma_s[i] = e.qfrc_smooth[i];
+    const double c_s = rows_pass(e, w, e.qacc_smooth, ma_s, true, 0.0, grad_s);
+    mul_M(e, e.warm, ma_w);
+    const double c_w = rows_pass(e, w, e.warm, ma_w, true, 0.0, grad);
+    if (c_s < c_w) {
+      for (int i = 0; i < NV; i++) { qacc[i] = e.qacc_smooth[i]; Ma[i] = ma_s[i]; }
+      cost = rows_pass(e, w, qacc, Ma, true, 0.0, grad);
+    } else {
+      for (int i = 0; i < NV; i++) { qacc[i] = e.warm[i]; Ma[i] = ma_w[i]; }
+      cost = c_w;
+    }
   }
-  mul_M(e, qacc, Ma);
-  set_jar(e, w, qacc);
-  double cost = constraint_update(e, w, qacc, Ma);
   const double scale = 1 / (m.meaninertia * NV);
-  double* const H = e.tmp;
-  double* const Lh = e.tmp + NTRI;
-  static_assert(2 * NTRI <= 256, "Hessian and factor fit the stage scratch");
   BG_COUNT(e, 2);
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     BG_COUNT(e, 0);
-    gradient(e, w, Ma, grad);
-    // Hessian: M + sum over quadratic rows D J^T J + cone blocks
-#pragma unroll 1
-    for (int k = 0; k < NTRI; k++) H[k] = e.M[k];
-#pragma unroll 1
-    for (int r = 0; r < e.nefc; r++) {
-      const int t = e.rtype[r];
-      if (t == 2) {
-        const Contact& con = e.con[e.rcon[r]];
-        double Jr[3][NV];
-        for (int a = 0; a < 3; a++)
-          for (int k = 0; k < NV; k++) Jr[a][k] = w.at(r + a, ROW_J + k);
-        double Hc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        const double D0 = w.at(r, ROW_D), D1 = w.at(r + 1, ROW_D);
-        if (con.zone == 2) { Hc[0][0] = D0; Hc[1][1] = D1; Hc[2][2] = D1; }
-        else if (con.zone == 1) {
-          const double mu = con.mu, fr = con.friction;
-          const double N = w.at(r, ROW_JAR) * mu, U1 = w.at(r + 1, ROW_JAR) * fr, U2 = w.at(r + 2, ROW_JAR) * fr, T = sqrt(U1 * U1 + U2 * U2);
-          const double Dm = D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
-          const double wv[3] = {0, fr * U1, fr * U2}, vv[3] = {mu, -mu * wv[1] / T, -mu * wv[2] / T};
-          for (int a = 0; a < 3; a++)
-            for (int b = 0; b < 3; b++) {
-              double curv = -wv[a] * wv[b] / (T * T * T);
-              if (a == b && a > 0) curv += fr * fr / T;
-              Hc[a][b] = Dm * (vv[a] * vv[b] - mu * NT * curv);
-            }
-        }
-        if (con.zone != 0)
-          for (int i = 0; i < NV; i++) {
-            double t3[3];
-            for (int a = 0; a < 3; a++) t3[a] = Hc[a][0] * Jr[0][i] + Hc[a][1] * Jr[1][i] + Hc[a][2] * Jr[2][i];
-            for (int j = 0; j <= i; j++) H[tri(i, j)] += Jr[0][j] * t3[0] + Jr[1][j] * t3[1] + Jr[2][j] * t3[2];
-          }
-        r += 2;
-        continue;
-      }
-      const double D = w.at(r, ROW_D);
-      if (!(t == 0 || w.at(r, ROW_JAR) < 0)) continue;
-      double Jr[NV];
-      for (int k = 0; k < NV; k++) Jr[k] = w.at(r, ROW_J + k);
-      for (int i = 0; i < NV; i++) {
-        const double dj = D * Jr[i];
-        if (dj == 0) continue;
-        for (int j = 0; j <= i; j++) H[tri(i, j)] += dj * Jr[j];
-      }
-    }
-    if (!chol_factor_dev(H, Lh)) break;
-    for (int i = 0; i < NV; i++) search[i] = -grad[i];
-    chol_solve_dev(Lh, search);
+    if (!newton_direction(w.base, grad, search)) break;
     mul_M(e, search, Mv);
     double g1 = 0, g2 = 0, snorm = 0;
     for (int i = 0; i < NV; i++) { g1 += search[i] * (Ma[i] - e.qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
     if (sqrt(snorm) < MJS_MINVAL) break;
-#pragma unroll 1
-    for (int r = 0; r < e.nefc; r++) {
-      double s = 0;
-      for (int k = 0; k < NV; k++) s += w.at(r, ROW_J + k) * search[k];
-      w.at(r, ROW_JV) = s;
-    }
     const double alpha = line_search(e, w, g1, g2, MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale);
     if (alpha == 0) break;
     for (int i = 0; i < NV; i++) { qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
-#pragma unroll 1
-    for (int r = 0; r < e.nefc; r++) w.at(r, ROW_JAR) += alpha * w.at(r, ROW_JV);
     const double oldcost = cost;
-    cost = constraint_update(e, w, qacc, Ma);
-    gradient(e, w, Ma, grad);
+    cost = rows_pass(e, w, qacc, Ma, false, alpha, grad);
     double gn = 0;
     for (int i = 0; i < NV; i++) gn += grad[i] * grad[i];
     if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
   }
-  for (int i = 0; i < NV; i++) { e.qacc[i] = qacc[i]; e.qfrc_constraint[i] = 0; }
-#pragma unroll 1
-  for (int r = 0; r < e.nefc; r++) {
-    const double f = w.at(r, ROW_FORCE);
-    if (f == 0) continue;
-    for (int i = 0; i < NV; i++) e.qfrc_constraint[i] += w.at(r, ROW_J + i) * f;
-  }
+  // qfrc_constraint = J^T f = M a - qfrc_smooth - gradient
+  for (int i = 0; i < NV; i++) { e.qacc[i] = qacc[i]; e.qfrc_constraint[i] = Ma[i] - e.qfrc_smooth[i] - grad[i]; }
 }
 // mj_sensorAcc, touch: normal forces of the contacts of the switch body whose point lies in the site cylinder (button x 1.01)
 MJS_DEV void touch_sensor(Env& e, const Rows& w) {
@@ -1266,7 +1319,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES
   const int i = blockIdx.x * epw + lane;
   if (i >= p.N) return;
   const Model& m = g_model;
-  const Rows w{ws_base + i, (size_t)p.N};
+  const Rows w{ws_base + (size_t)i * WS_DOUBLES, (size_t)p.N};
   uint8_t flags = p.flags[i];
   Env& e = reinterpret_cast<Env*>(lds_envs)[lane];
   e.overflow = false;
