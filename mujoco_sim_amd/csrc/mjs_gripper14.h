@@ -107,8 +107,9 @@ MJS_HD void cross3(const double* a, const double* b, double* r) {
 MJS_HD double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 
 // ---- per-env data (lane-private)
+struct SIn { double I[6], h[3], mass; };  // spatial inertia about the world origin: I (xx xy xz yy yz zz), h = m c, mass
 struct Contact {
-  double dist, pos[3], frame[9];
+  double dist, pos[3], nrm[3];  // (the contact frame is rebuilt from the normal where the rows are made: mju_makeFrame)
   int b1, b2;          // moving bodies (-1: static); the normal points from geom1 to geom2
   double friction;     // tangential friction coefficient of the pair (mj_contactParam)
   double solref, solimp[3], tran;  // time constant; d0, dmax, width; body_invweight0 of both bodies (translation), summed
@@ -122,7 +123,9 @@ struct Env {
   double sw[3];
   // position stage (mj_step1)
   double xpos[NV][3], xmat[NV][9], S[NV][6];
-  double M[NTRI], L[NTRI];  // joint-space inertia and its Cholesky factor, packed lower triangles
+  double M[NTRI];           // joint-space inertia (+ armature), packed lower triangle
+  double cs[NV], sn[NV];    // cos / sin of the joint angles, carried through the substeps by angle addition (rr::rotate_small; exact at
+                            // the start of every control step and whenever a substep turns a joint by more than 0.1 rad)
   double bias[NV], passive[NV];
   Contact con[MAXCON];
   int ncon, nefc, nlim;
@@ -132,6 +135,7 @@ struct Env {
   // acceleration stage
   double qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV], act_force[7], touch;
   int clamped;  // bit u: actuator u sits on its force range
+  SIn bI[NV];   // the bodies' own spatial inertias of this configuration (crb and the velocity stage both need them)
   // scratch of the stage that is running (composite inertias | spatial velocities, accelerations, forces | Hessian and its factor |
   // the integrator's matrix and its factor): kept with the env so that it lives in LDS like the rest
   double tmp[256];
@@ -169,8 +173,7 @@ MJS_HD void kinematics(const Model& m, Env& e) {
     for (int k = 0; k < 3; k++) anchor[k] = x0[k] + tmp[k];
     mat_vec(R0, m.axis[b], axw);
     // R = R0 * Rot(axis, q) with the Rodrigues formula in the body frame
-    double sn, cs;
-    sincos(e.q[b], &sn, &cs);
+    const double sn = e.sn[b], cs = e.cs[b];
     const double* a = m.axis[b];
     const double oc = 1 - cs;
     double Rl[9] = {cs + oc * a[0] * a[0], oc * a[0] * a[1] - sn * a[2], oc * a[0] * a[2] + sn * a[1],
@@ -185,7 +188,6 @@ MJS_HD void kinematics(const Model& m, Env& e) {
 }
 
 // spatial inertia of a moving body (welded composite) about the world origin: I (xx xy xz yy yz zz), h = m c, mass
-struct SIn { double I[6], h[3], mass; };
 MJS_HD void body_inertia(const Model& m, const Env& e, int b, SIn& s) {
   const double* R = e.xmat[b];
   double c[3], tmp[3];
@@ -281,6 +283,46 @@ __device__ __noinline__ bool chol_factor_dev(const double* A, double* L) {
   for (int k = 0; k < NTRI; k++) L[k] = a[k];
   return ok;
 }
+// x <- A^-1 x for a packed symmetric positive definite A: factorisation and both substitutions in registers, nothing stored but x
+__device__ __noinline__ void factor_solve_dev(const double* A, double* x) {
+  double a[NTRI], y[NV];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) a[k] = A[k];
+#pragma unroll
+  for (int k = 0; k < NV; k++) y[k] = x[k];
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double d = a[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= a[tri(j, k)] * a[tri(j, k)];
+    if (!(d >= MJS_MINVAL)) d = MJS_MINVAL;
+    const double ljj = sqrt(d);
+    a[tri(j, j)] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < NV; i++) {
+      double sij = a[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) sij -= a[tri(i, k)] * a[tri(j, k)];
+      a[tri(i, j)] = sij / ljj;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sy -= a[tri(i, k)] * y[k];
+    y[i] = sy / a[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; i--) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = i + 1; k < NV; k++) sy -= a[tri(k, i)] * y[k];
+    y[i] = sy / a[tri(i, i)];
+  }
+#pragma unroll
+  for (int k = 0; k < NV; k++) x[k] = y[k];
+}
 // x <- (L L^T)^-1 x, L and x in registers
 __device__ __noinline__ void chol_solve_dev(const double* L, double* x) {
   double a[NTRI], y[NV];
@@ -325,7 +367,7 @@ MJS_HD void crb(const Model& m, Env& e) {
   SIn* c = reinterpret_cast<SIn*>(e.tmp);
   static_assert(sizeof(SIn) * NV <= sizeof(double) * 256, "composite inertias fit the stage scratch");
 #pragma unroll 1
-  for (int b = 0; b < NV; b++) body_inertia(m, e, b, c[b]);
+  for (int b = 0; b < NV; b++) { body_inertia(m, e, b, e.bI[b]); c[b] = e.bI[b]; }
 #pragma unroll 1
   for (int b = NV - 1; b > 0; b--) {
     const int p = PBf(b);
@@ -373,8 +415,7 @@ MJS_DEV void velocity_stage(const Model& m, Env& e) {
     double sd[6];
     cross_motion6(vp, e.S[b], sd);
     for (int k = 0; k < 6; k++) { cacc[b][k] = ap[k] + sd[k] * e.v[b]; cvel[b][k] = vp[k] + e.S[b][k] * e.v[b]; }
-    SIn I;
-    body_inertia(m, e, b, I);
+    const SIn& I = e.bI[b];  // of this configuration (st_crb ran before)
     double Ia[6], Iv[6], vIv[6];
     sin_mul(I, cacc[b], Ia);
     sin_mul(I, cvel[b], Iv);
@@ -429,8 +470,7 @@ MJS_DEV void add_contact(Env& e, double dist, const double* pos, const double* n
   if (e.ncon >= MAXCON) { e.overflow = true; return; }
   Contact& c = e.con[e.ncon++];
   c.dist = dist;
-  for (int k = 0; k < 3; k++) c.pos[k] = pos[k];
-  make_frame9(nrm, c.frame);
+  for (int k = 0; k < 3; k++) { c.pos[k] = pos[k]; c.nrm[k] = nrm[k]; }
   c.b1 = b1; c.b2 = b2;
   c.friction = pp_.friction; c.solref = pp_.solref; c.solimp[0] = pp_.d0; c.solimp[1] = pp_.dmax; c.solimp[2] = pp_.width;
   c.tran = tran; c.on_switch = on_switch;
@@ -681,10 +721,12 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
     const double R0 = fmax(MJS_MINVAL, (1 - kb.imp) * con.tran / kb.imp), R1 = R0 / MJS_G85_IMPRATIO;
     con.mu = con.friction * sqrt(R1 / R0);
     con.row = r;
+    double frame[9];
+    make_frame9(con.nrm, frame);
     for (int k = 0; k < 3; k++) {
       for (int j = 0; j < NV; j++) {
         double s = 0;
-        for (int a = 0; a < 3; a++) s += con.frame[3 * k + a] * ((con.b2 >= 0 ? jt2[a][j] : 0.0) - (con.b1 >= 0 ? jt1[a][j] : 0.0));
+        for (int a = 0; a < 3; a++) s += frame[3 * k + a] * ((con.b2 >= 0 ? jt2[a][j] : 0.0) - (con.b1 >= 0 ? jt1[a][j] : 0.0));
         J[j] = s;
       }
       const double pos = k == 0 ? con.dist : 0.0;
@@ -714,7 +756,7 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
 extern __shared__ double lds_envs[];
 MJS_DEV Env& my_env() { return reinterpret_cast<Env*>(lds_envs)[threadIdx.x]; }
 __device__ __noinline__ void st_kinematics() { kinematics(g_model, my_env()); }
-__device__ __noinline__ void st_crb() { Env& e = my_env(); crb(g_model, e); chol_factor_dev(e.M, e.L); }
+__device__ __noinline__ void st_crb() { crb(g_model, my_env()); }
 __device__ __noinline__ void st_collision() { collision(g_model, my_env()); }
 __device__ __noinline__ void st_rows(double* ws_lane, size_t N) { make_rows(g_model, my_env(), Rows{ws_lane, N}); }
 __device__ __noinline__ void st_velocity() { velocity_stage(g_model, my_env()); }
@@ -1031,7 +1073,7 @@ MJS_DEV void forces(const Model& m, Env& e, const Rows& w) {
   double act[NV];
   actuation(m, e, act);
   for (int i = 0; i < NV; i++) { e.qfrc_smooth[i] = e.passive[i] - e.bias[i] + act[i]; e.qacc_smooth[i] = e.qfrc_smooth[i]; }
-  chol_solve_dev(e.L, e.qacc_smooth);
+  factor_solve_dev(e.M, e.qacc_smooth);  // mj_fwdAcceleration (the factor of M is not needed again)
   solve(m, e, w);
   touch_sensor(e, w);
 }
@@ -1039,7 +1081,6 @@ MJS_DEV void forces(const Model& m, Env& e, const Rows& w) {
 MJS_DEV bool integrate(const Model& m, Env& e) {
   bool bad = false;
   double* const A = e.tmp;
-  double* const L = e.tmp + NTRI;
   double qa[NV];
 #pragma unroll 1
   for (int k = 0; k < NTRI; k++) A[k] = e.M[k];
@@ -1056,12 +1097,14 @@ MJS_DEV bool integrate(const Model& m, Env& e) {
     const double kk = MJS_RR_PHYSICS_DT * MJS_G2F85_ACT_KV * MJS_G85_TENDON_COEF * MJS_G85_TENDON_COEF;
     A[tri(B_RDRIVER, B_RDRIVER)] += kk; A[tri(B_LDRIVER, B_LDRIVER)] += kk; A[tri(B_LDRIVER, B_RDRIVER)] += kk;
   }
-  chol_factor_dev(A, L);
-  chol_solve_dev(L, qa);
+  factor_solve_dev(A, qa);
   for (int i = 0; i < NV; i++) {
     e.v[i] += MJS_RR_PHYSICS_DT * qa[i];
-    e.q[i] += MJS_RR_PHYSICS_DT * e.v[i];
+    const double dq = MJS_RR_PHYSICS_DT * e.v[i];
+    e.q[i] += dq;
     bad = bad || bad_value(e.q[i]) || bad_value(e.v[i]);
+    if (dq * dq <= 0.01) { double c = e.cs[i], sn_ = e.sn[i]; rr::rotate_small(c, sn_, dq); e.cs[i] = c; e.sn[i] = sn_; }
+    else sincos(e.q[i], &e.sn[i], &e.cs[i]);
   }
   e.time += MJS_RR_PHYSICS_DT;
   return bad;
@@ -1201,10 +1244,11 @@ inline void build_model(Model& m) {
   quat_to_mat(MJS_UR_FLANGE_QUAT, m.site_rot);
   // mj_setConst at qpos0 = 0: connect anchors, meaninertia, invweight0
   static thread_local Env e;
-  for (int i = 0; i < NV; i++) { e.q[i] = 0; e.v[i] = 0; }
+  static thread_local double L0[NTRI];
+  for (int i = 0; i < NV; i++) { e.q[i] = 0; e.v[i] = 0; e.cs[i] = 1; e.sn[i] = 0; }
   kinematics(m, e);
   crb(m, e);
-  chol_factor_host(e.M, e.L);
+  chol_factor_host(e.M, L0);
   for (int s = 0; s < 2; s++) {
     const int b1 = s == 0 ? B_RFOLLOWER : B_LFOLLOWER, b2 = s == 0 ? B_RCOUPLER : B_LCOUPLER;
     double d[3];
@@ -1217,7 +1261,7 @@ inline void build_model(Model& m) {
   for (int i = 0; i < NV; i++) {
     double x[NV];
     for (int k = 0; k < NV; k++) x[k] = k == i ? 1.0 : 0.0;
-    chol_solve_host(e.L, x);
+    chol_solve_host(L0, x);
     m.dof_invweight0[i] = x[i];
   }
   auto invweight_tran = [&](int b, const double* local) {
@@ -1229,7 +1273,7 @@ inline void build_model(Model& m) {
     for (int k = 0; k < 3; k++) {
       double x[NV];
       for (int j = 0; j < NV; j++) x[j] = jt[k][j];
-      chol_solve_host(e.L, x);
+      chol_solve_host(L0, x);
       for (int j = 0; j < NV; j++) s += jt[k][j] * x[j];
     }
     return fmax(MJS_MINVAL, s / 3);
@@ -1261,6 +1305,7 @@ MJS_DEV void load_env(const KernelParams& p, int i, Env& e) {
   for (int j = 0; j < NV - NA; j++) { e.q[NA + j] = s[(S_GQ + j) * N]; e.v[NA + j] = s[(S_GV + j) * N]; e.warm[NA + j] = s[(S_GWARM + j) * N]; }
   e.time = s[S_TIME * N];
   for (int k = 0; k < 3; k++) e.sw[k] = s[(S_SWITCH + k) * N];
+  for (int j = 0; j < NV; j++) sincos(e.q[j], &e.sn[j], &e.cs[j]);  // exact at the start of every control step
 }
 MJS_DEV void store_env(const KernelParams& p, int i, const Env& e) {
   double* s = p.state + i;
@@ -1286,6 +1331,7 @@ MJS_DEV uint8_t episode_init(const Model& m, const KernelParams& p, int i, Env& 
   rng_close(p.rng, i, c);
   for (int j = 0; j < NV; j++) { e.q[j] = 0; e.v[j] = 0; e.warm[j] = 0; }
   for (int j = 0; j < NA; j++) { e.q[j] = ok ? q[j] : 0.0; e.ctrl[j] = e.q[j]; }
+  for (int j = 0; j < NV; j++) sincos(e.q[j], &e.sn[j], &e.cs[j]);
   e.ctrl[6] = 0;  // mj_resetData
   e.time = 0;
   e.overflow = false;
