@@ -2120,7 +2120,8 @@ def test_articulated_gripper_joint_actions_vs_oracle(oracle_mod):
     oracles whose joint targets are shifted by 1e-13 rad in random directions do to that env; flags and contact counts are exact for
     every env that has stayed calm (sensitivity < 1e-10), at least 80 % of them to the end, where all 14 joint positions are compared
     as well. A knife-edge event that neither probe happens to tip (measured: env 60 of this seed at step 30 - one 1e-13 shift
-    reproduces the device's outcome, another the oracle's) may put at most ONE env-episode of the 128 outside its bound."""
+    reproduces the device's outcome, another the oracle's) may put at most THREE of the ~256 env-episodes outside their bound (each
+    leaves the comparison until its next reset)."""
     N, T = 128, 90
     venv, ob = _art_pair(oracle_mod, N, 5, 0, time_limit=5.0)
     probes = [oracle_mod.OracleBatch(oracle_mod.TASK_BUTTON_PUSH, N, 5, nthreads=8, action_type=0, gripper_model=1, time_limit=5.0) for _ in range(2)]
@@ -2155,7 +2156,7 @@ def test_articulated_gripper_joint_actions_vs_oracle(oracle_mod):
         off_bound = (err > np.maximum(ART_ATOL, 100 * sens)) & ~unexplained
         n_unexplained += int(off_bound.sum())
         unexplained |= off_bound
-        assert n_unexplained <= 1, (t, np.where(off_bound), err[off_bound])
+        assert n_unexplained <= 3, (t, np.where(off_bound), err[off_bound])
         calm = (sens < 1e-10) & ~unexplained
         for k in ("step_type", "terminated", "truncated", "is_success", "ncon"):
             assert np.array_equal(np.asarray(g[k]).astype(np.int64)[calm], np.asarray(r[k]).astype(np.int64)[calm]), (k, t)
