@@ -144,14 +144,19 @@ struct Env {
 #endif
 };
 MJS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-// Row workspace of one env: rows are CONTIGUOUS per env (ws[env][row][entry]): with 16 of a wavefront's 64 lanes carrying an env a
-// struct-of-arrays layout buys no coalescing (a wave touches 2 cache lines per entry either way), while the env-major layout makes
-// every entry of a row a constant offset from one row pointer (no 64-bit multiply per access: address arithmetic was as large as the
-// FP64 work in the solver's row passes) and lets neighbouring entries travel in one 16-byte load.
+// Row workspace of one env. The first LROWS rows live in LDS (they alias the env's stage scratch e.tmp: mj_step1 runs the stages that
+// need that scratch - crb, the velocity stage - BEFORE it makes the rows, and the integrator reuses it only after the solver is
+// done with them); a typical substep has 9 - 12 rows (7 equality rows, the couplers' stops, a contact), so the solver's row passes
+// - chains of dependent loads on a wavefront that has its SIMD to itself - mostly stay out of HBM. Rows from LROWS on are in the
+// handle's HBM workspace, CONTIGUOUS per env (ws[env][row][entry]): with 16 of 64 lanes carrying an env a struct-of-arrays layout
+// buys no coalescing, while env-major makes every entry a constant offset from one row pointer. One accessor serves both (the row
+// pointer is a generic one: FLAT loads).
+constexpr int LROWS = 256 / ROW_STRIDE;
 struct Rows {
-  double* base;
-  size_t N;  // (kept for the launch interface; unused by the env-major layout)
-  MJS_DEV double& at(int r, int k) const { return base[r * ROW_STRIDE + k]; }
+  double* base;  // the env's rows in HBM
+  double* lds;   // the env's e.tmp
+  MJS_DEV double* row(int r) const { return (r < LROWS ? lds : base) + r * ROW_STRIDE; }
+  MJS_DEV double& at(int r, int k) const { return row(r)[k]; }
 };
 
 // ------------------------------------------------------------------------------------------------ tree passes
@@ -758,15 +763,15 @@ MJS_DEV Env& my_env() { return reinterpret_cast<Env*>(lds_envs)[threadIdx.x]; }
 __device__ __noinline__ void st_kinematics() { kinematics(g_model, my_env()); }
 __device__ __noinline__ void st_crb() { crb(g_model, my_env()); }
 __device__ __noinline__ void st_collision() { collision(g_model, my_env()); }
-__device__ __noinline__ void st_rows(double* ws_lane, size_t N) { make_rows(g_model, my_env(), Rows{ws_lane, N}); }
+__device__ __noinline__ void st_rows(double* ws_lane) { Env& e = my_env(); make_rows(g_model, e, Rows{ws_lane, e.tmp}); }
 __device__ __noinline__ void st_velocity() { velocity_stage(g_model, my_env()); }
 // mj_step1: position + velocity stages
 MJS_DEV void step1(const Model& m, Env& e, const Rows& w, double* prof) {
   BG_T(0, st_kinematics());
   BG_T(1, st_crb());
+  BG_T(4, st_velocity());  // (before the rows: it uses the stage scratch the first rows alias)
   BG_T(2, st_collision());
-  BG_T(3, st_rows(w.base, w.N));
-  BG_T(4, st_velocity());
+  BG_T(3, st_rows(w.base));
 }
 
 // ------------------------------------------------------------------------------------------------ forces and the solver
@@ -909,7 +914,7 @@ MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double g
 // and J search is written to the rows' JV entries; nothing of H touches memory. Returns false when H is not positive definite.
 __device__ __noinline__ bool newton_direction(double* ws_env, const double* grad, double* search) {
   Env& e = my_env();
-  const Rows w{ws_env, 0};
+  const Rows w{ws_env, e.tmp};
   double h[NTRI];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) h[k] = e.M[k];
@@ -1110,7 +1115,7 @@ MJS_DEV bool integrate(const Model& m, Env& e) {
   return bad;
 }
 
-__device__ __noinline__ void st_forces(double* ws_lane, size_t N) { forces(g_model, my_env(), Rows{ws_lane, N}); }
+__device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces(g_model, e, Rows{ws_lane, e.tmp}); }
 __device__ __noinline__ bool st_integrate() { return integrate(g_model, my_env()); }
 
 // ------------------------------------------------------------------------------------------------ model compilation (host)
@@ -1337,7 +1342,7 @@ MJS_DEV uint8_t episode_init(const Model& m, const KernelParams& p, int i, Env& 
   e.overflow = false;
   double prof[8];
   step1(m, e, w, prof);
-  st_forces(w.base, w.N);
+  st_forces(w.base);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   bp::switch_update(e.touch, f);
   return f;
@@ -1365,7 +1370,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES
   const int i = blockIdx.x * epw + lane;
   if (i >= p.N) return;
   const Model& m = g_model;
-  const Rows w{ws_base + (size_t)i * WS_DOUBLES, (size_t)p.N};
+  const Rows w{ws_base + (size_t)i * WS_DOUBLES, nullptr};  // (the kernel only hands the HBM pointer to the stages)
   uint8_t flags = p.flags[i];
   Env& e = reinterpret_cast<Env*>(lds_envs)[lane];
   e.overflow = false;
@@ -1402,7 +1407,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES
   for (int s = 0; s < MJS_RR_NSUB; s++) {
     const double t = fmin(fmax(e.time, t0), t1);
     for (int j = 0; j < NA; j++) e.ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;  // robot.py:261-263
-    BG_T(5, st_forces(w.base, w.N));       // mj_step2 ...
+    BG_T(5, st_forces(w.base));            // mj_step2 ...
     BG_T(6, bad = st_integrate() || bad);
     rows_active = rows_active || e.nefc > NEQ_ROWS;
     step1(m, e, w, prof);                  // ... mj_step1 (dm_control's legacy order)

@@ -23,8 +23,7 @@ a[:, 6] = 0.04
 for k in range(3):
     v.step(a)
 prof = v._buf["obs"][:, :7].cpu().numpy()
-dbg = v._buf["obs"][:, 7:11].cpu().numpy()
-print("per control step: Newton iterations %.1f (max %d), line-search iterations %.1f (max %d), solves %.1f" % (dbg[:, 0].mean(), dbg[:, 0].max(), dbg[:, 1].mean(), dbg[:, 1].max(), dbg[:, 2].mean()))
+
 names = ["kinematics", "crb+factor", "collision", "rows", "velocity", "forces+solve", "integrate"]
 tot = prof.mean(axis=0).sum()
 for k, nm in enumerate(names):
