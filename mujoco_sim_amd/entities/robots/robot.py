@@ -60,6 +60,56 @@ class UR5eBatch:
         self._run(nat.UR_CMD_NONE, None, 1.0, 0)
         return self._pose.clone()
 
+    # ------------------------------------------------------------------ IK helpers (robot.py:113-124,176-183)
+    @property
+    def tcp_offset_z(self) -> float:
+        return 0.174 if self._eef == nat.UR_EEF_GRIPPER else 0.0  # gripper.py:46-48 / bare flange
+
+    def get_joint_positions_from_tcp_pose(self, tcp_pose, current_joints=None):
+        """robot.py:113-121: TCP pose (xyz + scalar-last quaternion) -> flange pose -> inverse_kinematics_closest to ``current_joints``
+        (default: the home joints). Returns (joints [n, 6], found [n] bool); the reference returns None where no solution exists."""
+        pose = self._as(tcp_pose, 7)
+        guess = self._as(self.home_joint_positions if current_joints is None else current_joints, 6)
+        x, y, z, w = (pose[:, 3 + k] for k in range(4))
+        nrm = torch.sqrt(x * x + y * y + z * z + w * w)
+        x, y, z, w = x / nrm, y / nrm, z / nrm, w / nrm
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+                         2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                         2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=1)
+        t = pose[:, 0:3] - R.view(-1, 3, 3)[:, :, 2] * self.tcp_offset_z  # flange = TCP * inv(T_tcp_in_flange), robot.py:138-151
+        T = torch.cat([R, t], dim=1).contiguous()
+        q = torch.empty(self.n, 6, dtype=torch.float64, device=self.device)
+        ok = torch.empty(self.n, dtype=torch.uint8, device=self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        with torch.cuda.device(self.device):
+            nat.check(self._lib.mjs_debug_ur5e_ik(C.c_void_p(T.data_ptr()), C.c_void_p(guess.data_ptr()), C.c_void_p(q.data_ptr()), C.c_void_p(ok.data_ptr()),
+                                                  self.n, C.c_void_p(stream)))
+        return q, ok.bool()
+
+    def is_pose_reachable(self, tcp_pose) -> torch.Tensor:
+        """robot.py:123-124"""
+        return self.get_joint_positions_from_tcp_pose(tcp_pose)[1]
+
+    def set_tcp_pose(self, pose):
+        """robot.py:176-183: IK from the current joints; robots whose pose is unreachable keep their state (the reference passes silently)"""
+        self._flush()
+        q, ok = self.get_joint_positions_from_tcp_pose(pose, self.get_joint_positions())
+        new = self._state.clone()
+        new[ok] = 0.0
+        new[ok, 0:6] = q[ok]
+        new[ok, 12:18] = q[ok]
+        self._state.copy_(new)
+        return ok
+
+    def is_moving(self) -> torch.Tensor:
+        """robot.py:274-275: a joint trajectory is set. (It stays set once a command was given: before_substep hands
+        ``physics.timestep()`` to ``is_finished``, robot.py:271, so the reference never clears it either.)"""
+        self._flush()
+        return self._state[:, 19] != 0
+
+    def moveL(self, tcp_pose, speed: float):
+        raise NotImplementedError("moveL not implemented")  # robot.py:193-194
+
     # ------------------------------------------------------------------ control API (robot.py:198-259)
     def moveJ(self, target_joint_positions, speed: float):
         self._flush()
