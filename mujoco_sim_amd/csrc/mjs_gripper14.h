@@ -34,6 +34,16 @@
 namespace bg {
 
 #define MJS_HD __host__ __device__ __forceinline__  // shared by the kernels and the host-side model compiler (build_model)
+// the loops over the 14 bodies of the tree passes (kinematics, crb, velocity stage): fully unrolled - static LDS offsets and scalar model
+// loads that the scheduler can batch (6.9 -> 6.5 ms per launch against the rolled loops, profiles/r04_f_*; -DBG_TREE_LOOP='_Pragma("unroll 1")')
+#ifndef BG_TREE_LOOP
+#define BG_TREE_LOOP _Pragma("unroll")
+#endif
+// the register-resident blocks (Hessian + Cholesky + substitutions, M x, factor-solve) stay OUT of line: inlined into their stages the
+// launch takes 8.4 instead of 6.7 ms (register allocation over the larger function; profiles/r04_f_*)
+#ifndef BG_NEWTON_INLINE
+#define BG_NEWTON_INLINE __device__ __noinline__
+#endif
 
 constexpr int NV = 14, NA = 6;
 constexpr int MAXCON = 16;     // contacts per env (detected); the surplus is dropped and reported (MJS_FAULT_UNSUPPORTED_CONTACT)
@@ -75,6 +85,7 @@ struct Model {
   double pad_friction[2];
   double pad_pos[2][2][3], pad_rot[2][9];  // [side][box] centre, [side] orientation in the follower's frame
   double pad_com[2][3];                    // pad body's own COM in the follower's frame
+  double pad_reach[2];                     // radius about the follower's origin that holds both pad boxes of the side (collision guards)
   double site_pos[3], site_rot[9];         // flange site in wrist_3's frame
 };
 __constant__ Model g_model;  // constant address space: a wave-uniform index makes the load a scalar one
@@ -118,6 +129,7 @@ struct Contact {
   int zone;            // elliptic cone: 0 top, 1 middle, 2 bottom
   double mu;
 };
+constexpr int TMP_DOUBLES = 383;  // >= 3 x 14 spatial vectors (252); the rest buys rows in LDS (19 of them); odd size: the bank rule below
 struct Env {
   double q[NV], v[NV], ctrl[7], time, warm[NV];
   double sw[3];
@@ -135,33 +147,49 @@ struct Env {
   // acceleration stage
   double qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV], act_force[7], touch;
   int clamped;  // bit u: actuator u sits on its force range
-  SIn bI[NV];   // the bodies' own spatial inertias of this configuration (crb and the velocity stage both need them)
-  // scratch of the stage that is running (composite inertias | spatial velocities, accelerations, forces | Hessian and its factor |
-  // the integrator's matrix and its factor): kept with the env so that it lives in LDS like the rest
-  double tmp[256];
+  double sx[NV], sy[NV];  // vector arguments / results of the out-of-line register blocks (pointer arguments would be FLAT + scratch)
+  int r1_bad;   // the integrating wavefront (role 1) saw a non-finite state during this control step
+  // scratch of the stage that is running (the velocity stage's spatial velocities, accelerations and forces, then the first rows of the
+  // constraint problem): kept with the env so that it lives in LDS like the rest
+  double tmp[TMP_DOUBLES];
 #ifdef MJS_BG_PROFILE
-  double dbg[6];  // clocks inside the solver: warm-start trials + first update | gradient + Hessian | factor + direction | J search + line search | update | (spare)
+  double prof1[8];  // role 1's stage clocks (see the kernel)
+  double dbg[6];  // clocks inside st_forces: (spare) | newton_direction | line search | update pass | factor-solve of M | the whole solver
 #endif
 };
+// LDS banks: lane l reads field f of ITS env at l * sizeof(Env) + f, 16 lanes at a time, up to 16 bytes per lane (ds_read_b128 /
+// ds_read2_b64). The stride in dwords must spread 16 lanes x 4 dwords over the 64 banks: 34 mod 64 does (l * 34 mod 64 = 0, 34, 4, 38,
+// 8, ..: every lane its own group of four banks); 26 mod 64 - the struct without the padding - cost 21 M conflict cycles per launch
+// (SQ_LDS_BANK_CONFLICT, profiles/r04_f_*).
+#ifndef MJS_BG_PROFILE
+static_assert(sizeof(Env) % 8 == 0 && (sizeof(Env) / 4) % 64 == 34, "Env stride vs the LDS banks");
+#endif
 MJS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-// Row workspace of one env. The first LROWS rows live in LDS (they alias the env's stage scratch e.tmp: mj_step1 runs the stages that
-// need that scratch - crb, the velocity stage - BEFORE it makes the rows, and the integrator reuses it only after the solver is
-// done with them); a typical substep has 9 - 12 rows (7 equality rows, the couplers' stops, a contact), so the solver's row passes
-// - chains of dependent loads on a wavefront that has its SIMD to itself - mostly stay out of HBM. Rows from LROWS on are in the
-// handle's HBM workspace, CONTIGUOUS per env (ws[env][row][entry]): with 16 of 64 lanes carrying an env a struct-of-arrays layout
-// buys no coalescing, while env-major makes every entry a constant offset from one row pointer. One accessor serves both (the row
-// pointer is a generic one: FLAT loads).
-constexpr int LROWS = 256 / ROW_STRIDE;
+// Row workspace of one env. The first LROWS rows live in LDS (they alias the env's stage scratch e.tmp: the velocity stage, which
+// needs that scratch, runs BEFORE the rows are made on the same wavefront); a typical substep has 9 - 12 rows (7 equality rows, the
+// couplers' stops, a contact), so the solver's row passes - chains of dependent loads on a wavefront that has its SIMD to itself -
+// mostly stay out of HBM. Rows from LROWS on are in the handle's HBM workspace, CONTIGUOUS per env (ws[env][row][entry]): with 16 of
+// 64 lanes carrying an env a struct-of-arrays layout buys no coalescing, while env-major makes every entry a constant offset from one
+// row pointer. One accessor serves both (the row pointer is a generic one: FLAT loads).
+constexpr int LROWS = TMP_DOUBLES / ROW_STRIDE;
 struct Rows {
   double* base;  // the env's rows in HBM
   double* lds;   // the env's e.tmp
   MJS_DEV double* row(int r) const { return (r < LROWS ? lds : base) + r * ROW_STRIDE; }
   MJS_DEV double& at(int r, int k) const { return row(r)[k]; }
 };
+// The same rows when ALL of them are in LDS (nefc <= LROWS: the usual case). The accessor above selects between two address spaces,
+// which makes every row access a FLAT instruction - to the LDS aperture a slow one that also ties the vector-memory and the LDS
+// counters together (each access waits for the previous); with this type the compiler sees an LDS pointer and emits ds_read / ds_write.
+struct RowsLds {
+  double* lds;
+  MJS_DEV double* row(int r) const { return lds + r * ROW_STRIDE; }
+  MJS_DEV double& at(int r, int k) const { return row(r)[k]; }
+};
 
 // ------------------------------------------------------------------------------------------------ tree passes
 MJS_HD void kinematics(const Model& m, Env& e) {
-#pragma unroll 1
+BG_TREE_LOOP
   for (int b = 0; b < NV; b++) {
     const int p = PBf(b);
     double R0[9], x0[3], tmp[3];
@@ -263,33 +291,24 @@ inline void chol_solve_host(const double* L, double* x) {
     x[i] = s / L[tri(i, i)];
   }
 }
-__device__ __noinline__ bool chol_factor_dev(const double* A, double* L) {
-  double a[NTRI];
-#pragma unroll
-  for (int k = 0; k < NTRI; k++) a[k] = A[k];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NV; j++) {
-    double d = a[tri(j, j)];
-#pragma unroll
-    for (int k = 0; k < j; k++) d -= a[tri(j, k)] * a[tri(j, k)];
-    if (!(d >= MJS_MINVAL)) { ok = false; d = MJS_MINVAL; }
-    const double ljj = sqrt(d);
-    a[tri(j, j)] = ljj;
-#pragma unroll
-    for (int i = j + 1; i < NV; i++) {
-      double s = a[tri(i, j)];
-#pragma unroll
-      for (int k = 0; k < j; k++) s -= a[tri(i, k)] * a[tri(j, k)];
-      a[tri(i, j)] = s / ljj;
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NTRI; k++) L[k] = a[k];
-  return ok;
+extern __shared__ double lds_envs[];
+MJS_DEV Env& my_env() { return reinterpret_cast<Env*>(lds_envs)[threadIdx.x & 63]; }  // both wavefronts of a workgroup: lane l <-> env l
+#define BG_OFF(field) ((int)(offsetof(Env, field) / sizeof(double)))
+// 1 / sqrt(d) for d >= MJS_MINVAL: v_rsq_f64 refined by two Newton steps (y <- y + y (1 - d y^2) / 2; the second in the residual form
+// brings the result to within an ulp or two of the correctly rounded value); replaces a sqrt and 14 - j divisions per Cholesky column
+MJS_DEV double inv_sqrt(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  double h = 0.5 * y, r = fma(-d * y, y, 1.0);
+  y = fma(h, r, y);
+  h = 0.5 * y; r = fma(-d * y, y, 1.0);
+  return fma(h, r, y);
 }
 // x <- A^-1 x for a packed symmetric positive definite A: factorisation and both substitutions in registers, nothing stored but x
-__device__ __noinline__ void factor_solve_dev(const double* A, double* x) {
+template <int XO>
+BG_NEWTON_INLINE void factor_solve_env() {  // e[XO..] <- M^-1 e[XO..] (fields of the env, addressed by their offset in doubles)
+  Env& e = my_env();
+  double* const x = reinterpret_cast<double*>(&e) + XO;
+  const double* const A = e.M;
   double a[NTRI], y[NV];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) a[k] = A[k];
@@ -301,14 +320,14 @@ __device__ __noinline__ void factor_solve_dev(const double* A, double* x) {
 #pragma unroll
     for (int k = 0; k < j; k++) d -= a[tri(j, k)] * a[tri(j, k)];
     if (!(d >= MJS_MINVAL)) d = MJS_MINVAL;
-    const double ljj = sqrt(d);
-    a[tri(j, j)] = ljj;
+    const double inv = inv_sqrt(d);  // the diagonal holds 1 / l_jj: one reciprocal square root per column instead of 14 - j divisions
+    a[tri(j, j)] = inv;
 #pragma unroll
     for (int i = j + 1; i < NV; i++) {
       double sij = a[tri(i, j)];
 #pragma unroll
       for (int k = 0; k < j; k++) sij -= a[tri(i, k)] * a[tri(j, k)];
-      a[tri(i, j)] = sij / ljj;
+      a[tri(i, j)] = sij * inv;
     }
   }
 #pragma unroll
@@ -316,44 +335,25 @@ __device__ __noinline__ void factor_solve_dev(const double* A, double* x) {
     double sy = y[i];
 #pragma unroll
     for (int k = 0; k < i; k++) sy -= a[tri(i, k)] * y[k];
-    y[i] = sy / a[tri(i, i)];
+    y[i] = sy * a[tri(i, i)];
   }
 #pragma unroll
   for (int i = NV - 1; i >= 0; i--) {
     double sy = y[i];
 #pragma unroll
     for (int k = i + 1; k < NV; k++) sy -= a[tri(k, i)] * y[k];
-    y[i] = sy / a[tri(i, i)];
-  }
-#pragma unroll
-  for (int k = 0; k < NV; k++) x[k] = y[k];
-}
-// x <- (L L^T)^-1 x, L and x in registers
-__device__ __noinline__ void chol_solve_dev(const double* L, double* x) {
-  double a[NTRI], y[NV];
-#pragma unroll
-  for (int k = 0; k < NTRI; k++) a[k] = L[k];
-#pragma unroll
-  for (int k = 0; k < NV; k++) y[k] = x[k];
-#pragma unroll
-  for (int i = 0; i < NV; i++) {
-    double s = y[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) s -= a[tri(i, k)] * y[k];
-    y[i] = s / a[tri(i, i)];
-  }
-#pragma unroll
-  for (int i = NV - 1; i >= 0; i--) {
-    double s = y[i];
-#pragma unroll
-    for (int k = i + 1; k < NV; k++) s -= a[tri(k, i)] * y[k];
-    y[i] = s / a[tri(i, i)];
+    y[i] = sy * a[tri(i, i)];
   }
 #pragma unroll
   for (int k = 0; k < NV; k++) x[k] = y[k];
 }
 // y = M x with the packed symmetric M in registers
-__device__ __noinline__ void sym_mul_dev(const double* M, const double* x, double* y) {
+template <int XO, int YO>
+BG_NEWTON_INLINE void sym_mul_env() {  // e[YO..] = M e[XO..]
+  Env& e = my_env();
+  const double* const M = e.M;
+  const double* const x = reinterpret_cast<double*>(&e) + XO;
+  double* const y = reinterpret_cast<double*>(&e) + YO;
   double a[NTRI], xx[NV];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) a[k] = M[k];
@@ -367,32 +367,48 @@ __device__ __noinline__ void sym_mul_dev(const double* M, const double* x, doubl
     y[i] = s;
   }
 }
-// mj_crb + armature -> M (packed); the caller factorises it (chol_factor_dev / chol_factor_host)
-MJS_HD void crb(const Model& m, Env& e) {
-  SIn* c = reinterpret_cast<SIn*>(e.tmp);
-  static_assert(sizeof(SIn) * NV <= sizeof(double) * 256, "composite inertias fit the stage scratch");
-#pragma unroll 1
-  for (int b = 0; b < NV; b++) { body_inertia(m, e, b, e.bI[b]); c[b] = e.bI[b]; }
-#pragma unroll 1
-  for (int b = NV - 1; b > 0; b--) {
-    const int p = PBf(b);
-    if (p < 0) continue;
-    for (int k = 0; k < 6; k++) c[p].I[k] += c[b].I[k];
-    for (int k = 0; k < 3; k++) c[p].h[k] += c[b].h[k];
-    c[p].mass += c[b].mass;
+// mj_crb + armature -> M (packed); the callers factorise it (factor_solve_dev / chol_factor_host). The tree is the arm's chain with four
+// two-body branches on wrist_3 (PBf), so the composite inertias are accumulated in registers - branch by branch, then up the chain -
+// and nothing but M is written: the pass needs no scratch and can run next to the velocity stage of the other wavefront.
+MJS_HD void sin_add(SIn& a, const SIn& b) {
+  for (int k = 0; k < 6; k++) a.I[k] += b.I[k];
+  for (int k = 0; k < 3; k++) a.h[k] += b.h[k];
+  a.mass += b.mass;
+}
+MJS_HD void crb_row(const Model& m, Env& e, int i, const SIn& c) {  // M[i][j] for j = i and its ancestors
+  double f[6];
+  sin_mul(c, e.S[i], f);
+  for (int j = i; j >= 0; j = PBf(j)) {
+    double v = 0;
+    for (int k = 0; k < 6; k++) v += e.S[j][k] * f[k];
+    e.M[tri(i, j)] = v;
   }
-#pragma unroll 1
+  e.M[tri(i, i)] += m.armature[i];
+}
+MJS_HD void crb(const Model& m, Env& e) {
+BG_TREE_LOOP
   for (int k = 0; k < NTRI; k++) e.M[k] = 0;
-#pragma unroll 1
-  for (int i = 0; i < NV; i++) {
-    double f[6];
-    sin_mul(c[i], e.S[i], f);
-    for (int j = i; j >= 0; j = PBf(j)) {
-      double v = 0;
-      for (int k = 0; k < 6; k++) v += e.S[j][k] * f[k];
-      e.M[tri(i, j)] = v;
-    }
-    e.M[tri(i, i)] += m.armature[i];
+  SIn acc;
+  for (int k = 0; k < 6; k++) acc.I[k] = 0;
+  for (int k = 0; k < 3; k++) acc.h[k] = 0;
+  acc.mass = 0;
+BG_TREE_LOOP
+  for (int br = 0; br < 4; br++) {  // (driver, coupler), (spring_link, follower) of the right finger, then of the left one
+    const int pb = NA + 2 * br, cb = pb + 1;
+    SIn c, own;
+    body_inertia(m, e, cb, c);
+    crb_row(m, e, cb, c);
+    body_inertia(m, e, pb, own);
+    sin_add(c, own);
+    crb_row(m, e, pb, c);
+    sin_add(acc, c);
+  }
+BG_TREE_LOOP
+  for (int b = NA - 1; b >= 0; b--) {
+    SIn own;
+    body_inertia(m, e, b, own);
+    sin_add(acc, own);
+    crb_row(m, e, b, acc);
   }
 }
 
@@ -410,8 +426,8 @@ MJS_HD void jac_point(const Env& e, int b, const double* p, double jt[3][NV]) {
 // mj_comVel + mj_rne (flg_acc = 0) + mj_passive (damping, springs, gravity compensation of the arm's own bodies)
 MJS_DEV void velocity_stage(const Model& m, Env& e) {
   double (*cvel)[6] = reinterpret_cast<double (*)[6]>(e.tmp), (*cacc)[6] = cvel + NV, (*cfrc)[6] = cvel + 2 * NV;
-  static_assert(3 * NV * 6 <= 256, "spatial vectors fit the stage scratch");
-#pragma unroll 1
+  static_assert(3 * NV * 6 <= TMP_DOUBLES, "spatial vectors fit the stage scratch");
+BG_TREE_LOOP
   for (int b = 0; b < NV; b++) {
     const int p = PBf(b);
     double vp[6] = {0, 0, 0, 0, 0, 0}, ap[6] = {0, 0, 0, 0, 0, -MJS_GRAVITY_Z};
@@ -420,27 +436,28 @@ MJS_DEV void velocity_stage(const Model& m, Env& e) {
     double sd[6];
     cross_motion6(vp, e.S[b], sd);
     for (int k = 0; k < 6; k++) { cacc[b][k] = ap[k] + sd[k] * e.v[b]; cvel[b][k] = vp[k] + e.S[b][k] * e.v[b]; }
-    const SIn& I = e.bI[b];  // of this configuration (st_crb ran before)
+    SIn I;  // the body's own spatial inertia of this configuration (recomputed here rather than shared with crb: the two run on
+    body_inertia(m, e, b, I);  // different wavefronts at the same time)
     double Ia[6], Iv[6], vIv[6];
     sin_mul(I, cacc[b], Ia);
     sin_mul(I, cvel[b], Iv);
     cross_force6(cvel[b], Iv, vIv);
     for (int k = 0; k < 6; k++) cfrc[b][k] = Ia[k] + vIv[k];
   }
-#pragma unroll 1
+BG_TREE_LOOP
   for (int b = NV - 1; b > 0; b--) {
     const int p = PBf(b);
     if (p >= 0)
       for (int k = 0; k < 6; k++) cfrc[p][k] += cfrc[b][k];
   }
-#pragma unroll 1
+BG_TREE_LOOP
   for (int b = 0; b < NV; b++) {
     double s = 0;
     for (int k = 0; k < 6; k++) s += e.S[b][k] * cfrc[b][k];
     e.bias[b] = s;
     e.passive[b] = -m.damping[b] * e.v[b] - (m.stiffness[b] != 0 ? m.stiffness[b] * (e.q[b] - m.springref[b]) : 0.0);
   }
-#pragma unroll 1
+BG_TREE_LOOP
   for (int b = 0; b < NV; b++) {
     if (m.gravcomp[b] == 0) continue;
     double c[3], tmp[3];
@@ -581,15 +598,37 @@ MJS_DEV void collision(const Model& m, Env& e) {
       }
     }
   }
+  // Guards for the pads' pairs: both pad boxes of a side lie within pad_reach of the follower's origin, so a side whose sphere is
+  // clear of the floor / the switch / the other side's sphere cannot produce a contact there (detection has no margin: a contact
+  // exists only where the geoms touch), and its geoms are not even built. Pair ORDER is unchanged for the pairs that remain.
+  double fo[2][3];
+  for (int s = 0; s < 2; s++)
+    for (int k = 0; k < 3; k++) fo[s][k] = e.xpos[s == 0 ? B_RFOLLOWER : B_LFOLLOWER][k];
+  bool near_floor[2], near_switch[2];
+  static_assert(MJS_SW_BOX_HALF == 0.025 && MJS_SW_BUTTON_Z == 0.05 && MJS_SW_BUTTON_HALF == 0.02 && MJS_SW_BUTTON_RADIUS == 0.02, "the switch's bounding sphere below");
+  constexpr double SW_REACH = 0.0567;  // the switch box and the button about (sw.x, sw.y, sw.z + 0.035): |(0.025, 0.025, 0.035)| = 0.0495, button top corner 0.0403
+  for (int s = 0; s < 2; s++) {
+    near_floor[s] = fo[s][2] <= m.pad_reach[s];
+    const double dx = fo[s][0] - e.sw[0], dy = fo[s][1] - e.sw[1], dz = fo[s][2] - (e.sw[2] + 0.035), rr_ = m.pad_reach[s] + SW_REACH;
+    near_switch[s] = dx * dx + dy * dy + dz * dz <= rr_ * rr_;
+  }
+  bool near_pads;
+  {
+    const double dx = fo[0][0] - fo[1][0], dy = fo[0][1] - fo[1][1], dz = fo[0][2] - fo[1][2], rr_ = m.pad_reach[0] + m.pad_reach[1];
+    near_pads = dx * dx + dy * dy + dz * dz <= rr_ * rr_;
+  }
+  const bool need_side[2] = {near_floor[0] || near_switch[0] || near_pads, near_floor[1] || near_switch[1] || near_pads};
   // the pads' geoms
   pp::Geom pad[2][2];
   double pc[2][2][3], pR[2][9];
 #pragma unroll 1
   for (int s = 0; s < 2; s++)
-    for (int k = 0; k < 2; k++) pad_geom(m, e, s, k, pad[s][k], pc[s][k], pR[s]);
+    if (need_side[s])
+      for (int k = 0; k < 2; k++) pad_geom(m, e, s, k, pad[s][k], pc[s][k], pR[s]);
   // floor vs pad boxes (mjc_PlaneBox: corners at or below the plane, x index fastest, at most 4)
 #pragma unroll 1
-  for (int s = 0; s < 2; s++)
+  for (int s = 0; s < 2; s++) {
+    if (!near_floor[s]) continue;
 #pragma unroll 1
     for (int k = 0; k < 2; k++) {
       int cnt = 0;
@@ -607,35 +646,45 @@ MJS_DEV void collision(const Model& m, Env& e) {
         cnt++;
       }
     }
+  }
   // the arm's wrist cylinder (proxy 9) vs the switch box (cylinder - box: the cylinder is geom1)
   const pp::Geom box = static_box(e.sw), button = static_button(e.sw);
   {
     pp::Geom cyl;
     constexpr int g = MJS_UR_NCOLGEOM - 1;
     const int b = B_WRIST3;
-    double gp[3], tmp[3], gR[9];
+    double gp[3], tmp[3];
     mat_vec(e.xmat[b], m.col_pos[g], tmp);
     for (int k = 0; k < 3; k++) gp[k] = e.xpos[b][k] + tmp[k];
-    double lq[9];
-    quat_to_mat(MJS_UR_COL_QUAT[g], lq);
-    mat_mul(e.xmat[b], lq, gR);
-    cyl.c = v3(gp[0], gp[1], gp[2]);
-    cyl.R = M3{v3(gR[0], gR[3], gR[6]), v3(gR[1], gR[4], gR[7]), v3(gR[2], gR[5], gR[8])};
-    cyl.s = v3(MJS_UR_COL_SIZE[g][0], MJS_UR_COL_SIZE[g][1], 0);
-    cyl.box = false; cyl.cat = -1;
-    convex_pair(e, cyl, box, b, -1, default_pair(), m.invw_body[b], true);
+    const double dx = gp[0] - box.c.x, dy = gp[1] - box.c.y, dz = gp[2] - box.c.z;
+    const double rb = 0.0434 + sqrt(MJS_UR_COL_SIZE[g][0] * MJS_UR_COL_SIZE[g][0] + MJS_UR_COL_SIZE[g][1] * MJS_UR_COL_SIZE[g][1]);  // box: |(0.025)^3| = 0.04331
+    if (dx * dx + dy * dy + dz * dz <= rb * rb) {
+      double gR[9], lq[9];
+      quat_to_mat(MJS_UR_COL_QUAT[g], lq);
+      mat_mul(e.xmat[b], lq, gR);
+      cyl.c = v3(gp[0], gp[1], gp[2]);
+      cyl.R = M3{v3(gR[0], gR[3], gR[6]), v3(gR[1], gR[4], gR[7]), v3(gR[2], gR[5], gR[8])};
+      cyl.s = v3(MJS_UR_COL_SIZE[g][0], MJS_UR_COL_SIZE[g][1], 0);
+      cyl.box = false; cyl.cat = -1;
+      convex_pair(e, cyl, box, b, -1, default_pair(), m.invw_body[b], true);
+    }
   }
   // pad pairs in geom order: right pad k vs (left pad 0, left pad 1, switch box, button), then left pad k vs (switch box, button)
 #pragma unroll 1
   for (int k = 0; k < 2; k++) {
-    for (int l = 0; l < 2; l++) convex_pair(e, pad[0][k], pad[1][l], B_RFOLLOWER, B_LFOLLOWER, pad_pair(fmax(m.pad_friction[k], m.pad_friction[l])), m.invw_pad[0] + m.invw_pad[1], false);
-    convex_pair(e, pad[0][k], box, B_RFOLLOWER, -1, pad_pair(m.pad_friction[k]), m.invw_pad[0], true);
-    convex_pair(e, button, pad[0][k], -1, B_RFOLLOWER, pad_pair(m.pad_friction[k]), m.invw_pad[0], true);  // cylinder before box (geom type order)
+    if (near_pads)
+      for (int l = 0; l < 2; l++) convex_pair(e, pad[0][k], pad[1][l], B_RFOLLOWER, B_LFOLLOWER, pad_pair(fmax(m.pad_friction[k], m.pad_friction[l])), m.invw_pad[0] + m.invw_pad[1], false);
+    if (near_switch[0]) {
+      convex_pair(e, pad[0][k], box, B_RFOLLOWER, -1, pad_pair(m.pad_friction[k]), m.invw_pad[0], true);
+      convex_pair(e, button, pad[0][k], -1, B_RFOLLOWER, pad_pair(m.pad_friction[k]), m.invw_pad[0], true);  // cylinder before box (geom type order)
+    }
   }
+  if (near_switch[1]) {
 #pragma unroll 1
-  for (int k = 0; k < 2; k++) {
-    convex_pair(e, pad[1][k], box, B_LFOLLOWER, -1, pad_pair(m.pad_friction[k]), m.invw_pad[1], true);
-    convex_pair(e, button, pad[1][k], -1, B_LFOLLOWER, pad_pair(m.pad_friction[k]), m.invw_pad[1], true);
+    for (int k = 0; k < 2; k++) {
+      convex_pair(e, pad[1][k], box, B_LFOLLOWER, -1, pad_pair(m.pad_friction[k]), m.invw_pad[1], true);
+      convex_pair(e, button, pad[1][k], -1, B_LFOLLOWER, pad_pair(m.pad_friction[k]), m.invw_pad[1], true);
+    }
   }
 }
 #pragma clang fp contract(fast)
@@ -659,7 +708,8 @@ MJS_DEV KBI kbi(double timeconst, double d0, double dmax, double width, double p
   o.B = 2 / fmax(MJS_MINVAL, dmax * tc);
   return o;
 }
-MJS_DEV void put_row(const Rows& w, int r, const double* J, double pos, double D, double aref) {
+template <class RW>
+MJS_DEV void put_row(const RW& w, int r, const double* J, double pos, double D, double aref) {
   for (int k = 0; k < NV; k++) w.at(r, ROW_J + k) = J[k];
   w.at(r, ROW_POS) = pos; w.at(r, ROW_D) = D; w.at(r, ROW_AREF) = aref;
 }
@@ -668,8 +718,10 @@ MJS_DEV double row_vel(const Env& e, const double* J) {
   for (int k = 0; k < NV; k++) s += J[k] * e.v[k];
   return s;
 }
-// mj_makeConstraint + mj_makeImpedance + mj_referenceConstraint
-MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
+// mj_makeConstraint + mj_makeImpedance + mj_referenceConstraint, in two parts: the equality and joint-limit rows need the positions and
+// velocities only; the contact rows need the contacts of the collision stage (which runs on the other wavefront meanwhile)
+template <class RW>
+MJS_DEV void make_rows_eq(const Model& m, Env& e, const RW& w) {
   int r = 0;
   double J[NV], jt1[3][NV], jt2[3][NV];
   // connect: follower origin (body1, anchor 0 0 0) = the coupler's anchor
@@ -714,7 +766,13 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
       e.rtype[r++] = 1;
       e.nlim++;
     }
-  // contacts: elliptic cones, condim 3: the contact frame's rows applied to (jac2 - jac1)
+  e.nefc = r;
+}
+// contacts: elliptic cones, condim 3: the contact frame's rows applied to (jac2 - jac1)
+template <class RW>
+MJS_DEV void make_rows_contacts(const Model& m, Env& e, const RW& w) {
+  int r = e.nefc;
+  double J[NV], jt1[3][NV], jt2[3][NV];
 #pragma unroll 1
   for (int c = 0; c < e.ncon; c++) {
     Contact& con = e.con[c];
@@ -758,20 +816,21 @@ MJS_DEV void make_rows(const Model& m, Env& e, const Rows& w) {
 // The stages are OUT OF LINE, one copy each, and find their env in LDS themselves (an Env& argument would make every access a
 // FLAT one): a control step runs them 20 times, resets run them too, and inlined into the four call contexts the kernel was
 // 62 k instructions - far beyond the instruction cache, which the substep loop streams through once per substep.
-extern __shared__ double lds_envs[];
-MJS_DEV Env& my_env() { return reinterpret_cast<Env*>(lds_envs)[threadIdx.x]; }
 __device__ __noinline__ void st_kinematics() { kinematics(g_model, my_env()); }
 __device__ __noinline__ void st_crb() { crb(g_model, my_env()); }
 __device__ __noinline__ void st_collision() { collision(g_model, my_env()); }
-__device__ __noinline__ void st_rows(double* ws_lane) { Env& e = my_env(); make_rows(g_model, e, Rows{ws_lane, e.tmp}); }
+static_assert(NEQ_ROWS + MAXLIM <= LROWS, "the equality and limit rows are always in LDS");
+__device__ __noinline__ void st_rows_eq() { Env& e = my_env(); make_rows_eq(g_model, e, RowsLds{e.tmp}); }
+__device__ __noinline__ void st_rows_contacts(double* ws_lane) { Env& e = my_env(); make_rows_contacts(g_model, e, Rows{ws_lane, e.tmp}); }
 __device__ __noinline__ void st_velocity() { velocity_stage(g_model, my_env()); }
-// mj_step1: position + velocity stages
-MJS_DEV void step1(const Model& m, Env& e, const Rows& w, double* prof) {
-  BG_T(0, st_kinematics());
-  BG_T(1, st_crb());
-  BG_T(4, st_velocity());  // (before the rows: it uses the stage scratch the first rows alias)
-  BG_T(2, st_collision());
-  BG_T(3, st_rows(w.base));
+// mj_step1 on ONE wavefront (resets): position + velocity stages
+MJS_DEV void step1(const Model& m, Env& e, const Rows& w) {
+  st_kinematics();
+  st_crb();
+  st_velocity();  // (before the rows: it uses the stage scratch the first rows alias)
+  st_collision();
+  st_rows_eq();
+  st_rows_contacts(w.base);
 }
 
 // ------------------------------------------------------------------------------------------------ forces and the solver
@@ -804,7 +863,8 @@ MJS_DEV void actuation(const Model& m, Env& e, double* qfrc_act) {
 // constraint cost, and grad = Ma - qfrc_smooth - J^T f; returns the cost incl. the Gauss term. The oracle walks the rows once per
 // quantity; fused here because every pass over the HBM row workspace is a chain of dependent loads on a wavefront that has its
 // SIMD to itself.
-MJS_DEV double rows_pass(Env& e, const Rows& w, const double* qacc, const double* Ma, bool fresh, double alpha, double* grad) {
+template <class RW>
+MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* Ma, bool fresh, double alpha, double* grad) {
   double cost = 0;
   for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
 #pragma unroll 1
@@ -858,9 +918,9 @@ MJS_DEV double rows_pass(Env& e, const Rows& w, const double* qacc, const double
   for (int i = 0; i < NV; i++) gauss += (Ma[i] - e.qfrc_smooth[i]) * (qacc[i] - e.qacc_smooth[i]);
   return cost + 0.5 * gauss;
 }
-MJS_DEV void mul_M(const Env& e, const double* x, double* y) { sym_mul_dev(e.M, x, y); }
 // exact 1-D minimiser of the cost along the search direction (1-D Newton with bracketing, MuJoCo's gradient stopping rule)
-MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double gtol) {
+template <class RW>
+MJS_DEV double line_search(Env& e, const RW& w, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
 #pragma unroll 1
   for (int it = 0; it < 50; it++) {
@@ -912,9 +972,15 @@ MJS_DEV double line_search(Env& e, const Rows& w, double g1, double g2, double g
 // Newton direction, out of line and in REGISTERS: H = M + sum over the active rows D J^T J + the cone blocks is accumulated in 105
 // registers (rows in a run-time loop, the 14 x 14 triangle unrolled), factorised in place and back-substituted for search = -H^-1 grad
 // and J search is written to the rows' JV entries; nothing of H touches memory. Returns false when H is not positive definite.
-__device__ __noinline__ bool newton_direction(double* ws_env, const double* grad, double* search) {
+template <class RW> MJS_DEV RW rows_of(double* ws_env, Env& e);
+template <> MJS_DEV Rows rows_of<Rows>(double* ws_env, Env& e) { return Rows{ws_env, e.tmp}; }
+template <> MJS_DEV RowsLds rows_of<RowsLds>(double*, Env& e) { return RowsLds{e.tmp}; }
+template <class RW>
+BG_NEWTON_INLINE bool newton_direction(double* ws_env) {  // gradient in e.sx, search direction out in e.sy
   Env& e = my_env();
-  const Rows w{ws_env, e.tmp};
+  const double* const grad = e.sx;
+  double* const search = e.sy;
+  const RW w = rows_of<RW>(ws_env, e);
   double h[NTRI];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) h[k] = e.M[k];
@@ -968,7 +1034,7 @@ __device__ __noinline__ bool newton_direction(double* ws_env, const double* grad
       for (int j = 0; j <= i; j++) h[tri(i, j)] += dj * Jr[j];
     }
   }
-  // Cholesky in place
+  // Cholesky in place (the diagonal holds 1 / l_jj)
   bool ok = true;
 #pragma unroll
   for (int j = 0; j < NV; j++) {
@@ -976,14 +1042,14 @@ __device__ __noinline__ bool newton_direction(double* ws_env, const double* grad
 #pragma unroll
     for (int k = 0; k < j; k++) d -= h[tri(j, k)] * h[tri(j, k)];
     if (!(d >= MJS_MINVAL)) { ok = false; d = MJS_MINVAL; }
-    const double ljj = sqrt(d);
-    h[tri(j, j)] = ljj;
+    const double inv = inv_sqrt(d);
+    h[tri(j, j)] = inv;
 #pragma unroll
     for (int i = j + 1; i < NV; i++) {
       double sij = h[tri(i, j)];
 #pragma unroll
       for (int k = 0; k < j; k++) sij -= h[tri(i, k)] * h[tri(j, k)];
-      h[tri(i, j)] = sij / ljj;
+      h[tri(i, j)] = sij * inv;
     }
   }
   double y[NV];
@@ -994,14 +1060,14 @@ __device__ __noinline__ bool newton_direction(double* ws_env, const double* grad
     double sy = y[i];
 #pragma unroll
     for (int k = 0; k < i; k++) sy -= h[tri(i, k)] * y[k];
-    y[i] = sy / h[tri(i, i)];
+    y[i] = sy * h[tri(i, i)];
   }
 #pragma unroll
   for (int i = NV - 1; i >= 0; i--) {
     double sy = y[i];
 #pragma unroll
     for (int k = i + 1; k < NV; k++) sy -= h[tri(k, i)] * y[k];
-    y[i] = sy / h[tri(i, i)];
+    y[i] = sy * h[tri(i, i)];
   }
 #pragma unroll
   for (int i = 0; i < NV; i++) search[i] = y[i];
@@ -1016,7 +1082,9 @@ __device__ __noinline__ bool newton_direction(double* ws_env, const double* grad
   return ok;
 }
 // mj_fwdConstraint: primal Newton (mj_solPrimal) warm-started from the cheaper of qacc_warmstart and qacc_smooth
-MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
+// PRE: M qacc_warmstart was computed by the other wavefront meanwhile (it waits in e.qacc, which the solver only writes at its end)
+template <bool PRE, class RW>
+MJS_DEV void solve(const Model& m, Env& e, const RW& w, double* ws_env) {
   if (e.nefc == 0) {
     for (int i = 0; i < NV; i++) { e.qacc[i] = e.qacc_smooth[i]; e.qfrc_constraint[i] = 0; }
     return;
@@ -1029,7 +1097,11 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
     double ma_s[NV], ma_w[NV], grad_s[NV];
     for (int i = 0; i < NV; i++) ma_s[i] = e.qfrc_smooth[i];
     const double c_s = rows_pass(e, w, e.qacc_smooth, ma_s, true, 0.0, grad_s);
-    mul_M(e, e.warm, ma_w);
+    if (PRE) { for (int i = 0; i < NV; i++) ma_w[i] = e.qacc[i]; }
+    else {
+      sym_mul_env<BG_OFF(warm), BG_OFF(sy)>();
+      for (int i = 0; i < NV; i++) ma_w[i] = e.sy[i];
+    }
     const double c_w = rows_pass(e, w, e.warm, ma_w, true, 0.0, grad);
     if (c_s < c_w) {
       for (int i = 0; i < NV; i++) { qacc[i] = e.qacc_smooth[i]; Ma[i] = ma_s[i]; }
@@ -1044,16 +1116,21 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
     BG_COUNT(e, 0);
-    if (!newton_direction(w.base, grad, search)) break;
-    mul_M(e, search, Mv);
+    bool pd;
+    for (int i = 0; i < NV; i++) e.sx[i] = grad[i];
+    BG_S(e, 1, pd = newton_direction<RW>(ws_env));
+    if (!pd) break;
+    sym_mul_env<BG_OFF(sy), BG_OFF(sx)>();
+    for (int i = 0; i < NV; i++) { search[i] = e.sy[i]; Mv[i] = e.sx[i]; }
     double g1 = 0, g2 = 0, snorm = 0;
     for (int i = 0; i < NV; i++) { g1 += search[i] * (Ma[i] - e.qfrc_smooth[i]); g2 += search[i] * Mv[i]; snorm += search[i] * search[i]; }
     if (sqrt(snorm) < MJS_MINVAL) break;
-    const double alpha = line_search(e, w, g1, g2, MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale);
+    double alpha;
+    BG_S(e, 2, alpha = line_search(e, w, g1, g2, MJS_SOLVER_TOLERANCE * 0.01 * sqrt(snorm) / scale));
     if (alpha == 0) break;
     for (int i = 0; i < NV; i++) { qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
     const double oldcost = cost;
-    cost = rows_pass(e, w, qacc, Ma, false, alpha, grad);
+    BG_S(e, 3, cost = rows_pass(e, w, qacc, Ma, false, alpha, grad));
     double gn = 0;
     for (int i = 0; i < NV; i++) gn += grad[i] * grad[i];
     if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;
@@ -1062,7 +1139,8 @@ MJS_DEV void solve(const Model& m, Env& e, const Rows& w) {
   for (int i = 0; i < NV; i++) { e.qacc[i] = qacc[i]; e.qfrc_constraint[i] = Ma[i] - e.qfrc_smooth[i] - grad[i]; }
 }
 // mj_sensorAcc, touch: normal forces of the contacts of the switch body whose point lies in the site cylinder (button x 1.01)
-MJS_DEV void touch_sensor(Env& e, const Rows& w) {
+template <class RW>
+MJS_DEV void touch_sensor(Env& e, const RW& w) {
   e.touch = 0;
   for (int c = 0; c < e.ncon; c++) {
     const Contact& con = e.con[c];
@@ -1074,49 +1152,109 @@ MJS_DEV void touch_sensor(Env& e, const Rows& w) {
   }
 }
 // mj_fwdActuation + mj_fwdAcceleration + mj_fwdConstraint + mj_sensorAcc on the rows of the last step1
-MJS_DEV void forces(const Model& m, Env& e, const Rows& w) {
+MJS_DEV void forces_smooth(const Model& m, Env& e) {
   double act[NV];
   actuation(m, e, act);
   for (int i = 0; i < NV; i++) { e.qfrc_smooth[i] = e.passive[i] - e.bias[i] + act[i]; e.qacc_smooth[i] = e.qfrc_smooth[i]; }
-  factor_solve_dev(e.M, e.qacc_smooth);  // mj_fwdAcceleration (the factor of M is not needed again)
-  solve(m, e, w);
-  touch_sensor(e, w);
+  BG_S(e, 4, factor_solve_env<BG_OFF(qacc_smooth)>());  // mj_fwdAcceleration (the factor of M is not needed again)
 }
-// mj_step2 after the forces: warm start, implicitfast velocity update, position integration
-MJS_DEV bool integrate(const Model& m, Env& e) {
-  bool bad = false;
-  double* const A = e.tmp;
-  double qa[NV];
-#pragma unroll 1
-  for (int k = 0; k < NTRI; k++) A[k] = e.M[k];
-  for (int i = 0; i < NV; i++) {
-    bad = bad || bad_value(e.qacc[i]);
-    e.warm[i] = e.qacc[i];
-    A[tri(i, i)] += MJS_RR_PHYSICS_DT * m.damping[i];
-    qa[i] = e.qfrc_smooth[i] + e.qfrc_constraint[i];
+template <bool PRE>
+MJS_DEV void forces_constraint(const Model& m, Env& e, double* ws_env) {
+  if (e.nefc <= LROWS) {  // every row is in LDS
+    const RowsLds w{e.tmp};
+    BG_S(e, 5, (solve<PRE, RowsLds>(m, e, w, ws_env)));
+    touch_sensor(e, w);
+  } else {
+    const Rows w{ws_env, e.tmp};
+    BG_S(e, 5, (solve<PRE, Rows>(m, e, w, ws_env)));
+    touch_sensor(e, w);
   }
+}
+// mj_step2 after the forces (warm start, implicitfast velocity update, position integration) on the INTEGRATING wavefront (role 1): the
+// matrix M + dt (damping + the unclamped actuators' velocity gains) depends on what is known before the solver starts, so it is
+// factorised - in registers - WHILE role 0 solves the constraints; the workgroup barrier in the middle is the solver's completion
+// (role 0 executes the matching barrier after st_solve), after which only the two substitutions and the state update remain.
+__device__ __noinline__ void st_integrate_split() {
+  const Model& m = g_model;
+  Env& e = my_env();
+  double a[NTRI], y[NV];
+#pragma unroll
+  for (int k = 0; k < NTRI; k++) a[k] = e.M[k];
+#pragma unroll
+  for (int i = 0; i < NV; i++) a[tri(i, i)] += MJS_RR_PHYSICS_DT * m.damping[i];
 #pragma unroll
   for (int u = 0; u < NA; u++)
-    if (!(e.clamped & (1 << u))) A[tri(u, u)] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[u];
+    if (!(e.clamped & (1 << u))) a[tri(u, u)] += MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[u];
   if (!(e.clamped & (1 << 6))) {
     const double kk = MJS_RR_PHYSICS_DT * MJS_G2F85_ACT_KV * MJS_G85_TENDON_COEF * MJS_G85_TENDON_COEF;
-    A[tri(B_RDRIVER, B_RDRIVER)] += kk; A[tri(B_LDRIVER, B_LDRIVER)] += kk; A[tri(B_LDRIVER, B_RDRIVER)] += kk;
+    a[tri(B_RDRIVER, B_RDRIVER)] += kk; a[tri(B_LDRIVER, B_LDRIVER)] += kk; a[tri(B_LDRIVER, B_RDRIVER)] += kk;
   }
-  factor_solve_dev(A, qa);
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    double d = a[tri(j, j)];
+#pragma unroll
+    for (int k = 0; k < j; k++) d -= a[tri(j, k)] * a[tri(j, k)];
+    if (!(d >= MJS_MINVAL)) d = MJS_MINVAL;
+    const double inv = inv_sqrt(d);
+    a[tri(j, j)] = inv;
+#pragma unroll
+    for (int i = j + 1; i < NV; i++) {
+      double sij = a[tri(i, j)];
+#pragma unroll
+      for (int k = 0; k < j; k++) sij -= a[tri(i, k)] * a[tri(j, k)];
+      a[tri(i, j)] = sij * inv;
+    }
+  }
+  __syncthreads();  // the solver is done: qacc, qfrc_constraint
+  bool bad = false, far = false;
+#pragma unroll
   for (int i = 0; i < NV; i++) {
-    e.v[i] += MJS_RR_PHYSICS_DT * qa[i];
-    const double dq = MJS_RR_PHYSICS_DT * e.v[i];
-    e.q[i] += dq;
-    bad = bad || bad_value(e.q[i]) || bad_value(e.v[i]);
-    if (dq * dq <= 0.01) { double c = e.cs[i], sn_ = e.sn[i]; rr::rotate_small(c, sn_, dq); e.cs[i] = c; e.sn[i] = sn_; }
-    else sincos(e.q[i], &e.sn[i], &e.cs[i]);
+    const double qa = e.qacc[i];
+    bad = bad || bad_value(qa);
+    e.warm[i] = qa;
+    y[i] = e.qfrc_smooth[i] + e.qfrc_constraint[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sy -= a[tri(i, k)] * y[k];
+    y[i] = sy * a[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = NV - 1; i >= 0; i--) {
+    double sy = y[i];
+#pragma unroll
+    for (int k = i + 1; k < NV; k++) sy -= a[tri(k, i)] * y[k];
+    y[i] = sy * a[tri(i, i)];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) {
+    const double vi = e.v[i] + MJS_RR_PHYSICS_DT * y[i];
+    const double dq = MJS_RR_PHYSICS_DT * vi;
+    const double qi = e.q[i] + dq;
+    e.v[i] = vi; e.q[i] = qi;
+    bad = bad || bad_value(qi) || bad_value(vi);
+    double c = e.cs[i], sn_ = e.sn[i];
+    rr::rotate_small(c, sn_, dq);  // angle addition; exact again below when some joint of the env turned by more than 0.1 rad
+    e.cs[i] = c; e.sn[i] = sn_;
+    far = far || !(dq * dq <= 0.01);
+  }
+  if (far) {
+#pragma unroll 1
+    for (int i = 0; i < NV; i++) sincos(e.q[i], &e.sn[i], &e.cs[i]);
   }
   e.time += MJS_RR_PHYSICS_DT;
-  return bad;
+  if (bad) e.r1_bad = 1;
 }
 
-__device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces(g_model, e, Rows{ws_lane, e.tmp}); }
-__device__ __noinline__ bool st_integrate() { return integrate(g_model, my_env()); }
+__device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces_smooth(g_model, e); forces_constraint<false>(g_model, e, ws_lane); }  // one wavefront (resets)
+__device__ __noinline__ void st_smooth() { forces_smooth(g_model, my_env()); }
+#ifndef BG_PRE_MW
+#define BG_PRE_MW true
+#endif
+__device__ __noinline__ void st_solve(double* ws_lane) { Env& e = my_env(); forces_constraint<BG_PRE_MW>(g_model, e, ws_lane); }
+__device__ __noinline__ void st_mul_warm() { sym_mul_env<BG_OFF(warm), BG_OFF(qacc)>(); }  // role 1, while role 0 runs st_smooth
 
 // ------------------------------------------------------------------------------------------------ model compilation (host)
 // The role of MuJoCo's model compiler + mj_setConst for this scene: runs on the host at mjs_create, the result is copied into
@@ -1244,6 +1382,9 @@ inline void build_model(Model& m) {
     }
     mat_vec(rR[o], ob[o].ipos, tmp);
     for (int k = 0; k < 3; k++) m.pad_com[s][k] = rp[o][k] + tmp[k];
+    m.pad_reach[s] = 0;
+    for (int bx = 0; bx < 2; bx++)
+      m.pad_reach[s] = fmax(m.pad_reach[s], sqrt(dot3(m.pad_pos[s][bx], m.pad_pos[s][bx])) + sqrt(dot3(MJS_G85_PAD_SIZE, MJS_G85_PAD_SIZE)));
   }
   for (int k = 0; k < 3; k++) m.site_pos[k] = MJS_UR_FLANGE_POS[k];
   quat_to_mat(MJS_UR_FLANGE_QUAT, m.site_rot);
@@ -1340,8 +1481,7 @@ MJS_DEV uint8_t episode_init(const Model& m, const KernelParams& p, int i, Env& 
   e.ctrl[6] = 0;  // mj_resetData
   e.time = 0;
   e.overflow = false;
-  double prof[8];
-  step1(m, e, w, prof);
+  step1(m, e, w);
   st_forces(w.base);
   uint8_t f = old_flags & FLAG_SWITCH_PRESSED;  // was_pressed is stale from the previous episode (switch.py:53)
   bp::switch_update(e.touch, f);
@@ -1356,29 +1496,68 @@ MJS_DEV void reset_env(const Model& m, const KernelParams& p, int i, Env& e, con
   write_outputs<OBS_DIM>(p, i, obs, 0.0, 1.0, MJS_STEP_FIRST, false, false, false, e.overflow ? MJS_FAULT_UNSUPPORTED_CONTACT : 0, e.ncon);
 }
 
-// Envs per 64-lane workgroup (`epw` lanes work, the others leave at once): FP64 issue does not get faster with idle lanes, so
-// until every SIMD of the chip has a wavefront the envs are spread as thin as the LDS allows (4 per workgroup: 4 workgroups of
-// 4 x 9.6 KB per CU = one wavefront per SIMD at 4096 envs); larger batches take 8, 16, .. envs per workgroup (host: epw_for).
+// Envs per workgroup: `epw` lanes of each wavefront carry an env, the others leave at once (FP64 issue does not get faster with idle
+// lanes; the LDS holds 16 envs). A STEPPING workgroup has TWO wavefronts that share the envs in LDS, lane l of both working on env l:
+//   role 0: kinematics | crb (M), collision        | actuation, M^-1 qfrc_smooth | constraint solver, touch, switch |          |
+//   role 1:    (waits) | velocity stage, eq. rows  | contact rows                | factorises M + dt D              | integrate |
+//                      B1                          B2                            B3                                 B4         B5
+// five workgroup barriers per Physics.step(); every stage reads what the other role finished before the last barrier and writes
+// fields the other role does not touch until the next one (the stage scratch e.tmp belongs to role 1 until B3, then holds the rows).
+// The critical path is role 0's (65 % of the one-wavefront substep: profiles/r04_f_*). Resets run all stages on role 0 alone.
 extern __shared__ double lds_envs[];
 #ifndef MJS_BG_WAVES
 #define MJS_BG_WAVES 1  // wavefronts per SIMD the register budget is cut for (tools/ab experiments: -DMJS_BG_WAVES=2 / 4)
 #endif
 template <bool IS_RESET>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES, MJS_BG_WAVES))) void kernel(KernelParams p, double* ws_base, int epw) {
-  const int lane = threadIdx.x;
+__global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES, MJS_BG_WAVES))) void kernel(KernelParams p, double* ws_base, int epw) {
+  const int lane = threadIdx.x & 63;
+  const int role = IS_RESET ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (lane >= epw) return;
   const int i = blockIdx.x * epw + lane;
   if (i >= p.N) return;
   const Model& m = g_model;
   const Rows w{ws_base + (size_t)i * WS_DOUBLES, nullptr};  // (the kernel only hands the HBM pointer to the stages)
   uint8_t flags = p.flags[i];
+  if (!IS_RESET) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it
   Env& e = reinterpret_cast<Env*>(lds_envs)[lane];
-  e.overflow = false;
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
+    if (role != 0) return;
     if (IS_RESET && p.reset_mask && !p.reset_mask[i]) return;
+    e.overflow = false;
     reset_env(m, p, i, e, w, flags, 0);
     return;
   }
+#ifdef MJS_BG_PROFILE
+  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  if (role != 0) {  // ---------------------------------------------------------------- role 1
+    __syncthreads();                       // the env is loaded, kinematics done (B1)
+    BG_T(4, st_velocity());
+    BG_T(3, st_rows_eq());
+    __syncthreads();                       // B2
+#pragma unroll 1
+    for (int s = 0; s < MJS_RR_NSUB; s++) {
+      BG_T(3, st_rows_contacts(w.base));
+      if (BG_PRE_MW) st_mul_warm();
+      __syncthreads();                     // B3: the rows are complete
+      BG_T(6, st_integrate_split());       // (B4 inside)
+#ifdef MJS_BG_PROFILE
+      if (s == MJS_RR_NSUB - 1)
+        for (int k = 0; k < 8; k++) e.prof1[k] = prof[k];
+#endif
+      __syncthreads();                     // B5: the new state
+      __syncthreads();                     // B1
+      if (s < MJS_RR_NSUB - 1) {           // (the last mj_step1 only serves the observation and ncon: role 0's kinematics + collision)
+        BG_T(4, st_velocity());
+        BG_T(3, st_rows_eq());
+      }
+      __syncthreads();                     // B2
+    }
+    return;
+  }
+  // ------------------------------------------------------------------------------------ role 0
+  e.overflow = false;
+  e.r1_bad = 0;
   load_env(p, i, e);
   // before_step (robot_push_button.py:143-157): gripper.move -> fingers_actuator ctrl, servoJ / servoL -> joint trajectory
   double q0[NA], q1[NA];
@@ -1397,28 +1576,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES
     e.ctrl[6] = bp::grip_ctrl_of_opening(act[6]);
   }
   const double t0 = e.time, t1 = e.time + MJS_RR_CONTROL_DT, inv_span = 1.0 / (t1 - t0);
-  bool bad = false, rows_active = false;
-  double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  bool rows_active = false;
 #ifdef MJS_BG_PROFILE
-  for (int k = 0; k < 4; k++) e.dbg[k] = 0;
+  for (int k = 0; k < 6; k++) e.dbg[k] = 0;
 #endif
-  step1(m, e, w, prof);  // the previous Physics.step()'s mj_step1 (a function of the state)
+  BG_T(0, st_kinematics());  // the previous Physics.step()'s mj_step1 (a function of the state)
+  __syncthreads();           // B1
+  BG_T(1, st_crb());
+  BG_T(2, st_collision());
+  __syncthreads();           // B2
 #pragma unroll 1
   for (int s = 0; s < MJS_RR_NSUB; s++) {
     const double t = fmin(fmax(e.time, t0), t1);
     for (int j = 0; j < NA; j++) e.ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;  // robot.py:261-263
-    BG_T(5, st_forces(w.base));            // mj_step2 ...
-    BG_T(6, bad = st_integrate() || bad);
+    BG_T(5, st_smooth());                  // mj_step2: mj_fwdActuation, mj_fwdAcceleration ...
+    __syncthreads();                       // B3
     rows_active = rows_active || e.nefc > NEQ_ROWS;
-    step1(m, e, w, prof);                  // ... mj_step1 (dm_control's legacy order)
-    bp::switch_update(e.touch, flags);     // Switch.after_substep (switch.py:71-72)
+    BG_T(5, st_solve(w.base));             // ... mj_fwdConstraint, mj_sensorAcc
+    bp::switch_update(e.touch, flags);     // Switch.after_substep (switch.py:71-72): the touch force of this Physics.step()
+    __syncthreads();                       // B4: role 1 integrates
+    __syncthreads();                       // B5
+    BG_T(0, st_kinematics());              // ... mj_step1 (dm_control's legacy order)
+    __syncthreads();                       // B1
+    if (s < MJS_RR_NSUB - 1) BG_T(1, st_crb());
+    BG_T(2, st_collision());
+    __syncthreads();                       // B2
   }
+  const bool bad = e.r1_bad != 0;
   if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = bp::disturb(p.rng, i, flags);
   double obs[OBS_DIM];
   make_obs(m, e, flags, obs);
 #ifdef MJS_BG_PROFILE
-  for (int k = 0; k < 7; k++) obs[k] = prof[k];
-  for (int k = 0; k < 4; k++) obs[7 + k] = e.dbg[k];
+  for (int k = 0; k < 7; k++) obs[k] = prof[k] + e.prof1[k];
+  for (int k = 0; k < 6; k++) obs[7 + k] = e.dbg[k];
 #endif
   const double dx = obs[6] - MJS_BP_ROBOT_END_POS[0], dy = obs[7] - MJS_BP_ROBOT_END_POS[1], dz = obs[8] - MJS_BP_ROBOT_END_POS[2];
   const bool success = (flags & FLAG_SWITCH_ACTIVE) && sqrt(dx * dx + dy * dy + dz * dz) < MJS_BP_GOAL_THRESHOLD;

@@ -13,11 +13,13 @@ for n in [int(x) for x in (sys.argv[1:] or ["4096"])]:
     for k in range(3):
         v.step(a)
     torch.cuda.synchronize()
-    t0 = time.time()
-    K = 10
-    for k in range(K):
+    ts = []
+    for k in range(30):
+        t0 = time.time()
         v.step(a)
-    torch.cuda.synchronize()
-    dt = (time.time() - t0) / K
-    print(f"envs {n}: {dt * 1e3:.2f} ms per step = {n / dt / 1e6:.3f} M env-steps/s", flush=True)
+        torch.cuda.synchronize()
+        ts.append(time.time() - t0)
+    ts.sort()
+    dt = ts[len(ts) // 2]
+    print(f"envs {n}: median {dt * 1e3:.2f} ms per step (min {ts[0] * 1e3:.2f}, max {ts[-1] * 1e3:.2f}) = {n / dt / 1e6:.3f} M env-steps/s", flush=True)
     v.close()

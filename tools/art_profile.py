@@ -28,4 +28,7 @@ names = ["kinematics", "crb+factor", "collision", "rows", "velocity", "forces+so
 tot = prof.mean(axis=0).sum()
 for k, nm in enumerate(names):
     print(f"{nm:14s} {prof[:, k].mean():12.0f} clk  {100 * prof[:, k].mean() / tot:5.1f} %   max {prof[:, k].max():12.0f}")
+dbg = v._buf["obs"][:, 7:13].cpu().numpy()
+for k, nm in enumerate(["(spare)", "solver: newton_direction", "solver: line search", "solver: update pass", "forces: factor-solve of M", "forces: the whole solver"]):
+    print(f"  {nm:48s} {dbg[:, k].mean():12.0f} clk  {100 * dbg[:, k].mean() / tot:5.1f} %")
 print("total", tot, "clocks per control step (clock64 = 100 MHz wall clock on gfx9: x21 for shader cycles)")
