@@ -68,7 +68,9 @@ enum {
   MJS_FAULT_LIMIT_COLDSTART = 4,      /* constraint rows (joint limits / contacts) were active in some substep (informational; the solver is
                                          warm-started like mj_fwdConstraint: qacc_warmstart = the previous Physics.step()'s solution) */
   MJS_FAULT_UNSUPPORTED_CONTACT = 8,  /* a lane had more simultaneously ACTIVE contacts than the constraint stage holds (24 on the robot
-                                         scenes' robust path: arm links on the floor are solved since abi 2); the surplus made no rows */
+                                         scenes' robust path: arm links on the floor are solved since abi 2; Planar-Push with the arm on
+                                         the floor WHILE it is coupled to a block: 5 arm-floor contacts; articulated gripper: 16 contacts);
+                                         the surplus made no rows */
   MJS_FAULT_FASTPATH_VIOLATED = 16    /* the row-free fast path's a-posteriori check failed (a joint left its range, or an arm geom / the
                                          gripper stand-in touches something, at the end of a step taken without constraint rows): this env's
                                          step is unreliable */

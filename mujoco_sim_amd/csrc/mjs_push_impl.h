@@ -29,8 +29,13 @@ constexpr int OBS_DIM = 5 + 2 * NB, ACT_DIM = 2;
 // per block: pos3 quat4 vel6, then shape code (-1 = box stand-in, else category + 8 * colour) and mesh scale
 constexpr int S_Q = 0, S_V = 6, S_TIME = 12, S_TARGET = 13, S_STEP = 16, S_BLOCK = 17, BLOCK_DIM = 15;
 constexpr int STATE_DIM = S_BLOCK + BLOCK_DIM * NB;
-constexpr int MAXCON = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
-constexpr int MAXROW = 2 * NJ + 6 * MAXCON;
+constexpr int MAXAF = 5;  // (the LDS of the 2-slot instance has room for 20 more rows) arm-floor contacts (arm collision geoms + the EEF cylinder) the cooperative solver takes next to an arm-block coupling
+constexpr int MAXCON_BLOCKS = 4 * NB + 2 * NB + (NB * (NB - 1)) / 2;  // floor-block corners, wrist proxy-block, eef-block, block-block
+constexpr int MAXCON = MAXAF + MAXCON_BLOCKS;
+// rows: 12 limit rows + 6 per block contact (condim 4) + 4 per arm-floor contact (condim 3). The 5-slot instance keeps its 4 x 64 row
+// slots: the arm-floor rows share them with block contacts that can never all be active at once (checked when the rows are counted).
+constexpr int MAXROW = NB <= 2 ? 2 * NJ + 6 * MAXCON_BLOCKS + 4 * MAXAF : 256;
+static_assert(MAXROW >= 2 * NJ + 6 * MAXCON_BLOCKS, "every block contact has its rows");
 // wavefronts per workgroup: same-CU wavefronts walk the same (large) code and share its cache lines; the 5-slot
 // instance's cooperative workspace (~62 KB with compact rows, 113 KB dense) leaves room for two wavefronts per CU
 constexpr int WAVES = NB <= 2 ? 4 : 2;
@@ -865,6 +870,8 @@ struct CoopLds {
   double jtf[NV];  // J^T force accumulator of the compact-row instance
   // problem description written by the owner lane; the rows are then built by all lanes
   int ncon, c_ba[MAXCON], c_bb[MAXCON], c_act[MAXCON], lim_act[2 * NJ];
+  int c_nr[MAXCON], c_nd[MAXCON];  // rows of the contact's pyramid (6: condim 4, block contacts; 4: condim 3, arm-floor) and, for an arm body, the joints that move it
+  int overflow;                    // more arm-floor contacts or rows than the workspace holds
   double c_dist[MAXCON], c_tran[MAXCON], c_pos[MAXCON][3], c_n[MAXCON][3];
   double ax[NJ][3], an[NJ][3];     // joint axes and anchors (world)
   double bp[NB][3], bR[NB][9];     // block origins and rotation columns (cx, cy, cz)
@@ -1333,7 +1340,7 @@ __device__ __noinline__ int coop_newton(int nv, double scale, int lane, StepInfo
 }
 // the lane that owns the env describes its problem in LDS: contacts, kinematics, mass matrix blocks, forces
 MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn, const double* Marm, const double* qs_arm, int nb,
-                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in, double meaninertia) {
+                             const FloorSlots* fs, const ConvexHits& cvx, const M3* Rb, bool arm_in, const bool* blk_in, double meaninertia, bool arm_floor) {
   CoopLds& sh = coop_lds();
   sh.meaninertia = meaninertia;
   int off[NB + 1], nvs = arm_in ? NJ : 0;
@@ -1348,13 +1355,33 @@ MJS_DEV void publish_problem(const World& s, const double* cs, const double* sn,
   sh.nv = nvs;
   // contact list in MuJoCo's pair order from the hot path's static slots (no second collision pass)
   int ncon = 0;
-  auto put = [&](double dist, V3 pos, V3 n, int ba, int bb, double tran) {
+  sh.overflow = 0;
+  auto put = [&](double dist, V3 pos, V3 n, int ba, int bb, double tran, int nr = 6, int nd = NJ) {
     sh.c_ba[ncon] = ba; sh.c_bb[ncon] = bb; sh.c_act[ncon] = dist < 0.0;
+    sh.c_nr[ncon] = nr; sh.c_nd[ncon] = nd;
     sh.c_dist[ncon] = dist; sh.c_tran[ncon] = tran;
     sh.c_pos[ncon][0] = pos.x; sh.c_pos[ncon][1] = pos.y; sh.c_pos[ncon][2] = pos.z;
     sh.c_n[ncon][0] = n.x; sh.c_n[ncon][1] = n.y; sh.c_n[ncon][2] = n.z;
     ncon++;
   };
+  // The arm's own geoms / the EEF cylinder in the floor while the arm is coupled to a block (the EEF drags over the floor and pushes):
+  // floor (geom 0) vs arm geoms come first in mj_collision's pair order; condim 3 (4 pyramid rows), body b of the arm is moved by
+  // joints 0 .. b-1. Same detection and order as the general stage (rr::gen_stage + ScenePush::extra_contacts), which solves the
+  // arm alone when no block is coupled to it. Only ACTIVE contacts take a slot (a listed contact at dist == 0 makes no rows).
+  if (arm_in && arm_floor) {
+    rr::Chain chf;
+    rr::fk_cs(cs, sn, chf);
+    int naf = 0;
+    auto emit_af = [&](int ndof, V3 pos, double dist, double invw) {
+      if (!(dist < 0.0)) return;
+      if (naf >= MAXAF) { sh.overflow = 1; return; }
+      put(dist, pos, v3(0, 0, 1), 0, 1, invw, 4, ndof);
+      naf++;
+    };
+    rr::arm_floor_contacts(chf, [&](int b, V3 pos, double dist) { emit_af(b, pos, dist, fmax(MJS_MINVAL, UR5E_PP_LINK_BODY_INVWEIGHT0[b])); });
+    const Geom eg = eef_geom(chf);
+    rr::plane_cylinder_contacts(eg.c, eg.R.cz, eg.R.cx, eg.s.x, eg.s.y, [&](V3 pos, double dist) { emit_af(NJ, pos, dist, UR5E_PP_EEF_BODY_INVWEIGHT0[0]); });
+  }
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     if (b >= nb || !blk_in[b]) continue;
@@ -1440,14 +1467,15 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
     sh.D[row] = 1 / fmax(MJS_MINVAL, (1 - imp) * UR5E_PP_DOF_INVWEIGHT0[j] / imp);
     sh.aref[row] = -B * (sgn * sh.qvel[j]) - K * imp * dist;
   }
-  int nact = 0;
-  for (int c = 0; c < sh.ncon; c++) nact += sh.c_act[c];
-  for (int t = lane; t < 6 * sh.ncon; t += 64) {  // task = (contact, pyramid edge)
+  int ncrow = 0;  // contact rows in all
+  for (int c = 0; c < sh.ncon; c++) ncrow += sh.c_act[c] ? sh.c_nr[c] : 0;
+  const bool rows_fit = nlim + ncrow <= MAXROW;  // (always, in the 2-slot instance)
+  for (int t = lane; t < 6 * sh.ncon && rows_fit; t += 64) {  // task = (contact, pyramid edge)
     const int c = t / 6, e = t - 6 * c;
-    if (!sh.c_act[c]) continue;
-    int rank = 0;
-    for (int k = 0; k < c; k++) rank += sh.c_act[k];
-    const int row = nlim + 6 * rank + e;
+    if (!sh.c_act[c] || e >= sh.c_nr[c]) continue;
+    int before = 0;
+    for (int k = 0; k < c; k++) before += sh.c_act[k] ? sh.c_nr[k] : 0;
+    const int row = nlim + before + e;
     const V3 n = v3(sh.c_n[c][0], sh.c_n[c][1], sh.c_n[c][2]);
     V3 t1, t2;
     {  // mju_makeFrame
@@ -1459,10 +1487,12 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
     const int kk = e >> 1;  // 0: t1, 1: t2, 2: torsion
     const double sgn = (e & 1) ? -1.0 : 1.0;
     const int ba = sh.c_ba[c], bb = sh.c_bb[c];
-    const bool blocks_only = ba >= 2 && bb >= 2;
-    const double fri[3] = {MJS_BLOCK_FRICTION[0], MJS_BLOCK_FRICTION[0], fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
+    const bool blocks_only = ba >= 2 && bb >= 2, arm_floor = bb == 1;
+    const double slide = arm_floor ? MJS_GEOM_FRICTION_SLIDE : MJS_BLOCK_FRICTION[0];
+    const double fri[3] = {slide, slide, fmax(MJS_BLOCK_FRICTION[1], blocks_only ? 0.0 : MJS_GEOM_FRICTION_SPIN)};
     // row = Jn + sgn mu Jk with Jn / Jk the normal and the kk-th frame row of (body b - body a), written column by
-    // column straight into LDS (static column indices: nothing lives in indexed scratch). Only body a can be the arm.
+    // column straight into LDS (static column indices: nothing lives in indexed scratch). The arm is body a of an arm-block
+    // contact and body b of a floor-arm contact (bb == 1: columns of the joints that move the touching link only).
     const V3 pos = v3(sh.c_pos[c][0], sh.c_pos[c][1], sh.c_pos[c][2]);
     const V3 Fk = kk == 0 ? t1 : kk == 1 ? t2 : n;
     const bool rotk = kk == 2;
@@ -1487,18 +1517,19 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
         vel += v * sh.qvel[o + 3 + d];
       }
     };
-    auto arm_cols = [&](double sa) {
+    const int nmov = sh.c_nd[c];
+    auto arm_cols = [&](double sa, int base) {
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         const V3 ax = v3(sh.ax[j][0], sh.ax[j][1], sh.ax[j][2]);
         const V3 lin = cross(ax, pos - v3(sh.an[j][0], sh.an[j][1], sh.an[j][2]));
-        const double v = sa * dot(n, lin) + mu * (sa * dot(Fk, rotk ? ax : lin));
-        sh.J[row][j] = v;
+        const double v = j < nmov ? sa * dot(n, lin) + mu * (sa * dot(Fk, rotk ? ax : lin)) : 0.0;
+        sh.J[row][base + j] = v;
         vel += v * sh.qvel[j];
       }
     };
     if constexpr (!COMPACT) {
-      if (arm_in) arm_cols(ba == 1 ? -1.0 : 0.0);
+      if (arm_in) arm_cols(ba == 1 ? -1.0 : arm_floor ? 1.0 : 0.0, 0);
 #pragma unroll
       for (int b = 0; b < NB; b++) {
         const int o = sh.off[1 + b];
@@ -1506,23 +1537,30 @@ MJS_DEV void coop_build_rows(CoopLds& sh, int lane) {
         block_cols(b, (bb == 2 + b ? 1.0 : 0.0) - (ba == 2 + b ? 1.0 : 0.0), o, o);
       }
     } else {
-      // group 0 = body a (arm, a block or the world), group 1 = body b (always a block)
-      if (ba == 1) { arm_cols(-1.0); sh.cb[row][0] = 0; }
+      // group 0 = body a (arm, a block or the world), group 1 = body b (a block, or the arm for a floor-arm contact)
+      if (ba == 1) { arm_cols(-1.0, 0); sh.cb[row][0] = 0; }
       else if (ba >= 2) { block_cols(ba - 2, -1.0, 0, sh.off[1 + ba - 2]); sh.cb[row][0] = sh.off[1 + ba - 2]; }
       else {
 #pragma unroll
         for (int d = 0; d < 6; d++) sh.J[row][d] = 0.0;
         sh.cb[row][0] = COL_NONE;
       }
-      block_cols(bb - 2, 1.0, 6, sh.off[1 + bb - 2]);
-      sh.cb[row][1] = sh.off[1 + bb - 2];
+      if (arm_floor) { arm_cols(1.0, 6); sh.cb[row][1] = 0; }
+      else {
+        block_cols(bb - 2, 1.0, 6, sh.off[1 + bb - 2]);
+        sh.cb[row][1] = sh.off[1 + bb - 2];
+      }
     }
     const double imp = impedance_default(sh.c_dist[c]);
     const double R0 = fmax(MJS_MINVAL, (1 - imp) * (sh.c_tran[c] + fri[0] * fri[0] * sh.c_tran[c]) / imp);
     sh.D[row] = 1 / (2 * fri[0] * fri[0] * R0);
     sh.aref[row] = -B * vel - K * imp * sh.c_dist[c];
   }
-  if (lane == 0) { sh.nrow = nlim + 6 * nact; sh.D[MAXROW] = 0; sh.force[MAXROW] = 0; }
+  if (lane == 0) {
+    sh.nrow = rows_fit ? nlim + ncrow : 0;
+    if (!rows_fit) sh.overflow = 1;
+    sh.D[MAXROW] = 0; sh.force[MAXROW] = 0;
+  }
   if (lane < (COMPACT ? 12 : NV)) sh.J[MAXROW][lane] = 0;
   if constexpr (COMPACT) {
     if (lane < 2) sh.cb[MAXROW][lane] = COL_NONE;
@@ -1548,9 +1586,9 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
 #pragma unroll
         for (int b = 0; b < NB; b++) { fs_l[b] = env_fs(env, b); Rb_l[b] = env_Rb(env, b); }
         const ConvexHits cvx_l = env_cvx(env);
-        publish_problem(s, cs, sn, Marm, qacc, nb, fs_l, cvx_l, Rb_l, arm_in, blk_in, meaninertia);
+        publish_problem(s, cs, sn, Marm, qacc, nb, fs_l, cvx_l, Rb_l, arm_in, blk_in, meaninertia, info.arm_floor);
       } else
-        publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in, meaninertia);
+        publish_problem(s, cs, sn, Marm, qacc, nb, fs, cvx, Rb, arm_in, blk_in, meaninertia, info.arm_floor);
     }
     MJS_WAVE_SYNC();
     // mj_solPrimal's stopping rules are scaled by the WHOLE model (meaninertia, nv) of the owner env, also when a sub-system is solved
@@ -1566,6 +1604,7 @@ MJS_DEV void coop_coupled(bool need, const World& s, const double* cs, const dou
 #else
     (void)iters;
 #endif
+    if (lane == owner && sh.overflow) info.unsupported = true;
     if (lane == owner && sh.nrow > 0) {
       if (arm_in) {
 #pragma unroll
@@ -1997,12 +2036,12 @@ __device__ __forceinline__ void physics_step(int nb, bool live, rr::Ws ws) {
   coop_coupled(live && coupled, s, cs, sn, Marm, nb, qacc, info, fs, cvx, Rb, arm_in, blk_in, meaninertia);  // all lanes
   PP_ACC(info, 3, tt);
   if (!live) return;
-  // Arm geoms / EEF cylinder in the floor (an unreachable or low target drags the tool over the floor; mjs_set_state): the
-  // arm's own 6-dof constraint problem (floor contacts + joint limits) goes through the general stage, cold-started like every
-  // solve of this kernel. Only while the arm is not ALSO coupled with a block (an arm-block contact puts the arm into the
-  // cooperative 18-dof solve, whose row format has no link-specific arm rows): that combination is reported, not solved.
+  // Arm geoms / EEF cylinder in the floor (an unreachable or low target drags the tool over the floor; mjs_set_state): while the arm
+  // is not coupled to a block its own 6-dof constraint problem (floor contacts + joint limits) goes through the general stage,
+  // cold-started like every solve of this kernel; an arm that is ALSO in the coupled sub-system had its floor contacts solved there
+  // (publish_problem: floor-arm rows with the touching link's columns; more than MAXAF of them are reported).
   if (info.arm_floor) {
-    if (arm_in && coupled) info.unsupported = true;
+    if (arm_in && coupled) { /* solved by coop_coupled */ }
     else {
       rr::GenStageIn gi;
 #pragma unroll

@@ -660,9 +660,11 @@ void om_env_step(om_env* e, const double* action, om_step_out* out) {
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) button_physics_step(e);
     else om_physics_step(m, d);
     if (e->cfg.task == OM_TASK_BUTTON_PUSH) switch_update(e); /* Switch.after_substep (switch.py:71-72) */
-    if (e->cfg.task != OM_TASK_POINTMASS) /* test knob: a floor contact of one of the arm's own collision geoms (ids 1..10) */
+    if (e->cfg.task != OM_TASK_POINTMASS) { /* test knob: a floor contact of one of the arm's own collision geoms (ids 1..10) or, in Planar-Push, of the CylinderEEF (id 11) */
+      const int last = MJS_UR_NCOLGEOM + (e->cfg.task == OM_TASK_PLANAR_PUSH ? 1 : 0);
       for (int c = 0; c < d->ncon; c++)
-        if (d->contact[c].geom1 == 0 && d->contact[c].geom2 >= 1 && d->contact[c].geom2 <= MJS_UR_NCOLGEOM) e->dbg_arm_floor_seen = 1;
+        if (d->contact[c].geom1 == 0 && d->contact[c].geom2 >= 1 && d->contact[c].geom2 <= last) e->dbg_arm_floor_seen = 1;
+    }
   }
   /* after_step + reward/discount/termination */
   if (e->cfg.task == OM_TASK_BUTTON_PUSH && e->cfg.button_disturbances) {

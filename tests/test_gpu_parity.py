@@ -1150,8 +1150,8 @@ def test_planar_push_arm_on_the_floor_matches_oracle(oracle_mod):
     """Planar-Push with the arm's own collision geoms and the CylinderEEF pushed into the floor through mjs_set_state
     (shoulder-lift offsets from grazing to 1.1 rad; blocks parked away from the arm): plane-capsule and plane-cylinder
     contacts of the arm (mjc_PlaneCapsule, mjc_PlaneCylinder: up to four per cylinder) are solved by the general constraint
-    stage next to the blocks' own floor contacts; joint positions, block poses, reward and ncon equal the oracle's. The
-    combination the kernel reports instead of solving (arm on the floor AND coupled to a block, fault bit 8) does not occur here."""
+    stage next to the blocks' own floor contacts; joint positions, block poses, reward and ncon equal the oracle's. (The arm on the
+    floor AND coupled to a block: test_planar_push_arm_on_the_floor_while_pushing_a_block.)"""
     import mujoco_sim_amd as m
 
     N = 24
@@ -1185,6 +1185,54 @@ def test_planar_push_arm_on_the_floor_matches_oracle(oracle_mod):
         n_arm += int(ob.arm_floor_seen().sum())
         n_rows += int(((fault & 4) > 0).sum())
     assert n_arm >= 10 and n_rows >= 10, (n_arm, n_rows)
+
+
+def test_planar_push_arm_on_the_floor_while_pushing_a_block(oracle_mod):
+    """VERDICT r3 "What's missing" 2: the arm's geoms / the CylinderEEF in the floor AND the arm coupled to a block in the same
+    substep (the tool dragged over the floor while it pushes; robot_planar_push.py:185-201 lets the policy drive z = 0.02 anywhere).
+    The cooperative 18-dof solve now carries floor-arm rows with the touching link's Jacobian columns (condim 3, mj_collision's pair
+    order: floor-arm before floor-block); joints, block poses, reward and ncon equal the oracle's, no env reports fault bit 8."""
+    import mujoco_sim_amd as m
+
+    N = 12
+    venv = m.HipVectorEnv("robot_planar_push", N, seed=7, block_shape="box")
+    ob = oracle_mod.OracleBatch(oracle_mod.TASK_PLANAR_PUSH, N, 7, nthreads=8, block_shape=1)
+    venv.reset()
+    o = ob.reset()
+    act = o["obs"][:, :2].copy()
+    G_EEF = 11  # geoms: floor, the arm's ten collision proxies, the CylinderEEF, the blocks
+    both = 0
+    for rnd in range(3):
+        # the tool is put into the floor (shoulder lift; the servo pulls it out again within a control step or two) with block 0
+        # overlapping the EEF cylinder by ~3 mm (cylinder radius 0.02 + block half 0.0198) on the side it is then pushed to
+        qp, qv, tm = ob.get_state()
+        qv[:] = 0
+        qp[:, 6:13] = [0.55, 0.55, 0.0, 1, 0, 0, 0]
+        qp[:, 13:20] = [-0.55, 0.55, 0.0, 1, 0, 0, 0]
+        qp[:, 1] += np.linspace(0.015, 0.07, N) * (1 + 0.2 * rnd)
+        ob.set_state(qp, qv)
+        cyl = np.array([ob.geom_pose(i, G_EEF)[0] for i in range(N)])
+        assert (cyl[:, 2] < 0.068).all() and (cyl[:, 2] > 0.0).all(), cyl[:, 2]   # it is the tool's cylinder (half length 0.05), its lower rim in the floor
+        qp[:, 6] = cyl[:, 0] + 0.037
+        qp[:, 7] = cyl[:, 1]
+        ob.set_state(qp, qv)
+        _push_state_to_gpu(venv, qp, qv, tm)
+        for t in range(2):
+            x0 = ob.get_state()[0][:, 6].copy()
+            act[:, 0] += 0.01
+            venv.step(torch.from_numpy(act))
+            r = ob.step(act)
+            g = venv.get_state().cpu().numpy()
+            q2, v2, _ = ob.get_state()
+            fault = venv._buf["fault"].cpu().numpy()
+            assert not (fault & (1 | 8)).any(), (rnd, t, fault)
+            np.testing.assert_allclose(g[0:6].T, q2[:, :6], rtol=0, atol=1e-8, err_msg=f"joints, round {rnd} step {t}")
+            for b in range(2):
+                np.testing.assert_allclose(g[17 + 15 * b: 24 + 15 * b].T, q2[:, 6 + 7 * b: 13 + 7 * b], rtol=0, atol=1e-8, err_msg=f"block {b} pose, round {rnd} step {t}")
+            assert np.array_equal(venv._buf["ncon"].cpu().numpy(), r["ncon"]), (rnd, t, venv._buf["ncon"].cpu().numpy(), r["ncon"])
+            np.testing.assert_allclose(venv._buf["reward"].cpu().numpy(), r["reward"], rtol=0, atol=1e-8)
+            both += int((ob.arm_floor_seen() & (np.abs(q2[:, 6] - x0) > 1e-5)).sum())
+    assert both >= 2 * N, both  # env-steps with the arm on the floor while it moved the block
 
 
 @pytest.mark.parametrize("block_shape", ["mesh", "box"])
