@@ -228,6 +228,7 @@ void om_debug_set_robot_state(om_env* e, const double* q, const double* v);
 void om_debug_link_invweights(int task, double* out7);
 int om_debug_get_state(const om_env* e, double* qpos, double* qvel, double* time);
 int om_debug_arm_floor_seen(om_env* e);
+void om_debug_geom_shape(const om_env* e, int g, int* type_body /*2*/, double* size3);
 void om_debug_set_block_shape(om_env* e, int i, int cat, int color, double scale);
 void om_debug_get_block_shape(const om_env* e, int* cat, int* color, double* scale);
 void om_debug_set_state(om_env* e, const double* qpos, const double* qvel);

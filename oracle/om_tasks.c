@@ -846,6 +846,10 @@ void om_debug_geom_pose(const om_env* e, int g, double* pos3, double* mat9) {
   memcpy(pos3, e->d.geom_xpos[g], sizeof(double) * 3);
   memcpy(mat9, e->d.geom_xmat[g], sizeof(double) * 9);
 }
+void om_debug_geom_shape(const om_env* e, int g, int* type_body /*2*/, double* size3) {
+  type_body[0] = e->m.geom_type[g]; type_body[1] = e->m.geom_body[g];
+  memcpy(size3, e->m.geom_size[g], sizeof(double) * 3);
+}
 void om_debug_set_ctrl(om_env* e, int u, double value) { e->d.ctrl[u] = value; }
 void om_debug_get_dynamics(const om_env* e, double* M /*[nv][nv]*/, double* qfrc_smooth, double* qacc) {
   for (int i = 0; i < e->m.nv; i++) {

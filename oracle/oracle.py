@@ -326,6 +326,14 @@ class OracleBatch:
         L.om_debug_geom_pose(L.om_batch_env(self._h, i), g, pos.ctypes.data, mat.ctypes.data)
         return pos, mat.reshape(3, 3)
 
+    def geom_shape(self, g: int):
+        """debug: (type, body, size[3]) of geom g of the model (OM_GEOM_* codes: 0 plane, 2 sphere, 3 capsule, 5 cylinder, 6 box, 7 mesh)"""
+        L = lib()
+        L.om_debug_geom_shape.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        tb, size = np.zeros(2, np.int32), np.zeros(3)
+        L.om_debug_geom_shape(L.om_batch_env(self._h, 0), g, tb.ctypes.data, size.ctypes.data)
+        return int(tb[0]), int(tb[1]), size
+
     def set_ctrl(self, u: int, values):
         L = lib()
         L.om_debug_set_ctrl.argtypes = [C.c_void_p, C.c_int, C.c_double]
