@@ -2,6 +2,7 @@
 // tests/test_generated_dynamics.py: the same straight-line code the kernels run, compiled by g++.
 #include <cmath>
 #define MJS_DEV static inline
+#define MJS_SCHED_PIN ((void)0)
 #include "../../mujoco_sim_amd/csrc/mjs_ur5e_dyn_gen.h"
 
 extern "C" {

@@ -386,8 +386,9 @@ def build(links, uncomp):
     return tau, M
 
 
-def emit(outputs):
-    """straight-line code for the given (name, value) outputs; returns (lines, op counts)"""
+def emit(outputs, schedule=None):
+    """straight-line code for the given (name, value) outputs; returns (lines, op counts). schedule = (latency, barrier_every) emits a
+    pinned list schedule (below); None = creation order, which the compiler reschedules freely."""
     needed, stack = set(), [v.id for _, v in outputs if not v.is_const]
     while stack:
         k = stack.pop()
@@ -401,7 +402,46 @@ def emit(outputs):
             stack.append(a)
     lines, names = [], {}
     counts = {"add": 0, "sub": 0, "mul": 0, "mulc": 0, "addc": 0}
-    for k in sorted(needed):
+    order = sorted(needed)
+    # VERDICT r3 item 4 (profiles/r04_g_*): a LIST SCHEDULE of the DAG - critical path first, a dependent op at least `lat` slots after
+    # its operand - PINNED with a scheduling barrier after every statement, instead of the creation order that the compiler is free
+    # to reschedule. Same-session A/B at 4096 envs: Robot-Reach 35.38 -> 34.91 us (lat 4; lat 1 / 3 / 6 / 9: 35.08 / 35.06 / 34.94 /
+    # 35.87; unpinned list order: no change), but Button-Push 71.2 -> 72.2 us and Planar-Push 1750 -> 1821 us: only the Robot-Reach
+    # variant is emitted this way. GEN_ORDER=list GEN_LATENCY=k GEN_BARRIER=k override it for every variant (experiments).
+    import os
+    if os.environ.get("GEN_ORDER") == "list":
+        schedule = (int(os.environ.get("GEN_LATENCY", "2")), int(os.environ.get("GEN_BARRIER", "0")))
+    barrier = 0
+    if schedule is not None:
+        lat, barrier = schedule
+        preds = {}
+        for k in needed:
+            op, a, b = G.nodes[k]
+            preds[k] = [x for x in ((a, b) if op in ("add", "sub", "mul") else (a,) if op in ("mulc", "addc") else ()) if isinstance(x, int) and x in needed]
+        succs = {k: [] for k in needed}
+        for k, ps in preds.items():
+            for q in ps:
+                succs[q].append(k)
+        height = {}
+        for k in sorted(needed, reverse=True):  # creation order is topological
+            height[k] = 1 + max((height[x] for x in succs[k]), default=0)
+        done_at, order, slot = {}, [], 0
+        remaining = {k: len(set(preds[k])) for k in needed}
+        ready = [k for k in needed if remaining[k] == 0]
+        while ready:
+            ok = [k for k in ready if all(done_at[q] + lat <= slot for q in preds[k] if G.nodes[q][0] != "sym")]
+            pick = max(ok or ready, key=lambda k: (height[k], -k))
+            ready.remove(pick)
+            order.append(pick)
+            done_at[pick] = slot
+            if G.nodes[pick][0] != "sym":
+                slot += 1
+            for x in set(succs[pick]):
+                remaining[x] -= 1
+                if remaining[x] == 0:
+                    ready.append(x)
+    emitted = 0
+    for k in order:
         op, a, b = G.nodes[k]
         if op == "sym":
             names[k] = a
@@ -419,6 +459,9 @@ def emit(outputs):
         else:
             e = f"{names[a]} + {b!r}"
         lines.append(f"  const double t{k} = {e};")
+        emitted += 1
+        if barrier and emitted % barrier == 0:
+            lines.append("  MJS_SCHED_PIN;")
     for name, v in outputs:
         if v.is_const:
             lines.append(f"  {name} = {v.c!r};")
@@ -521,12 +564,12 @@ def link_body_invweights(M, links):
     return out
 
 
-def emit_variant(prefix, links, uncomp, body_com_local, what):
+def emit_variant(prefix, links, uncomp, body_com_local, what, schedule=None):
     tau, M = build(links, uncomp)
     out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
     out_M = [(f"M[{i * (i + 1) // 2 + j}]", M[i][j]) for i in range(NJ) for j in range(i + 1)]
-    lb, cb = emit(out_bias)
-    lm, cm = emit(out_M)
+    lb, cb = emit(out_bias, schedule)
+    lm, cm = emit(out_M, schedule)
     nb, nm = sum(cb.values()), sum(cm.values())
     invw, meaninertia, tran, rot = model_constants(M, links, body_com_local)
     _, _, w3tran, w3rot = model_constants(M, links, body_ipos[NJ])  # the wrist_3 body itself, at its own COM
@@ -569,10 +612,13 @@ def main():
 #ifndef MJS_DEV
 #define MJS_DEV __device__ __forceinline__
 #endif
+#ifndef MJS_SCHED_PIN  // holds a hand-ordered (list-scheduled) emission against the compiler's scheduler; a host build defines it away
+#define MJS_SCHED_PIN __builtin_amdgcn_sched_barrier(0)
+#endif
 """
     text = header
     links, uncomp = make_links([GRIPPER])
-    text += emit_variant("ur5e", links, uncomp, GRIPPER[1], "Robot-Reach: UR5e + lumped 2F-85 gripper (robot_reach.py:90-95)")
+    text += emit_variant("ur5e", links, uncomp, GRIPPER[1], "Robot-Reach: UR5e + lumped 2F-85 gripper (robot_reach.py:90-95)", schedule=(4, 1))
     cam = wrist_camera_part()
     links2, uncomp2 = make_links([GRIPPER, cam])
     text += emit_variant("ur5e_bp", links2, uncomp2, GRIPPER[1], "Button-Push: + wrist-camera geoms' mass at the flange (robot_push_button.py:90-96)")
