@@ -129,7 +129,7 @@ struct Contact {
   int zone;            // elliptic cone: 0 top, 1 middle, 2 bottom
   double mu;
 };
-constexpr int TMP_DOUBLES = 383;  // >= 3 x 14 spatial vectors (252); the rest buys rows in LDS (19 of them); odd size: the bank rule below
+constexpr int TMP_DOUBLES = 382;  // >= 3 x 14 spatial vectors (252); the rest buys rows in LDS (19 of them); its size: the bank rule below
 struct Env {
   double q[NV], v[NV], ctrl[7], time, warm[NV];
   double sw[3];
@@ -148,6 +148,7 @@ struct Env {
   double qfrc_smooth[NV], qacc_smooth[NV], qacc[NV], qfrc_constraint[NV], act_force[7], touch;
   int clamped;  // bit u: actuator u sits on its force range
   double sx[NV], sy[NV];  // vector arguments / results of the out-of-line register blocks (pointer arguments would be FLAT + scratch)
+  double cost_s;          // cost of the smooth candidate (role 2 -> role 0)
   int r1_bad;   // the integrating wavefront (role 1) saw a non-finite state during this control step
   // scratch of the stage that is running (the velocity stage's spatial velocities, accelerations and forces, then the first rows of the
   // constraint problem): kept with the env so that it lives in LDS like the rest
@@ -425,8 +426,10 @@ MJS_HD void jac_point(const Env& e, int b, const double* p, double jt[3][NV]) {
 
 // mj_comVel + mj_rne (flg_acc = 0) + mj_passive (damping, springs, gravity compensation of the arm's own bodies)
 MJS_DEV void velocity_stage(const Model& m, Env& e) {
-  double (*cvel)[6] = reinterpret_cast<double (*)[6]>(e.tmp), (*cacc)[6] = cvel + NV, (*cfrc)[6] = cvel + 2 * NV;
-  static_assert(3 * NV * 6 <= TMP_DOUBLES, "spatial vectors fit the stage scratch");
+  // spatial velocities, accelerations and forces of the 14 bodies: LOCAL arrays - with the body loops unrolled every index is static and
+  // they live in registers (a body's velocity / acceleration only until its children are done, the forces until the backward pass),
+  // so the stage needs no scratch in LDS and can run while another wavefront writes the rows into e.tmp
+  double cvel[NV][6], cacc[NV][6], cfrc[NV][6];
 BG_TREE_LOOP
   for (int b = 0; b < NV; b++) {
     const int p = PBf(b);
@@ -537,17 +540,21 @@ MJS_DEV void convex_pair(Env& e, const pp::Geom& g1, const pp::Geom& g2, int b1,
 MJS_DEV void collision(const Model& m, Env& e) {
   e.ncon = 0;
   const double up[3] = {0, 0, 1};
-  // floor vs the arm's capsules / cylinder (mjc_PlaneCapsule, mjc_PlaneCylinder)
-#pragma unroll 1
+  // floor vs the arm's capsules / cylinder (mjc_PlaneCapsule, mjc_PlaneCylinder). Unrolled over the geoms with the spec's constants
+  // (body, type, offset, size; the geom axis is the body's -y or z column: MJS_UR_COL_QUAT is the identity or Rx(90 deg)), so that
+  // the ten tests are straight-line code on static LDS offsets instead of a rolled loop of dependent scalar + LDS loads.
+#pragma unroll
   for (int g = 0; g < MJS_UR_NCOLGEOM; g++) {
-    const int b = m.col_body[g];
-    double gp[3], axis[3], tmp[3];
-    mat_vec(e.xmat[b], m.col_pos[g], tmp);
-    for (int k = 0; k < 3; k++) gp[k] = e.xpos[b][k] + tmp[k];
-    mat_vec(e.xmat[b], m.col_axis[g], axis);
-    const double rad = m.col_size[g][0], half = m.col_size[g][1];
+    const int b = MJS_UR_COL_BODY[g] - 1;
+    const double* R = e.xmat[b];
+    double gp[3], axis[3];
+    for (int k = 0; k < 3; k++)
+      gp[k] = e.xpos[b][k] + (R[3 * k] * MJS_UR_COL_POS[g][0] + R[3 * k + 1] * MJS_UR_COL_POS[g][1] + R[3 * k + 2] * MJS_UR_COL_POS[g][2]);
+    const bool rx90 = MJS_UR_COL_QUAT[g][1] != 0.0;
+    for (int k = 0; k < 3; k++) axis[k] = rx90 ? -R[3 * k + 1] : R[3 * k + 2];
+    const double rad = MJS_UR_COL_SIZE[g][0], half = MJS_UR_COL_SIZE[g][1];
     const double tran = m.invw_body[b];
-    if (m.col_type[g] == 3) {
+    if (MJS_UR_COL_TYPE[g] == 3) {
       for (int s = -1; s <= 1; s += 2) {
         double c[3], pos[3];
         for (int k = 0; k < 3; k++) c[k] = gp[k] + s * half * axis[k];
@@ -566,9 +573,7 @@ MJS_DEV void collision(const Model& m, Env& e) {
       for (int k = 0; k < 3; k++) vec[k] = ax[k] * prjaxis - up[k];
       const double len = sqrt(dot3(vec, vec));
       if (len < MJS_MINVAL) {  // disk parallel to the plane: the geom's x axis scaled by the radius
-        double col0[3];
-        mat_vec(e.xmat[b], m.col_xaxis[g], col0);
-        for (int k = 0; k < 3; k++) vec[k] = col0[k] * rad;
+        for (int k = 0; k < 3; k++) vec[k] = R[3 * k] * rad;  // (geom x = body x under Rx(90 deg))
       } else {
         for (int k = 0; k < 3; k++) vec[k] *= rad / len;
       }
@@ -863,10 +868,13 @@ MJS_DEV void actuation(const Model& m, Env& e, double* qfrc_act) {
 // constraint cost, and grad = Ma - qfrc_smooth - J^T f; returns the cost incl. the Gauss term. The oracle walks the rows once per
 // quantity; fused here because every pass over the HBM row workspace is a chain of dependent loads on a wavefront that has its
 // SIMD to itself.
-template <class RW>
+// COST_ONLY: nothing is written (no jar / force / zone, no gradient): the pass another wavefront runs on the smooth candidate while the
+// solving wavefront evaluates the warm one; same arithmetic for the cost, bit for bit.
+template <class RW, bool COST_ONLY = false>
 MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* Ma, bool fresh, double alpha, double* grad) {
   double cost = 0;
-  for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
+  if (!COST_ONLY)
+    for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
 #pragma unroll 1
   for (int r = 0; r < e.nefc; r++) {
     const int t = e.rtype[r];
@@ -881,20 +889,20 @@ MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* 
         z[a] = sj;
       } else
         z[a] = w.at(r + a, ROW_JAR) + alpha * w.at(r + a, ROW_JV);
-      w.at(r + a, ROW_JAR) = z[a];
+      if (!COST_ONLY) w.at(r + a, ROW_JAR) = z[a];
     }
     if (t == 2) {
       Contact& con = e.con[e.rcon[r]];
       const double D0 = w.at(r, ROW_D), D1 = w.at(r + 1, ROW_D);
       const double mu = con.mu, fr = con.friction;
       const double N = z[0] * mu, U1 = z[1] * fr, U2 = z[2] * fr, T = sqrt(U1 * U1 + U2 * U2);
-      if (N >= mu * T) con.zone = 0;
+      if (N >= mu * T) { if (!COST_ONLY) con.zone = 0; }
       else if (mu * N + T <= 0) {
-        con.zone = 2;
+        if (!COST_ONLY) con.zone = 2;
         f[0] = -D0 * z[0]; f[1] = -D1 * z[1]; f[2] = -D1 * z[2];
         cost += 0.5 * (D0 * z[0] * z[0] + D1 * z[1] * z[1] + D1 * z[2] * z[2]);
       } else {
-        con.zone = 1;
+        if (!COST_ONLY) con.zone = 1;
         const double Dm = D0 / (mu * mu * (1 + mu * mu)), NT = N - mu * T;
         cost += 0.5 * Dm * NT * NT;
         f[0] = -Dm * NT * mu;
@@ -906,12 +914,13 @@ MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* 
       f[0] = act ? -D * z[0] : 0.0;
       if (act) cost += 0.5 * D * z[0] * z[0];
     }
-    for (int a = 0; a < 3; a++) {
-      if (a >= nr) continue;
-      w.at(r + a, ROW_FORCE) = f[a];
-      if (f[a] != 0)
-        for (int k = 0; k < NV; k++) grad[k] -= Jr[a][k] * f[a];
-    }
+    if (!COST_ONLY)
+      for (int a = 0; a < 3; a++) {
+        if (a >= nr) continue;
+        w.at(r + a, ROW_FORCE) = f[a];
+        if (f[a] != 0)
+          for (int k = 0; k < NV; k++) grad[k] -= Jr[a][k] * f[a];
+      }
     r += nr - 1;
   }
   double gauss = 0;
@@ -1082,40 +1091,40 @@ BG_NEWTON_INLINE bool newton_direction(double* ws_env) {  // gradient in e.sx, s
   return ok;
 }
 // mj_fwdConstraint: primal Newton (mj_solPrimal) warm-started from the cheaper of qacc_warmstart and qacc_smooth
-// PRE: M qacc_warmstart was computed by the other wavefront meanwhile (it waits in e.qacc, which the solver only writes at its end)
+// mj_fwdConstraint's solver in two phases, so that the cost of the smooth candidate can come from another wavefront:
+//   solve_warm:   the warm candidate's pass (qacc_warmstart; the rows hold its jar / forces afterwards)
+//   cost_smooth:  the cost of qacc_smooth (M qacc_smooth = qfrc_smooth by definition: no Gauss term, nothing written)
+//   solve_newton: qacc_warmstart unless qacc_smooth is STRICTLY cheaper (then its pass is redone with the writes), the Newton iterations
+// PRE: M qacc_warmstart was computed by another wavefront meanwhile (it waits in e.qacc, which the solver only writes at its end).
+struct SolveState { double qacc[NV], Ma[NV], grad[NV], cost; };
 template <bool PRE, class RW>
-MJS_DEV void solve(const Model& m, Env& e, const RW& w, double* ws_env) {
-  if (e.nefc == 0) {
-    for (int i = 0; i < NV; i++) { e.qacc[i] = e.qacc_smooth[i]; e.qfrc_constraint[i] = 0; }
-    return;
+MJS_DEV void solve_warm(Env& e, const RW& w, SolveState& st) {
+  if (PRE) { for (int i = 0; i < NV; i++) st.Ma[i] = e.qacc[i]; }
+  else {
+    sym_mul_env<BG_OFF(warm), BG_OFF(sy)>();
+    for (int i = 0; i < NV; i++) st.Ma[i] = e.sy[i];
   }
-  double qacc[NV], Ma[NV], grad[NV], search[NV], Mv[NV];
-  // warm start: qacc_warmstart unless qacc_smooth is strictly cheaper (mj_fwdConstraint). The smooth candidate goes first so that
-  // the rows hold the warm candidate's jar / forces when it wins (the common case); M qacc_smooth = qfrc_smooth by definition.
-  double cost;
-  {
-    double ma_s[NV], ma_w[NV], grad_s[NV];
-    for (int i = 0; i < NV; i++) ma_s[i] = e.qfrc_smooth[i];
-    const double c_s = rows_pass(e, w, e.qacc_smooth, ma_s, true, 0.0, grad_s);
-    if (PRE) { for (int i = 0; i < NV; i++) ma_w[i] = e.qacc[i]; }
-    else {
-      sym_mul_env<BG_OFF(warm), BG_OFF(sy)>();
-      for (int i = 0; i < NV; i++) ma_w[i] = e.sy[i];
-    }
-    const double c_w = rows_pass(e, w, e.warm, ma_w, true, 0.0, grad);
-    if (c_s < c_w) {
-      for (int i = 0; i < NV; i++) { qacc[i] = e.qacc_smooth[i]; Ma[i] = ma_s[i]; }
-      cost = rows_pass(e, w, qacc, Ma, true, 0.0, grad);
-    } else {
-      for (int i = 0; i < NV; i++) { qacc[i] = e.warm[i]; Ma[i] = ma_w[i]; }
-      cost = c_w;
-    }
+  for (int i = 0; i < NV; i++) st.qacc[i] = e.warm[i];
+  st.cost = rows_pass(e, w, st.qacc, st.Ma, true, 0.0, st.grad);
+}
+template <class RW>
+MJS_DEV double cost_smooth(Env& e, const RW& w) {
+  double ma_s[NV];
+  for (int i = 0; i < NV; i++) ma_s[i] = e.qfrc_smooth[i];
+  return rows_pass<RW, true>(e, w, e.qacc_smooth, ma_s, true, 0.0, nullptr);
+}
+template <class RW>
+MJS_DEV void solve_newton(const Model& m, Env& e, const RW& w, double* ws_env, SolveState& st, double c_s) {
+  double search[NV], Mv[NV];
+  double* const qacc = st.qacc; double* const Ma = st.Ma; double* const grad = st.grad;
+  double cost = st.cost;
+  if (c_s < cost) {
+    for (int i = 0; i < NV; i++) { qacc[i] = e.qacc_smooth[i]; Ma[i] = e.qfrc_smooth[i]; }
+    cost = rows_pass(e, w, qacc, Ma, true, 0.0, grad);
   }
   const double scale = 1 / (m.meaninertia * NV);
-  BG_COUNT(e, 2);
 #pragma unroll 1
   for (int iter = 0; iter < MJS_SOLVER_ITERATIONS; iter++) {
-    BG_COUNT(e, 0);
     bool pd;
     for (int i = 0; i < NV; i++) e.sx[i] = grad[i];
     BG_S(e, 1, pd = newton_direction<RW>(ws_env));
@@ -1158,17 +1167,23 @@ MJS_DEV void forces_smooth(const Model& m, Env& e) {
   for (int i = 0; i < NV; i++) { e.qfrc_smooth[i] = e.passive[i] - e.bias[i] + act[i]; e.qacc_smooth[i] = e.qfrc_smooth[i]; }
   BG_S(e, 4, factor_solve_env<BG_OFF(qacc_smooth)>());  // mj_fwdAcceleration (the factor of M is not needed again)
 }
-template <bool PRE>
+// (every env has its seven equality rows: nefc > 0.) SPLIT: the smooth candidate's cost comes from another wavefront (e.cost_s) behind a
+// workgroup barrier - ONE barrier for the wavefront whatever accessor its lanes take, hence outside the two instantiations.
+template <bool PRE, bool SPLIT>
 MJS_DEV void forces_constraint(const Model& m, Env& e, double* ws_env) {
-  if (e.nefc <= LROWS) {  // every row is in LDS
-    const RowsLds w{e.tmp};
-    BG_S(e, 5, (solve<PRE, RowsLds>(m, e, w, ws_env)));
-    touch_sensor(e, w);
-  } else {
-    const Rows w{ws_env, e.tmp};
-    BG_S(e, 5, (solve<PRE, Rows>(m, e, w, ws_env)));
-    touch_sensor(e, w);
-  }
+  SolveState st;
+  const bool all_lds = e.nefc <= LROWS;  // every row is in LDS
+  const RowsLds wl{e.tmp};
+  const Rows wm{ws_env, e.tmp};
+  if (all_lds) solve_warm<PRE>(e, wl, st); else solve_warm<PRE>(e, wm, st);
+  double c_s;
+  if (SPLIT) {
+    __syncthreads();  // B3b
+    c_s = e.cost_s;
+  } else
+    c_s = all_lds ? cost_smooth(e, wl) : cost_smooth(e, wm);
+  if (all_lds) { BG_S(e, 5, solve_newton(m, e, wl, ws_env, st, c_s)); touch_sensor(e, wl); }
+  else { BG_S(e, 5, solve_newton(m, e, wm, ws_env, st, c_s)); touch_sensor(e, wm); }
 }
 // mj_step2 after the forces (warm start, implicitfast velocity update, position integration) on the INTEGRATING wavefront (role 1): the
 // matrix M + dt (damping + the unclamped actuators' velocity gains) depends on what is known before the solver starts, so it is
@@ -1248,12 +1263,22 @@ __device__ __noinline__ void st_integrate_split() {
   if (bad) e.r1_bad = 1;
 }
 
-__device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces_smooth(g_model, e); forces_constraint<false>(g_model, e, ws_lane); }  // one wavefront (resets)
+__device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces_smooth(g_model, e); forces_constraint<false, false>(g_model, e, ws_lane); }  // one wavefront (resets)
 __device__ __noinline__ void st_smooth() { forces_smooth(g_model, my_env()); }
 #ifndef BG_PRE_MW
 #define BG_PRE_MW true
 #endif
-__device__ __noinline__ void st_solve(double* ws_lane) { Env& e = my_env(); forces_constraint<BG_PRE_MW>(g_model, e, ws_lane); }
+#ifndef MJS_BG_ROLES
+#define MJS_BG_ROLES 3
+#endif
+#ifndef BG_SPLIT_COST
+#define BG_SPLIT_COST (MJS_BG_ROLES == 3)
+#endif
+__device__ __noinline__ void st_solve(double* ws_lane) { Env& e = my_env(); forces_constraint<BG_PRE_MW, BG_SPLIT_COST>(g_model, e, ws_lane); }
+__device__ __noinline__ void st_cost_smooth(double* ws_lane) {  // role 2, next to role 0's warm candidate
+  Env& e = my_env();
+  e.cost_s = e.nefc <= LROWS ? cost_smooth(e, RowsLds{e.tmp}) : cost_smooth(e, Rows{ws_lane, e.tmp});
+}
 __device__ __noinline__ void st_mul_warm() { sym_mul_env<BG_OFF(warm), BG_OFF(qacc)>(); }  // role 1, while role 0 runs st_smooth
 
 // ------------------------------------------------------------------------------------------------ model compilation (host)
@@ -1497,19 +1522,26 @@ MJS_DEV void reset_env(const Model& m, const KernelParams& p, int i, Env& e, con
 }
 
 // Envs per workgroup: `epw` lanes of each wavefront carry an env, the others leave at once (FP64 issue does not get faster with idle
-// lanes; the LDS holds 16 envs). A STEPPING workgroup has TWO wavefronts that share the envs in LDS, lane l of both working on env l:
-//   role 0: kinematics | crb (M), collision        | actuation, M^-1 qfrc_smooth | constraint solver, touch, switch |          |
-//   role 1:    (waits) | velocity stage, eq. rows  | contact rows                | factorises M + dt D              | integrate |
-//                      B1                          B2                            B3                                 B4         B5
-// five workgroup barriers per Physics.step(); every stage reads what the other role finished before the last barrier and writes
-// fields the other role does not touch until the next one (the stage scratch e.tmp belongs to role 1 until B3, then holds the rows).
-// The critical path is role 0's (65 % of the one-wavefront substep: profiles/r04_f_*). Resets run all stages on role 0 alone.
+// lanes; the LDS holds 16 envs). A STEPPING workgroup has ROLES wavefronts that share the envs in LDS, lane l of each working on env l:
+//   role 0: kinematics | crb (M), eq. / limit rows | actuation, M^-1 qfrc_smooth | warm candidate's pass  | Newton iterations, touch, switch |           |
+//   role 1:    (waits) | velocity stage            | M qacc_warmstart            |                        | factorises M + dt D              | integrate |
+//   role 2:    (waits) | collision                 | contact rows                | smooth candidate's cost|                                  |           |
+//                      B1                          B2                            B3                       B3b                                B4          B5
+// (ROLES == 2: collision on role 0, all rows on role 1, no B3b.) Six workgroup barriers per Physics.step(); every stage reads what another
+// role finished before the last barrier and writes fields no other role touches until the next one. What bounds the launch is the
+// latency of role 0's chain (profiles/r04_f_*): the roles exist to take everything off it that does not depend on its last result.
+// Resets run all stages on role 0.
 extern __shared__ double lds_envs[];
 #ifndef MJS_BG_WAVES
 #define MJS_BG_WAVES 1  // wavefronts per SIMD the register budget is cut for (tools/ab experiments: -DMJS_BG_WAVES=2 / 4)
 #endif
+#ifndef MJS_BG_ROLES
+#define MJS_BG_ROLES 3
+#endif
+constexpr int ROLES = MJS_BG_ROLES;
+static_assert(ROLES == 2 || ROLES == 3, "two or three wavefronts per env group");
 template <bool IS_RESET>
-__global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES, MJS_BG_WAVES))) void kernel(KernelParams p, double* ws_base, int epw) {
+__global__ __launch_bounds__(IS_RESET ? 64 : 64 * ROLES) __attribute__((amdgpu_waves_per_eu(MJS_BG_WAVES, MJS_BG_WAVES))) void kernel(KernelParams p, double* ws_base, int epw) {
   const int lane = threadIdx.x & 63;
   const int role = IS_RESET ? 0 : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (lane >= epw) return;
@@ -1518,7 +1550,7 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_pe
   const Model& m = g_model;
   const Rows w{ws_base + (size_t)i * WS_DOUBLES, nullptr};  // (the kernel only hands the HBM pointer to the stages)
   uint8_t flags = p.flags[i];
-  if (!IS_RESET) __syncthreads();  // both wavefronts have read flags[i] before role 0 may rewrite it
+  if (!IS_RESET) __syncthreads();  // every wavefront has read flags[i] before role 0 may rewrite it
   Env& e = reinterpret_cast<Env*>(lds_envs)[lane];
   if (IS_RESET || ((flags & FLAG_RESET_PENDING) && p.autoreset == MJS_AUTORESET_NEXT_STEP)) {
     if (role != 0) return;
@@ -1530,16 +1562,17 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_pe
 #ifdef MJS_BG_PROFILE
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-  if (role != 0) {  // ---------------------------------------------------------------- role 1
+  if (role == 1) {  // ---------------------------------------------------------------- role 1
     __syncthreads();                       // the env is loaded, kinematics done (B1)
     BG_T(4, st_velocity());
-    BG_T(3, st_rows_eq());
+    if (ROLES == 2) BG_T(3, st_rows_eq());
     __syncthreads();                       // B2
 #pragma unroll 1
     for (int s = 0; s < MJS_RR_NSUB; s++) {
-      BG_T(3, st_rows_contacts(w.base));
+      if (ROLES == 2) BG_T(3, st_rows_contacts(w.base));
       if (BG_PRE_MW) st_mul_warm();
       __syncthreads();                     // B3: the rows are complete
+      if (BG_SPLIT_COST) __syncthreads();  // B3b (roles 0 and 2 exchange the smooth candidate's cost)
       BG_T(6, st_integrate_split());       // (B4 inside)
 #ifdef MJS_BG_PROFILE
       if (s == MJS_RR_NSUB - 1)
@@ -1547,10 +1580,30 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_pe
 #endif
       __syncthreads();                     // B5: the new state
       __syncthreads();                     // B1
-      if (s < MJS_RR_NSUB - 1) {           // (the last mj_step1 only serves the observation and ncon: role 0's kinematics + collision)
+      if (s < MJS_RR_NSUB - 1) {           // (the last mj_step1 only serves the observation and ncon: kinematics + collision)
         BG_T(4, st_velocity());
-        BG_T(3, st_rows_eq());
+        if (ROLES == 2) BG_T(3, st_rows_eq());
       }
+      __syncthreads();                     // B2
+    }
+    return;
+  }
+  if (ROLES == 3 && role == 2) {  // --------------------------------------------------- role 2
+    __syncthreads();                       // B1
+    st_collision();
+    __syncthreads();                       // B2: the equality / limit rows are made (role 0)
+#pragma unroll 1
+    for (int s = 0; s < MJS_RR_NSUB; s++) {
+      st_rows_contacts(w.base);
+      __syncthreads();                     // B3
+      if (BG_SPLIT_COST) {
+        st_cost_smooth(w.base);            // qacc_smooth is role 0's, from before B3
+        __syncthreads();                   // B3b
+      }
+      __syncthreads();                     // B4
+      __syncthreads();                     // B5
+      __syncthreads();                     // B1
+      st_collision();
       __syncthreads();                     // B2
     }
     return;
@@ -1583,7 +1636,8 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_pe
   BG_T(0, st_kinematics());  // the previous Physics.step()'s mj_step1 (a function of the state)
   __syncthreads();           // B1
   BG_T(1, st_crb());
-  BG_T(2, st_collision());
+  if (ROLES == 2) BG_T(2, st_collision());
+  else BG_T(3, st_rows_eq());
   __syncthreads();           // B2
 #pragma unroll 1
   for (int s = 0; s < MJS_RR_NSUB; s++) {
@@ -1599,7 +1653,8 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 128) __attribute__((amdgpu_waves_pe
     BG_T(0, st_kinematics());              // ... mj_step1 (dm_control's legacy order)
     __syncthreads();                       // B1
     if (s < MJS_RR_NSUB - 1) BG_T(1, st_crb());
-    BG_T(2, st_collision());
+    if (ROLES == 2) BG_T(2, st_collision());
+    else if (s < MJS_RR_NSUB - 1) BG_T(3, st_rows_eq());
     __syncthreads();                       // B2
   }
   const bool bad = e.r1_bad != 0;

@@ -241,7 +241,7 @@ int launch(mjs_handle* h, const KernelParams& p, hipStream_t s) {
     pp5::kernel<IS_RESET><<<dim3((unsigned)(((!IS_RESET && p.prefetch) ? 2 : 1) * ((p.N + pp5::EPW * pp5::WAVES - 1) / (pp5::EPW * pp5::WAVES)))), BLOCK * pp5::WAVES, pp5::LDS_BYTES, s>>>(p);
   else if (articulated(h)) {
     const int epw = bg_epw_for(p.N);
-    bg::kernel<IS_RESET><<<dim3((unsigned)((p.N + epw - 1) / epw)), IS_RESET ? BLOCK : 2 * BLOCK, (size_t)epw * sizeof(bg::Env), s>>>(p, h->ws14, epw);  // stepping: two wavefronts share the envs
+    bg::kernel<IS_RESET><<<dim3((unsigned)((p.N + epw - 1) / epw)), IS_RESET ? BLOCK : bg::ROLES * BLOCK, (size_t)epw * sizeof(bg::Env), s>>>(p, h->ws14, epw);  // stepping: bg::ROLES wavefronts share the envs
   }
   else if (h->cfg.task == MJS_TASK_BUTTON_PUSH) {
     const dim3 bgrid((unsigned)((p.N + p.epg - 1) / p.epg));
