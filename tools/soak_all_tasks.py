@@ -76,7 +76,7 @@ def run(name, task, tid, N, T, actions, seed, tie_check=False, venv_kw=None, ob_
 
 
 rs = np.random.RandomState(123 + SEED_SHIFT)
-which = sys.argv[1:] or ["reach_box", "reach_success", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "planar_push", "pointmass"]
+which = sys.argv[1:] or ["reach_box", "reach_success", "reach_wild", "button_eef", "button_joint_full", "button_joint_nominal", "button_articulated", "planar_push", "pointmass"]
 if "reach_box" in which:
     run("Robot-Reach, workspace actions, 3 episodes", "robot_reach", oracle.TASK_ROBOT_REACH, 4096, 250, lambda t: rs.uniform([-0.1, -0.6, 0.02], [0.1, -0.4, 0.2], (4096, 3)), 11)
 if "reach_success" in which:
@@ -107,6 +107,16 @@ if "button_joint_nominal" in which:
     nominal = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04])
     run("Button-Push, joint actions around the nominal pose", "robot_push_button", oracle.TASK_BUTTON_PUSH, 2048, 220,
         lambda t: nominal + rs.uniform(-1, 1, (2048, 7)) * np.array([0.6, 0.4, 0.4, 0.4, 0.4, 0.6, 0.04]), 15)
+if "button_articulated" in which:
+    # the articulated 2F-85 (mjs_gripper14.h: three wavefronts per env group): EEF actions over the workspace with the fingers opening and
+    # closing (pads on the switch / the floor where the targets go low), same-step resets; joint actions around the nominal pose
+    run("Button-Push, articulated gripper, EEF actions, same-step reset", "robot_push_button", oracle.TASK_BUTTON_PUSH, 1024, 110,
+        lambda t: rs.uniform([-0.2, -0.6, 0.05, 0.0], [0.2, -0.3, 0.3, 0.085], (1024, 4)), 21,
+        venv_kw=dict(autoreset="same_step", action_type="absolute_eef_action", gripper_model="articulated"), ob_kw=dict(autoreset=1, action_type=1, gripper_model=1), atol=1e-6)
+    nominal14 = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0, 0.04])
+    run("Button-Push, articulated gripper, joint actions around the nominal pose", "robot_push_button", oracle.TASK_BUTTON_PUSH, 1024, 110,
+        lambda t: nominal14 + rs.uniform(-1, 1, (1024, 7)) * np.array([0.4, 0.3, 0.3, 0.3, 0.3, 0.6, 0.04]), 22,
+        venv_kw=dict(gripper_model="articulated"), ob_kw=dict(gripper_model=1), atol=1e-6)
 def run_push(name, shape, N=2048, LIMIT=40, T=85, seed=31):
     """Planar-Push with the conditioning rule of tests/test_gpu_parity.py::_check_ill_conditioned_envs: a second oracle whose resets are perturbed by
     1e-13 m measures every env's sensitivity; calm envs (< 1e-10) are held to 1e-6 (worst value reported) and exact flags / contact counts, the others to the episode
