@@ -408,7 +408,7 @@ def main():
                        "scaling_mode": ("weak: envs_per_gpu fixed, envs_total grows with the GPU count" if args.scaling == "weak" else
                                         "strong: envs_total fixed, envs_per_gpu = envs_total / n_gpus (a launch is latency-bound below ~16k envs per GPU: expect ~1x)")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else (None if (args.task == "robot_push_button" and args.gripper_model == "articulated") else measured_traffic(args.task, n_local)), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
+                         "traffic": None if (args.stub or (args.task == "robot_planar_push" and args.n_objects != 2)) else measured_traffic(args.task + ("_articulated" if (args.task == "robot_push_button" and args.gripper_model == "articulated") else ""), n_local), "kernel_ms": kernel_ms, "algorithmic_bytes_per_env_step": bytes_per_env_step,
                          "note": "state fits in L2 at this size; the kernel is bound by per-lane FP64 dependency chains (DESIGN.md)"},
             "faults": faults,
         }

@@ -768,6 +768,7 @@ MJS_DEV void make_rows_eq(const Model& m, Env& e, const RW& w) {
       const KBI kb = kbi(m.lim_solref[j], m.lim_solimp[j][0], m.lim_solimp[j][1], m.lim_solimp[j][2], dist);
       const double R = fmax(MJS_MINVAL, (1 - kb.imp) * m.dof_invweight0[j] / kb.imp);
       put_row(w, r, J, dist, 1 / R, -kb.B * (-side * e.v[j]) - kb.K * kb.imp * dist);
+      e.rcon[r] = (uint8_t)j;  // the row's dof (the solver's shortcuts for +-e_j rows)
       e.rtype[r++] = 1;
       e.nlim++;
     }
@@ -868,30 +869,75 @@ MJS_DEV void actuation(const Model& m, Env& e, double* qfrc_act) {
 // constraint cost, and grad = Ma - qfrc_smooth - J^T f; returns the cost incl. the Gauss term. The oracle walks the rows once per
 // quantity; fused here because every pass over the HBM row workspace is a chain of dependent loads on a wavefront that has its
 // SIMD to itself.
+// column pattern of the equality rows (make_rows_eq's order): rows 0-2 connect the right follower (body 9: chain 8, 5..0) to the right
+// coupler (7: 6, 5..0), rows 3-5 the left ones (13: 12, 5..0; 11: 10, 5..0), row 6 couples the drivers (6, 10)
+MJS_HD constexpr bool eq_row_touches(int r, int k) {
+  return r < 3 ? (k < NA + 4) : r < 6 ? (k < NA || k >= NA + 4) : (k == B_RDRIVER || k == B_LDRIVER);
+}
 // COST_ONLY: nothing is written (no jar / force / zone, no gradient): the pass another wavefront runs on the smooth candidate while the
-// solving wavefront evaluates the warm one; same arithmetic for the cost, bit for bit.
-template <class RW, bool COST_ONLY = false>
-MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* Ma, bool fresh, double alpha, double* grad) {
+// solving wavefront evaluates the warm one; same arithmetic for the cost, bit for bit. FRESH: jar = J q - aref with the candidate q_mem
+// (a field of the env in LDS: a limit row reads its one component by a run-time index), else jar += alpha jv. The seven equality rows
+// go first as straight-line code on their static column pattern (eq_row_touches); a limit row is +-e_j (dof in rcon) and hands its
+// J^T f to the gradient through e.sx (no run-time index into a register array).
+template <class RW, bool COST_ONLY, bool FRESH>
+MJS_DEV double rows_pass(Env& e, const RW& w, const double* q_mem, const double* qacc, const double* Ma, double alpha, double* grad) {
   double cost = 0;
-  if (!COST_ONLY)
+  if (!COST_ONLY) {
     for (int i = 0; i < NV; i++) grad[i] = Ma[i] - e.qfrc_smooth[i];
+    for (int i = 0; i < NV; i++) e.sx[i] = 0;
+  }
+#pragma unroll
+  for (int r = 0; r < NEQ_ROWS; r++) {
+    double Jr[NV], z;
+#pragma unroll
+    for (int k = 0; k < NV; k++) Jr[k] = (eq_row_touches(r, k) && (FRESH || !COST_ONLY)) ? w.at(r, ROW_J + k) : 0.0;
+    if (FRESH) {
+      z = -w.at(r, ROW_AREF);
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        if (eq_row_touches(r, k)) z += Jr[k] * q_mem[k];
+    } else
+      z = w.at(r, ROW_JAR) + alpha * w.at(r, ROW_JV);
+    const double D = w.at(r, ROW_D), f = -D * z;
+    cost += 0.5 * D * z * z;
+    if (!COST_ONLY) {
+      w.at(r, ROW_JAR) = z;
+      w.at(r, ROW_FORCE) = f;
+#pragma unroll
+      for (int k = 0; k < NV; k++)
+        if (eq_row_touches(r, k)) grad[k] -= Jr[k] * f;
+    }
+  }
 #pragma unroll 1
-  for (int r = 0; r < e.nefc; r++) {
+  for (int r = NEQ_ROWS; r < e.nefc; r++) {
     const int t = e.rtype[r];
-    const int nr = t == 2 ? 3 : 1;
+    if (t == 1) {
+      const int j = e.rcon[r];
+      const double Jj = w.at(r, ROW_J + j);
+      const double z = FRESH ? Jj * q_mem[j] - w.at(r, ROW_AREF) : w.at(r, ROW_JAR) + alpha * w.at(r, ROW_JV);
+      const double D = w.at(r, ROW_D);
+      const bool act = z < 0;
+      const double f = act ? -D * z : 0.0;
+      if (act) cost += 0.5 * D * z * z;
+      if (!COST_ONLY) {
+        w.at(r, ROW_JAR) = z;
+        w.at(r, ROW_FORCE) = f;
+        if (act) e.sx[j] += Jj * f;
+      }
+      continue;
+    }
     double Jr[3][NV], z[3], f[3] = {0, 0, 0};
     for (int a = 0; a < 3; a++) {
-      if (a >= nr) continue;
       for (int k = 0; k < NV; k++) Jr[a][k] = w.at(r + a, ROW_J + k);
-      if (fresh) {
+      if (FRESH) {
         double sj = -w.at(r + a, ROW_AREF);
-        for (int k = 0; k < NV; k++) sj += Jr[a][k] * qacc[k];
+        for (int k = 0; k < NV; k++) sj += Jr[a][k] * q_mem[k];
         z[a] = sj;
       } else
         z[a] = w.at(r + a, ROW_JAR) + alpha * w.at(r + a, ROW_JV);
       if (!COST_ONLY) w.at(r + a, ROW_JAR) = z[a];
     }
-    if (t == 2) {
+    {
       Contact& con = e.con[e.rcon[r]];
       const double D0 = w.at(r, ROW_D), D1 = w.at(r + 1, ROW_D);
       const double mu = con.mu, fr = con.friction;
@@ -908,21 +954,17 @@ MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* 
         f[0] = -Dm * NT * mu;
         f[1] = -f[0] / T * U1 * fr; f[2] = -f[0] / T * U2 * fr;
       }
-    } else {
-      const double D = w.at(r, ROW_D);
-      const bool act = t == 0 || z[0] < 0;
-      f[0] = act ? -D * z[0] : 0.0;
-      if (act) cost += 0.5 * D * z[0] * z[0];
     }
     if (!COST_ONLY)
       for (int a = 0; a < 3; a++) {
-        if (a >= nr) continue;
         w.at(r + a, ROW_FORCE) = f[a];
         if (f[a] != 0)
           for (int k = 0; k < NV; k++) grad[k] -= Jr[a][k] * f[a];
       }
-    r += nr - 1;
+    r += 2;
   }
+  if (!COST_ONLY)
+    for (int i = 0; i < NV; i++) grad[i] -= e.sx[i];
   double gauss = 0;
   for (int i = 0; i < NV; i++) gauss += (Ma[i] - e.qfrc_smooth[i]) * (qacc[i] - e.qacc_smooth[i]);
   return cost + 0.5 * gauss;
@@ -931,12 +973,18 @@ MJS_DEV double rows_pass(Env& e, const RW& w, const double* qacc, const double* 
 template <class RW>
 MJS_DEV double line_search(Env& e, const RW& w, double g1, double g2, double gtol) {
   double alpha = 0, lo = 0, hi = INFINITY;
+  // the equality rows are always active: their share of the derivatives is the same quadratic in every iteration, folded into (g1, g2)
+#pragma unroll
+  for (int r = 0; r < NEQ_ROWS; r++) {
+    const double D = w.at(r, ROW_D), jar = w.at(r, ROW_JAR), jv = w.at(r, ROW_JV);
+    g1 += D * jar * jv; g2 += D * jv * jv;
+  }
 #pragma unroll 1
   for (int it = 0; it < 50; it++) {
     BG_COUNT(e, 1);
     double d1 = g1 + alpha * g2, d2 = g2;
 #pragma unroll 1
-    for (int r = 0; r < e.nefc; r++) {
+    for (int r = NEQ_ROWS; r < e.nefc; r++) {
       const int t = e.rtype[r];
       if (t == 2) {
         const Contact& con = e.con[e.rcon[r]];
@@ -993,9 +1041,34 @@ BG_NEWTON_INLINE bool newton_direction(double* ws_env) {  // gradient in e.sx, s
   double h[NTRI];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) h[k] = e.M[k];
+  // The seven equality rows are always there, always active and in a fixed order with a STATIC column pattern (make_rows_eq: a connect
+  // row touches the arm and the two chains of its finger, 10 of 14 dofs; the coupling row the two drivers): unrolled with static LDS
+  // offsets, 55 / 3 multiply-adds per row instead of 105. A limit row is +-e_j: its D goes to one diagonal entry, collected per dof
+  // in e.sy (free until the search direction is written) because a register array has no run-time index.
+#pragma unroll
+  for (int r = 0; r < NEQ_ROWS; r++) {
+    const double D = w.at(r, ROW_D);
+    double Jr[NV];
+#pragma unroll
+    for (int k = 0; k < NV; k++) Jr[k] = eq_row_touches(r, k) ? w.at(r, ROW_J + k) : 0.0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      if (!eq_row_touches(r, i)) continue;
+      const double dj = D * Jr[i];
+#pragma unroll
+      for (int j = 0; j <= i; j++)
+        if (eq_row_touches(r, j)) h[tri(i, j)] += dj * Jr[j];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NV; k++) e.sy[k] = 0;
 #pragma unroll 1
-  for (int r = 0; r < e.nefc; r++) {
+  for (int r = NEQ_ROWS; r < e.nefc; r++) {
     const int t = e.rtype[r];
+    if (t == 1) {  // joint limit: J = +-e_j with j in rcon
+      if (w.at(r, ROW_JAR) < 0) e.sy[e.rcon[r]] += w.at(r, ROW_D);
+      continue;
+    }
     if (t == 2) {
       const Contact& con = e.con[e.rcon[r]];
       if (con.zone != 0) {
@@ -1031,18 +1104,9 @@ BG_NEWTON_INLINE bool newton_direction(double* ws_env) {  // gradient in e.sx, s
       r += 2;
       continue;
     }
-    if (!(t == 0 || w.at(r, ROW_JAR) < 0)) continue;
-    const double D = w.at(r, ROW_D);
-    double Jr[NV];
-#pragma unroll
-    for (int k = 0; k < NV; k++) Jr[k] = w.at(r, ROW_J + k);
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      const double dj = D * Jr[i];
-#pragma unroll
-      for (int j = 0; j <= i; j++) h[tri(i, j)] += dj * Jr[j];
-    }
   }
+#pragma unroll
+  for (int k = 0; k < NV; k++) h[tri(k, k)] += e.sy[k];
   // Cholesky in place (the diagonal holds 1 / l_jj)
   bool ok = true;
 #pragma unroll
@@ -1080,12 +1144,25 @@ BG_NEWTON_INLINE bool newton_direction(double* ws_env) {  // gradient in e.sx, s
   }
 #pragma unroll
   for (int i = 0; i < NV; i++) search[i] = y[i];
-  // J search for the line search
-#pragma unroll 1
-  for (int r = 0; r < e.nefc; r++) {
+  // J search for the line search (equality rows by their pattern; a limit row reads its one component of the search from LDS)
+#pragma unroll
+  for (int r = 0; r < NEQ_ROWS; r++) {
     double sj = 0;
 #pragma unroll
-    for (int k = 0; k < NV; k++) sj += w.at(r, ROW_J + k) * y[k];
+    for (int k = 0; k < NV; k++)
+      if (eq_row_touches(r, k)) sj += w.at(r, ROW_J + k) * y[k];
+    w.at(r, ROW_JV) = sj;
+  }
+#pragma unroll 1
+  for (int r = NEQ_ROWS; r < e.nefc; r++) {
+    double sj = 0;
+    if (e.rtype[r] == 1) {
+      const int j = e.rcon[r];
+      sj = w.at(r, ROW_J + j) * search[j];
+    } else {
+#pragma unroll
+      for (int k = 0; k < NV; k++) sj += w.at(r, ROW_J + k) * y[k];
+    }
     w.at(r, ROW_JV) = sj;
   }
   return ok;
@@ -1105,13 +1182,13 @@ MJS_DEV void solve_warm(Env& e, const RW& w, SolveState& st) {
     for (int i = 0; i < NV; i++) st.Ma[i] = e.sy[i];
   }
   for (int i = 0; i < NV; i++) st.qacc[i] = e.warm[i];
-  st.cost = rows_pass(e, w, st.qacc, st.Ma, true, 0.0, st.grad);
+  st.cost = rows_pass<RW, false, true>(e, w, e.warm, st.qacc, st.Ma, 0.0, st.grad);
 }
 template <class RW>
 MJS_DEV double cost_smooth(Env& e, const RW& w) {
   double ma_s[NV];
   for (int i = 0; i < NV; i++) ma_s[i] = e.qfrc_smooth[i];
-  return rows_pass<RW, true>(e, w, e.qacc_smooth, ma_s, true, 0.0, nullptr);
+  return rows_pass<RW, true, true>(e, w, e.qacc_smooth, e.qacc_smooth, ma_s, 0.0, nullptr);
 }
 template <class RW>
 MJS_DEV void solve_newton(const Model& m, Env& e, const RW& w, double* ws_env, SolveState& st, double c_s) {
@@ -1120,7 +1197,7 @@ MJS_DEV void solve_newton(const Model& m, Env& e, const RW& w, double* ws_env, S
   double cost = st.cost;
   if (c_s < cost) {
     for (int i = 0; i < NV; i++) { qacc[i] = e.qacc_smooth[i]; Ma[i] = e.qfrc_smooth[i]; }
-    cost = rows_pass(e, w, qacc, Ma, true, 0.0, grad);
+    cost = rows_pass<RW, false, true>(e, w, e.qacc_smooth, qacc, Ma, 0.0, grad);
   }
   const double scale = 1 / (m.meaninertia * NV);
 #pragma unroll 1
@@ -1139,7 +1216,7 @@ MJS_DEV void solve_newton(const Model& m, Env& e, const RW& w, double* ws_env, S
     if (alpha == 0) break;
     for (int i = 0; i < NV; i++) { qacc[i] += alpha * search[i]; Ma[i] += alpha * Mv[i]; }
     const double oldcost = cost;
-    BG_S(e, 3, cost = rows_pass(e, w, qacc, Ma, false, alpha, grad));
+    BG_S(e, 3, (cost = rows_pass<RW, false, false>(e, w, nullptr, qacc, Ma, alpha, grad)));
     double gn = 0;
     for (int i = 0; i < NV; i++) gn += grad[i] * grad[i];
     if (scale * (oldcost - cost) < MJS_SOLVER_TOLERANCE || scale * sqrt(gn) < MJS_SOLVER_TOLERANCE) break;

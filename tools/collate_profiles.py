@@ -15,8 +15,9 @@ from pathlib import Path
 
 ROOT = Path(__file__).resolve().parents[1]
 FETCH_CALIBRATION = 0.5039
-STEP_KERNELS = {"robot_reach": "rr::kernel3", "point_mass_reach": "pm::kernel<false>", "robot_push_button": "bp::kernel<false", "robot_planar_push": "pp::kernel<false>"}
-ALG_BYTES = {"robot_reach": 571, "point_mass_reach": 267, "robot_push_button": 643, "robot_planar_push": 843}  # mjs_algorithmic_bytes_per_env_step (abi 2)
+STEP_KERNELS = {"robot_reach": "rr::kernel3", "point_mass_reach": "pm::kernel<false>", "robot_push_button": "bp::kernel<false", "robot_planar_push": "pp::kernel<false>",
+                "robot_push_button_articulated": "bg::kernel<false>"}
+ALG_BYTES = {"robot_reach": 571, "point_mass_reach": 267, "robot_push_button": 643, "robot_planar_push": 843, "robot_push_button_articulated": 1123}  # mjs_algorithmic_bytes_per_env_step (abi 2)
 
 
 def find(d, suffix):

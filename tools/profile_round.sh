@@ -33,6 +33,8 @@ for task in robot_reach point_mass_reach robot_push_button; do
   pmc ${task}_FETCH_SIZE FETCH_SIZE --task $task --steps 100 --warmup 10 --no-cpu-baseline
   pmc ${task}_WRITE_SIZE WRITE_SIZE --task $task --steps 100 --warmup 10 --no-cpu-baseline
 done
+pmc robot_push_button_articulated_FETCH_SIZE FETCH_SIZE --task robot_push_button --gripper-model articulated --steps 30 --warmup 5 --no-cpu-baseline
+pmc robot_push_button_articulated_WRITE_SIZE WRITE_SIZE --task robot_push_button --gripper-model articulated --steps 30 --warmup 5 --no-cpu-baseline
 pmc robot_planar_push_FETCH_SIZE FETCH_SIZE --task robot_planar_push --steps 30 --warmup 10 --no-cpu-baseline
 pmc robot_planar_push_WRITE_SIZE WRITE_SIZE --task robot_planar_push --steps 30 --warmup 10 --no-cpu-baseline
 pmc reach_valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" --steps 100 --warmup 10 --no-cpu-baseline
