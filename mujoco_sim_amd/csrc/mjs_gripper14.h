@@ -349,8 +349,11 @@ BG_NEWTON_INLINE void factor_solve_env() {  // e[XO..] <- M^-1 e[XO..] (fields o
   for (int k = 0; k < NV; k++) x[k] = y[k];
 }
 // y = M x with the packed symmetric M in registers
+#ifndef BG_SYMMUL_ATTR
+#define BG_SYMMUL_ATTR BG_NEWTON_INLINE
+#endif
 template <int XO, int YO>
-BG_NEWTON_INLINE void sym_mul_env() {  // e[YO..] = M e[XO..]
+BG_SYMMUL_ATTR void sym_mul_env() {  // e[YO..] = M e[XO..]
   Env& e = my_env();
   const double* const M = e.M;
   const double* const x = reinterpret_cast<double*>(&e) + XO;
@@ -1266,9 +1269,7 @@ MJS_DEV void forces_constraint(const Model& m, Env& e, double* ws_env) {
 // matrix M + dt (damping + the unclamped actuators' velocity gains) depends on what is known before the solver starts, so it is
 // factorised - in registers - WHILE role 0 solves the constraints; the workgroup barrier in the middle is the solver's completion
 // (role 0 executes the matching barrier after st_solve), after which only the two substitutions and the state update remain.
-__device__ __noinline__ void st_integrate_split() {
-  const Model& m = g_model;
-  Env& e = my_env();
+MJS_DEV void integrate_split(const Model& m, Env& e) {
   double a[NTRI], y[NV];
 #pragma unroll
   for (int k = 0; k < NTRI; k++) a[k] = e.M[k];
@@ -1340,6 +1341,7 @@ __device__ __noinline__ void st_integrate_split() {
   if (bad) e.r1_bad = 1;
 }
 
+__device__ __noinline__ void st_integrate_split() { integrate_split(g_model, my_env()); }
 __device__ __noinline__ void st_forces(double* ws_lane) { Env& e = my_env(); forces_smooth(g_model, e); forces_constraint<false, false>(g_model, e, ws_lane); }  // one wavefront (resets)
 __device__ __noinline__ void st_smooth() { forces_smooth(g_model, my_env()); }
 #ifndef BG_PRE_MW
@@ -1352,10 +1354,17 @@ __device__ __noinline__ void st_smooth() { forces_smooth(g_model, my_env()); }
 #define BG_SPLIT_COST (MJS_BG_ROLES == 3)
 #endif
 __device__ __noinline__ void st_solve(double* ws_lane) { Env& e = my_env(); forces_constraint<BG_PRE_MW, BG_SPLIT_COST>(g_model, e, ws_lane); }
-__device__ __noinline__ void st_cost_smooth(double* ws_lane) {  // role 2, next to role 0's warm candidate
-  Env& e = my_env();
-  e.cost_s = e.nefc <= LROWS ? cost_smooth(e, RowsLds{e.tmp}) : cost_smooth(e, Rows{ws_lane, e.tmp});
-}
+MJS_DEV void cost_smooth_stage(Env& e, double* ws_lane) { e.cost_s = e.nefc <= LROWS ? cost_smooth(e, RowsLds{e.tmp}) : cost_smooth(e, Rows{ws_lane, e.tmp}); }
+__device__ __noinline__ void st_cost_smooth(double* ws_lane) { cost_smooth_stage(my_env(), ws_lane); }  // role 2, next to role 0's warm candidate
+// stage call in the role loops: out of line (one shared copy, callee-saved registers through scratch on every call) or in line
+#ifndef BG_STAGE_INLINE
+#define BG_STAGE_INLINE 1
+#endif
+#if BG_STAGE_INLINE
+#define BG_ST(call, body) body
+#else
+#define BG_ST(call, body) call
+#endif
 __device__ __noinline__ void st_mul_warm() { sym_mul_env<BG_OFF(warm), BG_OFF(qacc)>(); }  // role 1, while role 0 runs st_smooth
 
 // ------------------------------------------------------------------------------------------------ model compilation (host)
@@ -1639,49 +1648,47 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 64 * ROLES) __attribute__((amdgpu_w
 #ifdef MJS_BG_PROFILE
   double prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+  // Each role's loop names every stage ONCE (the loop starts with the mj_step1 of the state it finds and ends after the last one), so
+  // that BG_STAGE_INLINE can put the stage bodies in line without duplicating them: an out-of-line stage saves and restores the
+  // callee-saved registers it uses on every call (scratch traffic: profiles/r04_f_*), an in-line one does not.
   if (role == 1) {  // ---------------------------------------------------------------- role 1
-    __syncthreads();                       // the env is loaded, kinematics done (B1)
-    BG_T(4, st_velocity());
-    if (ROLES == 2) BG_T(3, st_rows_eq());
-    __syncthreads();                       // B2
 #pragma unroll 1
-    for (int s = 0; s < MJS_RR_NSUB; s++) {
-      if (ROLES == 2) BG_T(3, st_rows_contacts(w.base));
+    for (int s = 0;; s++) {
+      __syncthreads();                     // B1: (the env is loaded,) kinematics done
+      if (s < MJS_RR_NSUB) {               // (the last mj_step1 only serves the observation and ncon: kinematics + collision)
+        BG_T(4, BG_ST(st_velocity(), velocity_stage(g_model, e)));
+        if (ROLES == 2) BG_T(3, BG_ST(st_rows_eq(), make_rows_eq(g_model, e, RowsLds{e.tmp})));
+      }
+      __syncthreads();                     // B2
+      if (s == MJS_RR_NSUB) break;
+      if (ROLES == 2) BG_T(3, BG_ST(st_rows_contacts(w.base), make_rows_contacts(g_model, e, Rows{w.base, e.tmp})));
       if (BG_PRE_MW) st_mul_warm();
       __syncthreads();                     // B3: the rows are complete
       if (BG_SPLIT_COST) __syncthreads();  // B3b (roles 0 and 2 exchange the smooth candidate's cost)
-      BG_T(6, st_integrate_split());       // (B4 inside)
+      BG_T(6, BG_ST(st_integrate_split(), integrate_split(g_model, e)));  // (B4 inside)
 #ifdef MJS_BG_PROFILE
       if (s == MJS_RR_NSUB - 1)
         for (int k = 0; k < 8; k++) e.prof1[k] = prof[k];
 #endif
       __syncthreads();                     // B5: the new state
-      __syncthreads();                     // B1
-      if (s < MJS_RR_NSUB - 1) {           // (the last mj_step1 only serves the observation and ncon: kinematics + collision)
-        BG_T(4, st_velocity());
-        if (ROLES == 2) BG_T(3, st_rows_eq());
-      }
-      __syncthreads();                     // B2
     }
     return;
   }
   if (ROLES == 3 && role == 2) {  // --------------------------------------------------- role 2
-    __syncthreads();                       // B1
-    st_collision();
-    __syncthreads();                       // B2: the equality / limit rows are made (role 0)
 #pragma unroll 1
-    for (int s = 0; s < MJS_RR_NSUB; s++) {
-      st_rows_contacts(w.base);
+    for (int s = 0;; s++) {
+      __syncthreads();                     // B1
+      BG_ST(st_collision(), collision(g_model, e));
+      __syncthreads();                     // B2: the equality / limit rows are made (role 0)
+      if (s == MJS_RR_NSUB) break;
+      BG_ST(st_rows_contacts(w.base), make_rows_contacts(g_model, e, Rows{w.base, e.tmp}));
       __syncthreads();                     // B3
       if (BG_SPLIT_COST) {
-        st_cost_smooth(w.base);            // qacc_smooth is role 0's, from before B3
+        BG_ST(st_cost_smooth(w.base), cost_smooth_stage(e, w.base));  // qacc_smooth is role 0's, from before B3
         __syncthreads();                   // B3b
       }
       __syncthreads();                     // B4
       __syncthreads();                     // B5
-      __syncthreads();                     // B1
-      st_collision();
-      __syncthreads();                     // B2
     }
     return;
   }
@@ -1710,29 +1717,24 @@ __global__ __launch_bounds__(IS_RESET ? 64 : 64 * ROLES) __attribute__((amdgpu_w
 #ifdef MJS_BG_PROFILE
   for (int k = 0; k < 6; k++) e.dbg[k] = 0;
 #endif
-  BG_T(0, st_kinematics());  // the previous Physics.step()'s mj_step1 (a function of the state)
-  __syncthreads();           // B1
-  BG_T(1, st_crb());
-  if (ROLES == 2) BG_T(2, st_collision());
-  else BG_T(3, st_rows_eq());
-  __syncthreads();           // B2
 #pragma unroll 1
-  for (int s = 0; s < MJS_RR_NSUB; s++) {
+  for (int s = 0;; s++) {
+    BG_T(0, BG_ST(st_kinematics(), kinematics(g_model, e)));  // mj_step1 of the state (first pass: the previous Physics.step()'s; dm_control's legacy order)
+    __syncthreads();                       // B1
+    if (s < MJS_RR_NSUB) BG_T(1, BG_ST(st_crb(), crb(g_model, e)));
+    if (ROLES == 2) BG_T(2, BG_ST(st_collision(), collision(g_model, e)));
+    else if (s < MJS_RR_NSUB) BG_T(3, BG_ST(st_rows_eq(), make_rows_eq(g_model, e, RowsLds{e.tmp})));
+    __syncthreads();                       // B2
+    if (s == MJS_RR_NSUB) break;
     const double t = fmin(fmax(e.time, t0), t1);
     for (int j = 0; j < NA; j++) e.ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;  // robot.py:261-263
-    BG_T(5, st_smooth());                  // mj_step2: mj_fwdActuation, mj_fwdAcceleration ...
+    BG_T(5, BG_ST(st_smooth(), forces_smooth(g_model, e)));  // mj_step2: mj_fwdActuation, mj_fwdAcceleration ...
     __syncthreads();                       // B3
     rows_active = rows_active || e.nefc > NEQ_ROWS;
-    BG_T(5, st_solve(w.base));             // ... mj_fwdConstraint, mj_sensorAcc
+    BG_T(5, BG_ST(st_solve(w.base), (forces_constraint<BG_PRE_MW, BG_SPLIT_COST>(g_model, e, w.base))));  // ... mj_fwdConstraint, mj_sensorAcc (B3b inside)
     bp::switch_update(e.touch, flags);     // Switch.after_substep (switch.py:71-72): the touch force of this Physics.step()
     __syncthreads();                       // B4: role 1 integrates
     __syncthreads();                       // B5
-    BG_T(0, st_kinematics());              // ... mj_step1 (dm_control's legacy order)
-    __syncthreads();                       // B1
-    if (s < MJS_RR_NSUB - 1) BG_T(1, st_crb());
-    if (ROLES == 2) BG_T(2, st_collision());
-    else if (s < MJS_RR_NSUB - 1) BG_T(3, st_rows_eq());
-    __syncthreads();                       // B2
   }
   const bool bad = e.r1_bad != 0;
   if (p.button_disturbances && (flags & FLAG_SWITCH_ACTIVE) && !(flags & FLAG_SWITCH_PRESSED)) flags = bp::disturb(p.rng, i, flags);
