@@ -6,7 +6,7 @@
 # into profiles/.
 set -o pipefail
 tag=${1:-r4p}
-part=${2:-all}   # stats | pmc | all (a gpurun call is limited to 20 minutes: run the two halves separately)
+part=${2:-all}   # stats | pmc | art | all (a gpurun call is limited to 20 minutes: run the two halves separately; art = the articulated-gripper lines only)
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -18,6 +18,13 @@ pmc() {  # name, counters (quoted), bench args...
   local name=$1 counters=$2; shift 2
   rocprofv3 --pmc $counters -d $out/pmc_$name -o pmc --output-format csv -- python3 bench.py "$@" > $out/pmc_$name.json 2> $out/pmc_$name.log || echo "pmc $name failed"
 }
+if [ "$part" == "art" ]; then
+stats button_articulated --task robot_push_button --gripper-model articulated --steps 30 --warmup 5
+pmc robot_push_button_articulated_FETCH_SIZE FETCH_SIZE --task robot_push_button --gripper-model articulated --steps 30 --warmup 5 --no-cpu-baseline
+pmc robot_push_button_articulated_WRITE_SIZE WRITE_SIZE --task robot_push_button --gripper-model articulated --steps 30 --warmup 5 --no-cpu-baseline
+ls -R $out | head -20
+exit 0
+fi
 if [ "$part" != "pmc" ]; then
 stats reach --steps 2000 --warmup 200
 stats reach_driver --steps 20 --warmup 5 --no-cpu-baseline
