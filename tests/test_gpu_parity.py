@@ -2252,6 +2252,30 @@ def test_articulated_gripper_follows_move_and_shards(oracle_mod):
     venv.close()
 
 
+def test_articulated_gripper_full_size_matches_oracle(oracle_mod):
+    """BASELINE's batch size for the nv = 14 variant: 4096 envs (16 per workgroup, three wavefronts each: the shape bench.py times) against
+    the oracle for 8 control steps of bench.py's workload (joint targets around the home pose, a new gripper opening every step), and
+    a second handle of 4100 envs (a last workgroup with 4 of its 16 lanes in use) whose first 4096 envs are bitwise the same."""
+    N, T = 4096, 8
+    venv, ob = _art_pair(oracle_mod, N, 5, 0)
+    import mujoco_sim_amd as m
+    odd = m.HipVectorEnv("robot_push_button", N + 4, seed=5, action_type="absolute_joint_action", gripper_model="articulated")
+    venv.reset()
+    odd.reset()
+    ob.reset()
+    rs = np.random.RandomState(3)
+    home = np.array([-1.57, -1.57, 1.57, -1.57, -1.57, 0.0])
+    for t in range(T):
+        a = np.concatenate([home + rs.uniform(-0.2, 0.2, (N + 4, 6)), rs.uniform(0.0, 0.085, (N + 4, 1))], axis=1)
+        venv.step(torch.from_numpy(a[:N]))
+        odd.step(torch.from_numpy(a))
+        o = ob.step(a[:N])
+        _art_compare(t, _gpu_result(venv), o)
+    assert torch.equal(odd.get_state()[:, :N], venv.get_state())
+    venv.close()
+    odd.close()
+
+
 def test_rccl_backend_initialises_and_gathers_a_rollout_block():
     """SCALE was skipped three rounds running, so the first multi-GPU run must not be the first time `nccl` (= RCCL) initialises:
     a fresh child process inits the backend with world size 1 on the one GPU gpurun gives, runs dist.all_gather_into_tensor on a
