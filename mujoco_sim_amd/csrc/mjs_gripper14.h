@@ -129,7 +129,7 @@ struct Contact {
   int zone;            // elliptic cone: 0 top, 1 middle, 2 bottom
   double mu;
 };
-constexpr int TMP_DOUBLES = 382;  // >= 3 x 14 spatial vectors (252); the rest buys rows in LDS (19 of them); its size: the bank rule below
+constexpr int TMP_DOUBLES = 382;  // 19 rows of the constraint problem in LDS; the exact size serves the bank rule below
 struct Env {
   double q[NV], v[NV], ctrl[7], time, warm[NV];
   double sw[3];
@@ -150,8 +150,7 @@ struct Env {
   double sx[NV], sy[NV];  // vector arguments / results of the out-of-line register blocks (pointer arguments would be FLAT + scratch)
   double cost_s;          // cost of the smooth candidate (role 2 -> role 0)
   int r1_bad;   // the integrating wavefront (role 1) saw a non-finite state during this control step
-  // scratch of the stage that is running (the velocity stage's spatial velocities, accelerations and forces, then the first rows of the
-  // constraint problem): kept with the env so that it lives in LDS like the rest
+  // the first LROWS rows of the constraint problem (struct Rows below); no stage uses it as scratch any more
   double tmp[TMP_DOUBLES];
 #ifdef MJS_BG_PROFILE
   double prof1[8];  // role 1's stage clocks (see the kernel)
@@ -166,12 +165,11 @@ struct Env {
 static_assert(sizeof(Env) % 8 == 0 && (sizeof(Env) / 4) % 64 == 34, "Env stride vs the LDS banks");
 #endif
 MJS_HD int tri(int i, int j) { return i * (i + 1) / 2 + j; }
-// Row workspace of one env. The first LROWS rows live in LDS (they alias the env's stage scratch e.tmp: the velocity stage, which
-// needs that scratch, runs BEFORE the rows are made on the same wavefront); a typical substep has 9 - 12 rows (7 equality rows, the
-// couplers' stops, a contact), so the solver's row passes - chains of dependent loads on a wavefront that has its SIMD to itself -
-// mostly stay out of HBM. Rows from LROWS on are in the handle's HBM workspace, CONTIGUOUS per env (ws[env][row][entry]): with 16 of
-// 64 lanes carrying an env a struct-of-arrays layout buys no coalescing, while env-major makes every entry a constant offset from one
-// row pointer. One accessor serves both (the row pointer is a generic one: FLAT loads).
+// Row workspace of one env. The first LROWS rows live in LDS (e.tmp); a typical substep has 9 - 12 rows (7 equality rows, the couplers'
+// stops, a contact), so the solver's row passes - chains of dependent loads on a wavefront that has its SIMD to itself - stay out of
+// HBM. Rows from LROWS on are in the handle's HBM workspace, CONTIGUOUS per env (ws[env][row][entry]): with 16 of 64 lanes carrying an
+// env a struct-of-arrays layout buys no coalescing, while env-major makes every entry a constant offset from one row pointer. One
+// accessor serves both (the row pointer is a generic one: FLAT loads); RowsLds below is the all-LDS case.
 constexpr int LROWS = TMP_DOUBLES / ROW_STRIDE;
 struct Rows {
   double* base;  // the env's rows in HBM
@@ -836,7 +834,7 @@ __device__ __noinline__ void st_velocity() { velocity_stage(g_model, my_env()); 
 MJS_DEV void step1(const Model& m, Env& e, const Rows& w) {
   st_kinematics();
   st_crb();
-  st_velocity();  // (before the rows: it uses the stage scratch the first rows alias)
+  st_velocity();
   st_collision();
   st_rows_eq();
   st_rows_contacts(w.base);
