@@ -1742,6 +1742,22 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
 #pragma unroll
           for (int j = 0; j < NJ; j++) ctrl[j] = q0[j] + (q1[j] - q0[j]) * (t - t0) * inv_span;
           int clamped = actuator_forces(st.q, st.v, ctrl, fdummy);
+#ifndef MJS_RR_SPLIT_FACTOR
+          // M(q) + armature + dt kd -> U D U^T -> U^-1 as ONE generated, list-scheduled block (tools/gen_ur5e_dynamics.py factor_inverse:
+          // the pivot chain runs next to the tail of the CRBA by construction; profiles/r04_g_*)
+          {
+            double dd[NJ], Wp[15];
+#pragma unroll
+            for (int j = 0; j < NJ; j++) dd[j] = MJS_UR_ARMATURE + (((clamped >> j) & 1) ? 0.0 : MJS_RR_PHYSICS_DT * MJS_UR_ACT_KD[j]);
+            ur5e_MW_gen(cs, sn, dd, Wp, Dinv);
+#pragma unroll
+            for (int r = 1; r < NJ; r++) {
+#pragma unroll
+              for (int j = 0; j < r; j++) W[r][j] = Wp[r * (r - 1) / 2 + j];
+            }
+            (void)M; (void)A;
+          }
+#else
           ur5e_M_gen(cs, sn, M);
 #pragma unroll
           for (int r = 0; r < NJ; r++) {
@@ -1750,6 +1766,7 @@ __global__ __launch_bounds__(192) void kernel3(KernelParams p) {
           }
           factor_system(A, clamped, Dinv);
           invert_unit_upper(A, W);
+#endif
 #pragma unroll
           for (int r = 0; r < NJ; r++) {
             asm volatile("" : "+v"(Dinv[r]));

@@ -58,3 +58,21 @@ def test_generated_link_body_invweights_match_generic_engine(oracle_mod, gen_lib
     L.om_debug_link_invweights(task, o.ctypes.data_as(C.c_void_p))
     np.testing.assert_allclose(np.maximum(g, 1e-15)[2:], o[2:], rtol=1e-10)
     assert (o[:2] <= 1e-12).all() and (g[:2] <= 1e-12).all(), (o, g)
+
+
+def test_generated_factor_inverse_block_solves_the_implicit_system(gen_lib):
+    """ur5e_MW_gen (the Robot-Reach role-0 block as one scheduled expression graph: M + dd -> U D U^T -> V = U^-1) with
+    rr::apply_inverse's two mat-vecs equals numpy's solve of (M(q) + diag(dd)) x = b; M from ur5e_M_gen."""
+    rs = np.random.RandomState(11)
+    worst = 0.0
+    for _ in range(200):
+        q = rs.uniform(-3.1, 3.1, 6)
+        dd = 0.1 + rs.uniform(0.0, 1.0, 6) * (rs.uniform(size=6) < 0.7)   # armature + dt * kd of the unclamped actuators
+        b = rs.uniform(-50, 50, 6)
+        x = np.zeros(6)
+        gen_lib.gen_solve(q.ctypes.data_as(C.c_void_p), dd.ctypes.data_as(C.c_void_p), b.ctypes.data_as(C.c_void_p), x.ctypes.data_as(C.c_void_p))
+        Mg, bg = np.zeros(36), np.zeros(6)
+        gen_lib.gen_dynamics(0, q.ctypes.data_as(C.c_void_p), np.zeros(6).ctypes.data_as(C.c_void_p), Mg.ctypes.data_as(C.c_void_p), bg.ctypes.data_as(C.c_void_p))
+        ref = np.linalg.solve(Mg.reshape(6, 6) + np.diag(dd), b)
+        worst = max(worst, np.abs(x - ref).max() / max(1.0, np.abs(ref).max()))
+    assert worst < 1e-11, worst

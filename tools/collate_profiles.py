@@ -63,6 +63,18 @@ def main():
                                   "algorithmic_bytes_per_launch": ALG_BYTES[task] * 4096}
         print(task, "read %.3f MB write %.3f MB per launch (algorithmic %.3f MB)" % (read / 1e6, write / 1e6, ALG_BYTES[task] * 4096 / 1e6))
     json.dump(traffic, open(dst / f"{rnd}_traffic_all_tasks.json", "w"), indent=1)
+    # bench.py replays the COMMITTED traffic figure in its line; the lines of this very run were printed before the figure existed (or
+    # with the previous round's): put this run's figure in, so that the jsonl is self-consistent
+    run_task = {"reach": "robot_reach", "reach_driver": "robot_reach", "pointmass": "point_mass_reach", "button": "robot_push_button",
+                "push": "robot_planar_push", "button_articulated": "robot_push_button_articulated"}
+    fixed = []
+    for l in (dst / f"{rnd}_final_bench_lines.jsonl").read_text().splitlines():
+        d = json.loads(l)
+        t = traffic["tasks"].get(run_task.get(d["run"], ""))
+        if t and d.get("roofline"):
+            d["roofline"]["traffic"] = t["corrected_bytes_per_launch"]["total"]
+        fixed.append(json.dumps(d))
+    (dst / f"{rnd}_final_bench_lines.jsonl").write_text("\n".join(fixed) + "\n")
     vd = src / "pmc_reach_valu"
     vf = find(vd, "counter_collection.csv") if vd.exists() else None
     if vf:

@@ -125,6 +125,12 @@ class V:
 
     __rmul__ = __mul__
 
+    def rcp(self):
+        """reciprocal (the kernels' Newton-refined v_rcp_f64: MJS_GEN_RCP); 1 / (-x) = -(1 / x)"""
+        if self.is_const:
+            return V(1.0 / self.c)
+        return V(None, self.sign, G.node("rcp", self.id))
+
 
 def lift(x):
     return x if isinstance(x, V) else V(float(x))
@@ -398,16 +404,17 @@ def emit(outputs, schedule=None):
         op, a, b = G.nodes[k]
         if op in ("add", "sub", "mul"):
             stack += [a, b]
-        elif op in ("mulc", "addc"):
+        elif op in ("mulc", "addc", "rcp"):
             stack.append(a)
     lines, names = [], {}
-    counts = {"add": 0, "sub": 0, "mul": 0, "mulc": 0, "addc": 0}
+    counts = {"add": 0, "sub": 0, "mul": 0, "mulc": 0, "addc": 0, "rcp": 0}
     order = sorted(needed)
     # VERDICT r3 item 4 (profiles/r04_g_*): a LIST SCHEDULE of the DAG - critical path first, a dependent op at least `lat` slots after
     # its operand - PINNED with a scheduling barrier after every statement, instead of the creation order that the compiler is free
-    # to reschedule. Same-session A/B at 4096 envs: Robot-Reach 35.38 -> 34.91 us (lat 4; lat 1 / 3 / 6 / 9: 35.08 / 35.06 / 34.94 /
-    # 35.87; unpinned list order: no change), but Button-Push 71.2 -> 72.2 us and Planar-Push 1750 -> 1821 us: only the Robot-Reach
-    # variant is emitted this way. GEN_ORDER=list GEN_LATENCY=k GEN_BARRIER=k override it for every variant (experiments).
+    # to reschedule. Same-session A/Bs at 4096 envs: the pinned M / bias blocks of Robot-Reach 35.38 -> 34.91 us (lat 4; lat 1 / 3 / 6
+    # / 9: 35.08 / 35.06 / 34.94 / 35.87; unpinned list order: no change), Button-Push 71.2 -> 72.2 us, Planar-Push 1750 -> 1821 us.
+    # What won in the end is the COMBINED block (factor_inverse below) left to the compiler: 34.52 us with nothing pinned, so no
+    # variant is emitted pinned; GEN_ORDER=list GEN_LATENCY=k GEN_BARRIER=k (all blocks) / GEN_MW_PIN=1 keep the experiment reproducible.
     import os
     if os.environ.get("GEN_ORDER") == "list":
         schedule = (int(os.environ.get("GEN_LATENCY", "2")), int(os.environ.get("GEN_BARRIER", "0")))
@@ -417,25 +424,27 @@ def emit(outputs, schedule=None):
         preds = {}
         for k in needed:
             op, a, b = G.nodes[k]
-            preds[k] = [x for x in ((a, b) if op in ("add", "sub", "mul") else (a,) if op in ("mulc", "addc") else ()) if isinstance(x, int) and x in needed]
+            preds[k] = [x for x in ((a, b) if op in ("add", "sub", "mul") else (a,) if op in ("mulc", "addc", "rcp") else ()) if isinstance(x, int) and x in needed]
         succs = {k: [] for k in needed}
         for k, ps in preds.items():
             for q in ps:
                 succs[q].append(k)
+        rcp_lat = int(os.environ.get("GEN_RCP_LATENCY", "10"))  # a refined reciprocal is a chain of five dependent instructions
+        lat_of = {k: (rcp_lat if G.nodes[k][0] == "rcp" else lat) for k in needed}
         height = {}
         for k in sorted(needed, reverse=True):  # creation order is topological
-            height[k] = 1 + max((height[x] for x in succs[k]), default=0)
+            height[k] = lat_of[k] + max((height[x] for x in succs[k]), default=0)
         done_at, order, slot = {}, [], 0
         remaining = {k: len(set(preds[k])) for k in needed}
         ready = [k for k in needed if remaining[k] == 0]
         while ready:
-            ok = [k for k in ready if all(done_at[q] + lat <= slot for q in preds[k] if G.nodes[q][0] != "sym")]
+            ok = [k for k in ready if all(done_at[q] + lat_of[q] <= slot for q in preds[k] if G.nodes[q][0] != "sym")]
             pick = max(ok or ready, key=lambda k: (height[k], -k))
             ready.remove(pick)
             order.append(pick)
             done_at[pick] = slot
             if G.nodes[pick][0] != "sym":
-                slot += 1
+                slot += 5 if G.nodes[pick][0] == "rcp" else 1  # issue slots of the op itself
             for x in set(succs[pick]):
                 remaining[x] -= 1
                 if remaining[x] == 0:
@@ -456,6 +465,8 @@ def emit(outputs, schedule=None):
             e = f"{names[a]} * {names[b]}"
         elif op == "mulc":
             e = f"{b!r} * {names[a]}"
+        elif op == "rcp":
+            e = f"MJS_GEN_RCP({names[a]})"
         else:
             e = f"{names[a]} + {b!r}"
         lines.append(f"  const double t{k} = {e};")
@@ -488,6 +499,8 @@ def evaluate(vals, env):
             r = ev(a) * ev(b)
         elif op == "mulc":
             r = ev(a) * b
+        elif op == "rcp":
+            r = 1.0 / ev(a)
         else:
             r = ev(a) + b
         memo[k] = r
@@ -564,7 +577,37 @@ def link_body_invweights(M, links):
     return out
 
 
-def emit_variant(prefix, links, uncomp, body_com_local, what, schedule=None):
+def factor_inverse(M):
+    """The role-0 block of the Robot-Reach substep as ONE expression graph: A = M + dd (dd[j] = armature + dt * kd_j of the unclamped
+    actuators, an input), A = U D U^T eliminated from the wrist end, V = U^-1 - literally rr::factor_system + rr::invert_unit_upper
+    (mjs_reach.h) on graph values, so that the list schedule can run the pivot chain next to the tail of the CRBA.
+    Returns (W[j][i] = V(i, j) for i < j, Dinv[j])."""
+    A = [[M[j][i] for i in range(j + 1)] for j in range(NJ)]
+    for j in range(NJ):
+        A[j][j] = A[j][j] + sym(f"dd[{j}]")
+    Dg, Dinv = [None] * NJ, [None] * NJ
+    for j in range(NJ - 1, -1, -1):
+        d = A[j][j]
+        for m in range(j + 1, NJ):
+            d = d - A[m][j] * A[m][j] * Dg[m]
+        Dg[j] = d
+        Dinv[j] = d.rcp()
+        for i in range(j):
+            sv = A[j][i]
+            for m in range(j + 1, NJ):
+                sv = sv - A[m][i] * A[m][j] * Dg[m]
+            A[j][i] = sv * Dinv[j]
+    W = [[None] * NJ for _ in range(NJ)]
+    for j in range(NJ - 1, 0, -1):
+        for i in range(j - 1, -1, -1):
+            sv = A[j][i]
+            for k in range(i + 1, j):
+                sv = sv + A[k][i] * W[j][k]
+            W[j][i] = -sv
+    return W, Dinv
+
+
+def emit_variant(prefix, links, uncomp, body_com_local, what, schedule=None, with_factor=False):
     tau, M = build(links, uncomp)
     out_bias = [(f"bias[{j}]", tau[j]) for j in range(NJ)]
     out_M = [(f"M[{i * (i + 1) // 2 + j}]", M[i][j]) for i in range(NJ) for j in range(i + 1)]
@@ -593,6 +636,21 @@ MJS_DEV void {prefix}_bias_gen(const double* c, const double* s, const double* q
 """ + "\n".join(lb) + """
 }
 """
+    if with_factor:
+        W, Dinv = factor_inverse(M)
+        out_f = [(f"W[{j * (j - 1) // 2 + i}]", W[j][i]) for j in range(1, NJ) for i in range(j)] + [(f"Dinv[{j}]", Dinv[j]) for j in range(NJ)]
+        import os
+        # the combined block in creation order, the compiler free to schedule it: 34.67 us per launch against 34.94 with the pinned
+        # M block + rr::factor_system / invert_unit_upper, and 35.3 - 35.4 with the combined block pinned (GEN_MW_PIN=1;
+        # profiles/r04_g_*): the pivot chain's reciprocals want the compiler's own latency model
+        lf, cf = emit(out_f, schedule if os.environ.get("GEN_MW_PIN") else None)
+        text += f"""
+// M + dd -> U D U^T -> V = U^-1 as one scheduled block (rr::factor_system + rr::invert_unit_upper on the graph): W[j (j - 1) / 2 + i] =
+// V(i, j) for i < j, Dinv[j] = 1 / D_j; dd[j] = joint armature + dt * kd_j for an unclamped actuator
+MJS_DEV void {prefix}_MW_gen(const double* c, const double* s, const double* dd, double* W, double* Dinv) {{  // {sum(cf.values())} ops before FMA fusion
+""" + "\n".join(lf) + """
+}
+"""
     print(f"variant {prefix}: M {nm} ops, bias {nb} ops, eef invweight0 = ({tran:.6g}, {rot:.6g})")
     return text
 
@@ -612,16 +670,24 @@ def main():
 #ifndef MJS_DEV
 #define MJS_DEV __device__ __forceinline__
 #endif
+#ifndef MJS_GEN_RCP  // the kernels' reciprocal: v_rcp_f64 + two Newton steps (rr::rcp_fast); a host build defines 1.0 / x
+#define MJS_GEN_RCP(x) mjs_gen_rcp(x)
+MJS_DEV double mjs_gen_rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+  return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+#endif
 #ifndef MJS_SCHED_PIN  // holds a hand-ordered (list-scheduled) emission against the compiler's scheduler; a host build defines it away
 #define MJS_SCHED_PIN __builtin_amdgcn_sched_barrier(0)
 #endif
 """
     text = header
     links, uncomp = make_links([GRIPPER])
-    text += emit_variant("ur5e", links, uncomp, GRIPPER[1], "Robot-Reach: UR5e + lumped 2F-85 gripper (robot_reach.py:90-95)", schedule=(4, 1))
+    text += emit_variant("ur5e", links, uncomp, GRIPPER[1], "Robot-Reach: UR5e + lumped 2F-85 gripper (robot_reach.py:90-95)", with_factor=True)
     cam = wrist_camera_part()
     links2, uncomp2 = make_links([GRIPPER, cam])
-    text += emit_variant("ur5e_bp", links2, uncomp2, GRIPPER[1], "Button-Push: + wrist-camera geoms' mass at the flange (robot_push_button.py:90-96)")
+    text += emit_variant("ur5e_bp", links2, uncomp2, GRIPPER[1], "Button-Push: + wrist-camera geoms' mass at the flange (robot_push_button.py:90-96)")  # (the combined factor block loses here: 71.08 -> 71.30 us)
     cyl = cylinder_eef_part()
     links3, uncomp3 = make_links([cyl])
     text += emit_variant("ur5e_pp", links3, uncomp3, cyl[1], "Planar-Push: UR5e + CylinderEEF (robot_planar_push.py:81-87)")

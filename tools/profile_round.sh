@@ -6,7 +6,7 @@
 # into profiles/.
 set -o pipefail
 tag=${1:-r4p}
-part=${2:-all}   # stats | pmc | art | all (a gpurun call is limited to 20 minutes: run the two halves separately; art = the articulated-gripper lines only)
+part=${2:-all}   # stats | pmc | art | reach | all (a gpurun call is limited to 20 minutes: run the two halves separately; art = the articulated-gripper lines only)
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
@@ -18,6 +18,14 @@ pmc() {  # name, counters (quoted), bench args...
   local name=$1 counters=$2; shift 2
   rocprofv3 --pmc $counters -d $out/pmc_$name -o pmc --output-format csv -- python3 bench.py "$@" > $out/pmc_$name.json 2> $out/pmc_$name.log || echo "pmc $name failed"
 }
+if [ "$part" == "reach" ]; then
+stats reach --steps 2000 --warmup 200
+stats reach_driver --steps 20 --warmup 5 --no-cpu-baseline
+pmc robot_reach_FETCH_SIZE FETCH_SIZE --task robot_reach --steps 100 --warmup 10 --no-cpu-baseline
+pmc robot_reach_WRITE_SIZE WRITE_SIZE --task robot_reach --steps 100 --warmup 10 --no-cpu-baseline
+pmc reach_valu "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" --steps 100 --warmup 10 --no-cpu-baseline
+exit 0
+fi
 if [ "$part" == "art" ]; then
 stats button_articulated --task robot_push_button --gripper-model articulated --steps 30 --warmup 5
 pmc robot_push_button_articulated_FETCH_SIZE FETCH_SIZE --task robot_push_button --gripper-model articulated --steps 30 --warmup 5 --no-cpu-baseline
