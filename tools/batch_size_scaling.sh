@@ -7,3 +7,4 @@ for n in 4096 16384 65536; do run --task robot_push_button --envs-per-gpu $n --s
 for n in 4096 16384 65536; do run --task robot_planar_push --envs-per-gpu $n --steps 60 --warmup 10; done
 for n in 4096 16384; do run --task robot_planar_push --block-shape box --envs-per-gpu $n --steps 60 --warmup 10; done
 for n in 2048 8192; do run --task robot_push_button --envs-per-gpu $n --visual 64 --steps 100 --warmup 20; done
+for n in 4096 16384 65536; do run --task robot_push_button --gripper-model articulated --envs-per-gpu $n --steps 60 --warmup 10; done
