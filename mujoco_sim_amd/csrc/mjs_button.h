@@ -161,6 +161,22 @@ MJS_DEV WristBox detect_wrist_box(const rr::Chain& ch, V3 sw) {
   box.cat = -1;
   pp::Contact c;
   WristBox w;
+  // Exact reject ahead of the MPR run: the switch box is axis-aligned in the world, and the cylinder's extent along world axis k is
+  // half |a_k| + radius sqrt(1 - a_k^2) (a = its axis). Disjoint boxes mean disjoint geoms, for which the MPR finds no portal and reports
+  // no hit - the same result without its iterations. The bounding-sphere test inside collide_convex alone lets the MPR run whenever
+  // the wrist is within 9 cm of the box, and ONE such lane costs its whole wavefront the run in every substep of the robust path
+  // (profiles/r04_i_*: 150 -> 7x us per row-free control step there).
+  {
+    const V3 a = cyl.R.cz, d = cyl.c - box.c;
+    const double ex = cyl.s.y * fabs(a.x) + cyl.s.x * sqrt(fmax(0.0, 1.0 - a.x * a.x));
+    const double ey = cyl.s.y * fabs(a.y) + cyl.s.x * sqrt(fmax(0.0, 1.0 - a.y * a.y));
+    const double ez = cyl.s.y * fabs(a.z) + cyl.s.x * sqrt(fmax(0.0, 1.0 - a.z * a.z));
+    constexpr double gap = 1e-9;
+    if (fabs(d.x) > ex + MJS_SW_BOX_HALF + gap || fabs(d.y) > ey + MJS_SW_BOX_HALF + gap || fabs(d.z) > ez + MJS_SW_BOX_HALF + gap) {
+      w.hit = false; w.dist = 0.0; w.pos = v3(0, 0, 0); w.nrm = v3(0, 0, 1);
+      return w;
+    }
+  }
   w.hit = pp::collide_convex(cyl, box, 1, 0, 0.0, c);
   w.dist = w.hit ? c.dist : 0.0;
   w.pos = w.hit ? c.pos : v3(0, 0, 0);
